@@ -1,0 +1,72 @@
+"""Case definitions shared by the fixture generator (make_golden.py, build container only) and the tests.
+
+Only inputs are defined here (shapes, seeds, target boxes); expected outputs live in the .npz fixtures.
+"""
+import numpy as np
+import torch
+
+from oracle.graph import Layer as L
+
+MODES = {"ciou": (False, False), "wiou": (True, False), "ciou_nwd": (False, True), "wiou_nwd": (True, True)}
+
+_MODULES = {
+    "conv_k3s1": (L(0, -1, "Conv", 16, 32, dict(k=3, s=1)), [(2, 16, 12, 20)]),
+    "conv_k3s2": (L(0, -1, "Conv", 16, 32, dict(k=3, s=2)), [(2, 16, 13, 21)]),
+    "conv_k1": (L(0, -1, "Conv", 24, 16, dict(k=1, s=1)), [(2, 24, 9, 7)]),
+    "conv_stem": (L(0, -1, "Conv", 3, 16, dict(k=3, s=2)), [(2, 3, 32, 48)]),
+    "c2f_n2_sc": (L(0, -1, "C2f", 32, 32, dict(n=2, shortcut=True)), [(2, 32, 10, 12)]),
+    "c2f_n1": (L(0, -1, "C2f", 48, 32, dict(n=1, shortcut=False)), [(2, 48, 8, 8)]),
+    "sppf": (L(0, -1, "SPPF", 32, 32, dict(k=5)), [(2, 32, 9, 11)]),
+    "scalseq": (L(0, [0, 1, 2], "ScalSeq", [16, 32, 64], 16, {}), [(2, 16, 16, 24), (2, 32, 8, 12), (2, 64, 4, 6)]),
+    "scalseq_conv0": (L(0, [0, 1, 2], "ScalSeq", [32, 32, 64], 16, {}), [(2, 32, 8, 8), (2, 32, 4, 4), (2, 64, 2, 2)]),
+    "zoom_cat": (L(0, [0, 1, 2], "Zoom_cat", [8, 8, 8], 24, {}), [(2, 8, 16, 16), (2, 8, 8, 8), (2, 8, 4, 4)]),
+    "add": (L(0, [0, 1], "Add", [8, 8], 8, {}), [(2, 8, 6, 5), (2, 8, 6, 5)]),
+    "ldconv_n3s2": (L(0, -1, "LDConv", 8, 16, dict(N=3, s=2)), [(2, 8, 13, 17)]),
+    "ldconv_n1s1": (L(0, -1, "LDConv", 16, 8, dict(N=1, s=1)), [(2, 16, 9, 10)]),
+    "ldconv_n5s1": (L(0, -1, "LDConv", 8, 8, dict(N=5, s=1)), [(1, 8, 7, 9)]),
+    "ldconv_stem": (L(0, -1, "LDConv", 3, 16, dict(N=3, s=2)), [(2, 3, 24, 32)]),
+}
+
+
+def module_cases():
+    """name -> (oracle Layer spec, case index).  State seed = 100+ci, input seeds 1000+10*ci+j, gy seed 2000+ci."""
+    return {k: (v[0], ci) for ci, (k, v) in enumerate(_MODULES.items())}
+
+
+def module_shapes():
+    return {k: v[1] for k, v in _MODULES.items()}
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def synth_batch(seed, B, n_per, nc, hw=(64, 64), wh=(0.05, 0.35)):
+    rng = np.random.default_rng(seed)
+    img = torch.from_numpy(rng.random((B, 3, *hw), dtype=np.float32))
+    n = B * n_per
+    bi = torch.arange(B).repeat_interleave(n_per).float()
+    cls = torch.from_numpy(rng.integers(0, nc, (n, 1)).astype(np.float32))
+    w = torch.from_numpy((rng.random((n, 2)) * (wh[1] - wh[0]) + wh[0]).astype(np.float32))
+    xy = torch.from_numpy((rng.random((n, 2)) * 0.7 + 0.15).astype(np.float32))
+    return dict(img=img, batch_idx=bi, cls=cls, bboxes=torch.cat([xy, w], 1))
+
+
+def _boxes(rows):
+    t = torch.tensor(rows, dtype=torch.float32).view(-1, 6)
+    return dict(batch_idx=t[:, 0], cls=t[:, 1:2], bboxes=t[:, 2:6])
+
+
+def loss_cases():
+    """Targets for the loss fixtures: a 3-level 64x64 head (16x16, 8x8, 4x4; strides 4/8/16), nc=6, B=2.
+    Feature seeds: 400 + 10*case_index + level, scale 1.5."""
+    b = synth_batch(300, 2, 5, 6)
+    return {
+        "random5": {k: b[k] for k in ("batch_idx", "cls", "bboxes")},
+        "no_gt": _boxes([]),
+        "one_gt": _boxes([[1, 3, 0.5, 0.5, 0.4, 0.3]]),
+        "overlap": _boxes([[0, 1, 0.50, 0.50, 0.50, 0.50], [0, 2, 0.52, 0.50, 0.48, 0.52], [0, 1, 0.45, 0.55, 0.5, 0.45],
+                           [1, 0, 0.3, 0.3, 0.4, 0.4], [1, 5, 0.32, 0.3, 0.4, 0.42]]),
+        "tiny": _boxes([[0, 4, 0.51, 0.49, 0.01, 0.012], [0, 2, 0.2, 0.8, 0.02, 0.02], [1, 1, 0.7, 0.3, 0.3, 0.3]]),
+        "ragged": _boxes([[0, 0, 0.3, 0.3, 0.2, 0.2]] + [[1, i % 6, 0.1 + 0.08 * i, 0.5, 0.15, 0.2 + 0.02 * i] for i in range(9)]),
+    }

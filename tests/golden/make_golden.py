@@ -1,0 +1,415 @@
+"""Generate the golden fixtures (tests/golden/*.npz) from the REFERENCE implementation.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference ships no tests or vectors for this path, so the oracle is pinned
+by outputs of the reference itself.  Inputs come from numpy PCG64 streams and weights from
+``oracle.graph.fill_state`` (a deterministic fill keyed by parameter name order), so fixtures hold
+inputs + expected outputs only, never weights or reference source.
+"""
+import os
+import sys
+import warnings
+
+warnings.filterwarnings("ignore")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import _refimport  # noqa: E402
+
+_refimport.install()
+
+from types import SimpleNamespace  # noqa: E402
+
+from ultralytics.cfg import get_cfg  # noqa: E402
+from ultralytics.engine.trainer import BaseTrainer  # noqa: E402
+from ultralytics.nn.extra_modules.block import Add, ScalSeq, Zoom_cat  # noqa: E402
+from ultralytics.nn.modules import SPPF, C2f, Conv, Detect, LDConv  # noqa: E402
+from ultralytics.nn.tasks import DetectionModel  # noqa: E402
+from ultralytics.utils import DEFAULT_CFG, ops  # noqa: E402
+from ultralytics.utils.loss import v8DetectionLoss  # noqa: E402
+from ultralytics.utils.metrics import WiseIouLoss  # noqa: E402
+from ultralytics.utils.torch_utils import ModelEMA, initialize_weights  # noqa: E402
+
+from oracle import graph as og  # noqa: E402
+from cases import MODES, loss_cases, module_cases, module_shapes, rnd, synth_batch  # noqa: E402
+
+CFG_DIR = os.path.join(_refimport.REF, "ultralytics/cfg/models")
+torch.set_num_threads(8)
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  ({len(out)} arrays)")
+
+
+def load_filled(module, layer, seed, prefix="model.0."):
+    """Fill a reference module with the shared deterministic state for a one-layer oracle graph."""
+    g = og.Graph([layer], [], layer.args.get("nc", 0), 0, "", [], {})
+    sd = og.fill_state(og.state_layout(g), seed)
+    sd = {k[len(prefix):]: v for k, v in sd.items()}
+    initialize_weights(module)  # BN eps/momentum exactly as DetectionModel.__init__ does
+    module.load_state_dict(sd, strict=True)
+    return module
+
+
+# ----------------------------------------------------------------------------- A. modules
+REF_CTORS = {
+    "conv_k3s1": lambda: Conv(16, 32, 3, 1), "conv_k3s2": lambda: Conv(16, 32, 3, 2), "conv_k1": lambda: Conv(24, 16, 1, 1),
+    "conv_stem": lambda: Conv(3, 16, 3, 2), "c2f_n2_sc": lambda: C2f(32, 32, 2, True), "c2f_n1": lambda: C2f(48, 32, 1, False),
+    "sppf": lambda: SPPF(32, 32, 5), "scalseq": lambda: ScalSeq([16, 32, 64], 16), "scalseq_conv0": lambda: ScalSeq([32, 32, 64], 16),
+    "zoom_cat": lambda: Zoom_cat(), "add": lambda: Add(), "ldconv_n3s2": lambda: LDConv(8, 16, 3, 2),
+    "ldconv_n1s1": lambda: LDConv(16, 8, 1, 1), "ldconv_n5s1": lambda: LDConv(8, 8, 5, 1), "ldconv_stem": lambda: LDConv(3, 16, 3, 2),
+}
+
+
+def gen_modules():
+    arrs = {}
+    for name, (layer, ci) in module_cases().items():
+        shapes = module_shapes()[name]
+        torch.manual_seed(0)
+        m = load_filled(REF_CTORS[name](), layer, seed=100 + ci).train()
+        xs = [rnd(1000 + 10 * ci + j, *s).requires_grad_(True) for j, s in enumerate(shapes)]
+        y = m(xs[0] if len(xs) == 1 else list(xs))
+        gy = rnd(2000 + ci, *y.shape)
+        y.backward(gy)
+        arrs[f"{name}/y"] = y
+        arrs[f"{name}/gy"] = gy
+        for j, x in enumerate(xs):
+            arrs[f"{name}/x{j}"] = x
+            arrs[f"{name}/gx{j}"] = x.grad
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                arrs[f"{name}/gp/{k}"] = p.grad
+        for k, b in m.named_buffers():
+            if "running" in k:
+                arrs[f"{name}/buf/{k}"] = b
+        # eval-mode output with the (now updated) running statistics
+        m.eval()
+        with torch.no_grad():
+            arrs[f"{name}/y_eval"] = m(xs[0].detach() if len(xs) == 1 else [x.detach() for x in xs])
+    # Detect: train list + eval decode
+    layer = og.Layer(0, [0, 1, 2], "Detect", [16, 32, 64], 70, dict(nc=6))
+    det = load_filled(Detect(6, (16, 32, 64)), layer, seed=150)
+    det.stride = torch.tensor([4.0, 8.0, 16.0])
+    xs = [rnd(3000 + j, *s).requires_grad_(True) for j, s in enumerate([(2, 16, 8, 12), (2, 32, 4, 6), (2, 64, 2, 3)])]
+    det.train()
+    outs = det(list(xs))
+    gys = [rnd(3100 + j, *o.shape) for j, o in enumerate(outs)]
+    torch.autograd.backward(outs, gys)
+    for j in range(3):
+        arrs[f"detect/x{j}"], arrs[f"detect/gx{j}"] = xs[j], xs[j].grad
+        arrs[f"detect/y{j}"], arrs[f"detect/gy{j}"] = outs[j], gys[j]
+    for k, p in det.named_parameters():
+        if p.grad is not None:
+            arrs[f"detect/gp/{k}"] = p.grad
+    det.eval()
+    with torch.no_grad():
+        y, feats = det([x.detach() for x in xs])
+    arrs["detect/y_eval"] = y
+    npz("modules", **arrs)
+
+
+# ----------------------------------------------------------------------------- B. whole models
+def set_mode(model, wiou, nwd):
+    crit = model.criterion
+    crit.bbox_loss.use_wiseiou = wiou
+    crit.bbox_loss.nwd_loss = nwd
+    if wiou:
+        crit.bbox_loss.wiou_loss = WiseIouLoss(ltype="WIoU", monotonous=False, inner_iou=False, focaler_iou=False)
+
+
+
+
+def gen_models():
+    arrs = {}
+    for mi, name in enumerate(["yolov8n-ASF-P2P2", "yolov8n-LD-P2", "yolov8n-ASF-P2", "yolov8n-p2"]):
+        torch.manual_seed(0)
+        m = DetectionModel(os.path.join(CFG_DIR, name + ".yaml"), ch=3, verbose=False)
+        m.args = get_cfg(DEFAULT_CFG)
+        g = og.build_graph(og.load_yaml(os.path.join(CFG_DIR, name + ".yaml")))
+        layout = og.state_layout(g)
+        keys = list(m.state_dict().keys())
+        assert keys == list(layout.keys()), (name, [k for k in keys if k not in layout][:5], [k for k in layout if k not in keys][:5])
+        arrs[f"{name}/n_params"] = sum(p.numel() for p in m.parameters())
+        arrs[f"{name}/stride"] = m.stride
+        arrs[f"{name}/keys"] = np.array(keys)
+        arrs[f"{name}/shapes"] = np.array([str(tuple(v.shape)) for v in m.state_dict().values()])
+        # reference-initialised Detect biases and BN hyper-parameters (bias_init / initialize_weights)
+        sd0 = m.state_dict()
+        det = f"model.{len(m.model) - 1}"
+        arrs[f"{name}/init_cls_bias"] = torch.stack([sd0[f"{det}.cv3.{l}.2.bias"] for l in range(len(m.stride))])
+        m.load_state_dict(og.fill_state(layout, seed=7 + mi), strict=True)
+        batch = synth_batch(50 + mi, 2, 4, g.nc)
+        arrs[f"{name}/img"] = batch["img"]
+        for k in ("batch_idx", "cls", "bboxes"):
+            arrs[f"{name}/{k}"] = batch[k]
+        m.train()
+        # per-layer outputs (train mode, batch statistics)
+        ys, x = [], batch["img"]
+        sd_before = {k: v.clone() for k, v in m.state_dict().items()}
+        for layer in m.model:
+            if layer.f != -1:
+                x = ys[layer.f] if isinstance(layer.f, int) else [x if j == -1 else ys[j] for j in layer.f]
+            x = layer(x)
+            ys.append(x)
+        for i, y in enumerate(ys[:-1]):
+            arrs[f"{name}/layer{i}"] = y.detach().to(torch.float16)  # fp16 storage: 2e-3 tolerance layer dump
+        for l, f in enumerate(ys[-1]):
+            arrs[f"{name}/feat{l}"] = f.detach()
+        m.load_state_dict(sd_before)
+        if name in ("yolov8n-ASF-P2P2", "yolov8n-LD-P2"):
+            for mode, (wiou, nwd) in MODES.items():
+                m.load_state_dict(sd_before)
+                m.zero_grad()
+                if hasattr(m, "criterion"):
+                    del m.criterion
+                m.criterion = m.init_criterion()
+                set_mode(m, wiou, nwd)
+                loss, items = m(batch)
+                loss.backward()
+                arrs[f"{name}/{mode}/loss"] = loss.detach()
+                arrs[f"{name}/{mode}/items"] = items
+                gn = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+                arrs[f"{name}/{mode}/grad_names"] = np.array(list(gn.keys()))
+                arrs[f"{name}/{mode}/grad_l2"] = torch.stack([v.norm() for v in gn.values()])
+                arrs[f"{name}/{mode}/grad_sum"] = torch.stack([v.sum() for v in gn.values()])
+                if mode == "ciou":
+                    first = next(iter(gn))
+                    arrs[f"{name}/{mode}/grad_first"] = gn[first]
+                    sdm = m.state_dict()
+                    rm = [k for k in sdm if k.endswith("running_mean")]
+                    arrs[f"{name}/run_mean_names"] = np.array(rm)
+                    arrs[f"{name}/run_mean_sum"] = torch.stack([sdm[k].sum() for k in rm])
+                    arrs[f"{name}/run_var_sum"] = torch.stack([sdm[k.replace("mean", "var")].sum() for k in rm])
+        # eval + fused eval
+        m.load_state_dict(sd_before)
+        m.eval()
+        with torch.no_grad():
+            y, _ = m(batch["img"])
+            arrs[f"{name}/y_eval"] = y
+            m.fuse(verbose=False)
+            yf, _ = m(batch["img"])
+            arrs[f"{name}/y_eval_fused"] = yf
+            arrs[f"{name}/n_params_fused"] = sum(p.numel() for p in m.parameters())
+    npz("models", **arrs)
+
+
+# ----------------------------------------------------------------------------- C. loss
+class _FakeModel(torch.nn.Module):
+    def __init__(self, nc, strides):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(1))
+        self.args = get_cfg(DEFAULT_CFG)
+        self.model = [SimpleNamespace(stride=torch.tensor(strides), nc=nc, no=nc + 64, reg_max=16)]
+
+
+def gen_loss():
+    arrs = {}
+    shapes = [(16, 16), (8, 8), (4, 4)]
+    for ci, (name, tg) in enumerate(loss_cases().items()):
+        for mode, (wiou, nwd) in MODES.items():
+            crit = v8DetectionLoss(_FakeModel(6, [4.0, 8.0, 16.0]))
+            crit.bbox_loss.use_wiseiou, crit.bbox_loss.nwd_loss = wiou, nwd
+            if wiou:
+                crit.bbox_loss.wiou_loss = WiseIouLoss(ltype="WIoU", monotonous=False, inner_iou=False, focaler_iou=False)
+            feats = [rnd(400 + 10 * ci + l, 2, 70, *s, scale=1.5).requires_grad_(True) for l, s in enumerate(shapes)]
+            batch = dict(tg)
+            captured = {}
+            orig = crit.assigner.forward
+
+            def spy(*a, **k):
+                out = orig(*a, **k)
+                captured["asg"] = out
+                return out
+
+            crit.assigner.forward = spy
+            n_calls = 3 if (wiou and name == "random5") else 1
+            for call in range(n_calls):
+                for f in feats:
+                    f.grad = None
+                loss, items = crit([f for f in feats], batch)
+                loss.backward()
+                tag = f"{name}/{mode}" + (f"/call{call}" if n_calls > 1 else "")
+                arrs[f"{tag}/loss"], arrs[f"{tag}/items"] = loss.detach(), items
+                for l, f in enumerate(feats):
+                    arrs[f"{tag}/gfeat{l}"] = f.grad if f.grad is not None else torch.zeros_like(f)
+                if wiou:
+                    arrs[f"{tag}/iou_mean"] = crit.bbox_loss.wiou_loss.iou_mean.clone()
+            if mode == "ciou":
+                for l, f in enumerate(feats):
+                    arrs[f"{name}/feat{l}"] = f
+                for k, v in tg.items():
+                    arrs[f"{name}/{k}"] = v
+                tl, tb, ts, fg, tgi = captured["asg"]
+                arrs[f"{name}/target_labels"] = tl
+                arrs[f"{name}/target_bboxes"] = tb
+                arrs[f"{name}/target_scores"] = ts
+                arrs[f"{name}/fg_mask"] = fg
+                arrs[f"{name}/target_gt_idx"] = tgi
+    npz("loss", **arrs)
+
+
+# ----------------------------------------------------------------------------- D. decode + NMS
+def gen_nms():
+    arrs = {}
+    rng = np.random.default_rng(77)
+    # raw soft_nms on hand-made candidate sets
+    def case(name, boxes, scores, thr=0.7):
+        b, s = torch.tensor(boxes, dtype=torch.float32).view(-1, 4), torch.tensor(scores, dtype=torch.float32)
+        arrs[f"soft/{name}/boxes"], arrs[f"soft/{name}/scores_in"] = b.clone(), s.clone()
+        keep = ops.soft_nms(b, s, thr)
+        arrs[f"soft/{name}/keep"], arrs[f"soft/{name}/scores_out"], arrs[f"soft/{name}/thr"] = keep, s, thr
+
+    case("n0", [], [])
+    case("n1", [[0, 0, 10, 10]], [0.9])
+    case("n2_disjoint", [[0, 0, 10, 10], [20, 20, 30, 30]], [0.5, 0.9])
+    case("n2_overlap", [[0, 0, 10, 10], [1, 1, 11, 11]], [0.9, 0.8], 0.5)
+    case("n3_chain", [[0, 0, 10, 10], [1, 0, 11, 10], [2, 0, 12, 10]], [0.6, 0.9, 0.7], 0.5)
+    case("first_not_top", [[0, 0, 10, 10], [50, 50, 60, 60], [0.5, 0, 10.5, 10], [51, 50, 61, 60]], [0.3, 0.95, 0.9, 0.5], 0.5)
+    # borderline decay: iou just above threshold, score*exp(-iou^2/0.5) close to 0.25
+    case("borderline", [[0, 0, 10, 10], [0, 0, 10, 9.1], [0, 0, 10, 7.2], [30, 30, 40, 40]], [0.9, 0.9, 0.4436, 0.3], 0.7)
+    n = 400
+    xy = rng.random((n, 2)) * 80
+    wh = rng.random((n, 2)) * 25 + 5
+    case("random400", np.concatenate([xy, xy + wh], 1), rng.random(n) * 0.75 + 0.25, 0.7)
+    n = 1500
+    xy = rng.random((n, 2)) * 200
+    wh = rng.random((n, 2)) * 40 + 8
+    case("random1500", np.concatenate([xy, xy + wh], 1), rng.random(n) * 0.7 + 0.3, 0.7)
+    # full non_max_suppression on a synthetic (B, 4+nc, A) prediction
+    B, nc, A = 2, 6, 1344
+    ctr = rng.random((B, 2, A)) * 64
+    whp = rng.random((B, 2, A)) * 20 + 4
+    cls = rng.random((B, nc, A)) ** 6  # mostly small, a few confident
+    pred = torch.from_numpy(np.concatenate([ctr, whp, cls], 1).astype(np.float32))
+    arrs["nms/pred"] = pred
+    for tag, kw in {"predict": dict(conf_thres=0.25, iou_thres=0.7, max_det=300),
+                    "val": dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300),
+                    "agnostic": dict(conf_thres=0.25, iou_thres=0.45, agnostic=True, max_det=300),
+                    "classes": dict(conf_thres=0.2, iou_thres=0.6, classes=[1, 4], max_det=20)}.items():
+        out = ops.non_max_suppression(pred.clone(), **kw)
+        for i, o in enumerate(out):
+            arrs[f"nms/{tag}/img{i}"] = o
+    npz("nms", **arrs)
+
+
+# ----------------------------------------------------------------------------- E. trainer micro-trace
+def gen_trainer():
+    """5 iterations of the reference's own optimizer_step/build_optimizer/ModelEMA on DEAL-YOLO-N 64x64,
+    batch 2, driven exactly as engine/trainer.py:780-815 does (warm-up interpolation, loss, backward, step)."""
+    arrs = {}
+    name = "yolov8n-ASF-P2P2"
+    for opt_name in ("SGD", "AdamW"):
+        torch.manual_seed(0)
+        m = DetectionModel(os.path.join(CFG_DIR, name + ".yaml"), ch=3, verbose=False)
+        args = get_cfg(DEFAULT_CFG)
+        m.args = args
+        g = og.build_graph(og.load_yaml(os.path.join(CFG_DIR, name + ".yaml")))
+        m.load_state_dict(og.fill_state(og.state_layout(g), seed=11), strict=True)
+        for k, v in m.named_parameters():
+            v.requires_grad = ".dfl" not in k
+        bs, nb, epochs = 2, 8, 100
+        fake = SimpleNamespace(args=args, model=m)
+        accumulate = max(round(args.nbs / bs), 1)
+        wd = args.weight_decay * bs * accumulate / args.nbs
+        lr0 = args.lr0 if opt_name == "SGD" else 0.001
+        fake.optimizer = BaseTrainer.build_optimizer(fake, model=m, name=opt_name, lr=lr0, momentum=args.momentum, decay=wd)
+        fake.scaler = torch.cuda.amp.GradScaler(enabled=False)
+        fake.ema = ModelEMA(m)
+        lf = lambda x: max(1 - x / epochs, 0) * (1.0 - args.lrf) + args.lrf  # noqa: E731
+        for pg in fake.optimizer.param_groups:
+            pg["initial_lr"] = pg["lr"]
+        nw = max(round(args.warmup_epochs * nb), 100)
+        last_opt_step = -1
+        m.train()
+        trace = []
+        for ni in range(5):
+            xi = [0, nw]
+            accumulate = max(1, int(np.interp(ni, xi, [1, args.nbs / bs]).round()))
+            for j, x in enumerate(fake.optimizer.param_groups):
+                x["lr"] = np.interp(ni, xi, [args.warmup_bias_lr if j == 0 else 0.0, x["initial_lr"] * lf(0)])
+                if "momentum" in x:
+                    x["momentum"] = np.interp(ni, xi, [args.warmup_momentum, args.momentum])
+            batch = synth_batch(900 + ni, bs, 4, g.nc)
+            loss, items = m(batch)
+            loss.backward()
+            gnorm = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in m.parameters() if p.grad is not None))
+            stepped = 0
+            if ni - last_opt_step >= accumulate:
+                BaseTrainer.optimizer_step(fake)
+                last_opt_step = ni
+                stepped = 1
+            sd = m.state_dict()
+            esd = fake.ema.ema.state_dict()
+            trace.append([float(loss), *[float(v) for v in items], float(gnorm), stepped,
+                          *[float(pg["lr"]) for pg in fake.optimizer.param_groups],
+                          float(sum(v.double().sum() for k, v in sd.items() if v.dtype.is_floating_point)),
+                          float(sum(v.double().abs().sum() for k, v in sd.items() if v.dtype.is_floating_point)),
+                          float(sum(v.double().abs().sum() for k, v in esd.items() if v.dtype.is_floating_point))])
+        arrs[f"{opt_name}/trace"] = np.array(trace, dtype=np.float64)
+        arrs[f"{opt_name}/final_w0"] = m.state_dict()["model.0.conv.weight"]
+        arrs[f"{opt_name}/final_bn22"] = m.state_dict()["model.22.cv2.bn.weight"] if "model.22.cv2.bn.weight" in m.state_dict() else m.state_dict()["model.23.cv2.bn.weight"]
+        arrs[f"{opt_name}/final_bias"] = m.state_dict()["model.26.cv3.0.2.bias"]
+        arrs[f"{opt_name}/ema_w0"] = fake.ema.ema.state_dict()["model.0.conv.weight"]
+        arrs[f"{opt_name}/group_sizes"] = np.array([len(pg["params"]) for pg in fake.optimizer.param_groups])
+    arrs["trace_columns"] = np.array(["loss", "box", "cls", "dfl", "grad_norm", "stepped", "lr_bias", "lr_w", "lr_bn",
+                                      "sum_state", "abs_state", "abs_ema"])
+    npz("trainer", **arrs)
+
+
+# ----------------------------------------------------------------------------- F. full-size scalars
+def gen_fullsize():
+    arrs = {}
+    for mi, name in enumerate(["yolov8n-ASF-P2P2", "yolov8n-LD-P2"]):
+        m = DetectionModel(os.path.join(CFG_DIR, name + ".yaml"), ch=3, verbose=False)
+        m.args = get_cfg(DEFAULT_CFG)
+        g = og.build_graph(og.load_yaml(os.path.join(CFG_DIR, name + ".yaml")))
+        m.load_state_dict(og.fill_state(og.state_layout(g), seed=21 + mi), strict=True)
+        m.train()
+        sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+        # SURVEY.md 8(d) synthetic recipe: 8 boxes/img, wh in [0.01,0.09), xy in [0.1,0.9)
+        rng = np.random.default_rng(5 + mi)
+        B, nb = 2, 8
+        batch = dict(img=torch.from_numpy(rng.random((B, 3, 640, 640), dtype=np.float32)),
+                     batch_idx=torch.arange(B).repeat_interleave(nb).float(),
+                     cls=torch.from_numpy(rng.integers(0, 6, (B * nb, 1)).astype(np.float32)),
+                     bboxes=torch.from_numpy(np.concatenate([rng.random((B * nb, 2)) * 0.8 + 0.1,
+                                                             rng.random((B * nb, 2)) * 0.08 + 0.01], 1).astype(np.float32)))
+        for k in ("batch_idx", "cls", "bboxes"):
+            arrs[f"{name}/{k}"] = batch[k]
+        arrs[f"{name}/img_seed"] = 5 + mi
+        for mode, (wiou, nwd) in MODES.items():
+            m.load_state_dict(sd0)
+            m.zero_grad()
+            if hasattr(m, "criterion"):
+                del m.criterion
+            m.criterion = m.init_criterion()
+            set_mode(m, wiou, nwd)
+            loss, items = m(batch)
+            arrs[f"{name}/{mode}/loss"], arrs[f"{name}/{mode}/items"] = loss.detach(), items
+            if mode == "ciou":
+                loss.backward()
+                gn = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+                arrs[f"{name}/grad_names"] = np.array(list(gn.keys()))
+                arrs[f"{name}/grad_l2"] = torch.stack([v.norm() for v in gn.values()])
+    npz("fullsize", **arrs)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["modules", "models", "loss", "nms", "trainer", "fullsize"]
+    for w in which:
+        globals()["gen_" + w]()
