@@ -1,0 +1,307 @@
+// BatchNorm (training statistics / affine apply) + activation, forward and backward, for NHWC fp16 tensors.
+//
+// Replaces the ATen batch_norm + silu_ / leaky_relu launches behind Conv.forward (reference
+// nn/modules/conv.py:49-55; eps 1e-3 / momentum 0.03 from utils/torch_utils.py:347-349) and their autograd
+// backward.  Statistics arrive as per-workgroup partial sums written by the conv epilogue, so the raw conv
+// output is never re-read just to be averaged.  HBM-bound: every kernel moves 16 bytes per lane.
+#include "common.h"
+#include "dealyolo_hip.h"
+
+// ---------------------------------------------------------------------------------------------- finalize
+struct BnFinArgs {
+  const float* part[3];  // up to three partial sets [P][2][C] (ScalSeq sums three resolutions)
+  int nparts[3];
+  float pweight[3];
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float* coef;  // [4][C]: scale, shift, mean, invstd
+  int C;
+  float count, eps, momentum;
+  int update_running;
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    if (!a.part[k]) continue;
+    double t1 = 0.0, t2 = 0.0;
+    for (int i = tid; i < a.nparts[k]; i += 256) {
+      t1 += a.part[k][((size_t)i * 2 + 0) * a.C + c];
+      t2 += a.part[k][((size_t)i * 2 + 1) * a.C + c];
+    }
+    s1 += t1 * a.pweight[k];
+    s2 += t2 * a.pweight[k];
+  }
+  __shared__ double r1[256], r2[256];
+  r1[tid] = s1;
+  r2[tid] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      r1[tid] += r1[tid + o];
+      r2[tid] += r2[tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double mean = r1[0] / a.count;
+    double var = r2[0] / a.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float sc = a.gamma[c] * invstd;
+    a.coef[0 * a.C + c] = sc;
+    a.coef[1 * a.C + c] = a.beta[c] - (float)mean * sc;
+    a.coef[2 * a.C + c] = (float)mean;
+    a.coef[3 * a.C + c] = invstd;
+    if (a.update_running) {
+      const double unbiased = a.count > 1.f ? var * a.count / (a.count - 1.0) : var;
+      a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+      a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+    }
+  }
+}
+
+extern "C" int dy_bn_finalize(const float* p0, int n0, float w0, const float* p1, int n1, float w1, const float* p2,
+                              int n2, float w2, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float* coef, int C, float count, float eps, float momentum,
+                              int update_running, hipStream_t stream) {
+  BnFinArgs a{{p0, p1, p2}, {n0, n1, n2}, {w0, w1, w2}, gamma, beta, running_mean, running_var, coef, C, count, eps,
+              momentum, update_running};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// coefficients from running statistics (eval mode, unfused BN)
+__global__ void bn_eval_coef_kernel(const float* g, const float* b, const float* rm, const float* rv, float* coef, int C,
+                                    float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rv[c] + eps), sc = g[c] * invstd;
+  coef[c] = sc;
+  coef[C + c] = b[c] - rm[c] * sc;
+  coef[2 * C + c] = rm[c];
+  coef[3 * C + c] = invstd;
+}
+extern "C" int dy_bn_eval_coef(const float* gamma, const float* beta, const float* rm, const float* rv, float* coef,
+                               int C, float eps, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, gamma, beta, rm, rv, coef, C, eps);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- apply (forward)
+static __device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == DY_ACT_SILU) return silu_f(z);
+  if (act == DY_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
+  return z;
+}
+static __device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == DY_ACT_SILU) {
+    const float s = sigmoid_f(z);
+    return s * (1.f + z * (1.f - s));
+  }
+  if (act == DY_ACT_LEAKY) return z > 0.f ? 1.f : 0.1f;
+  return 1.f;
+}
+
+struct ApplyArgs {
+  const f16* x;
+  const f16* res;  // optional residual added AFTER the activation (Bottleneck shortcut)
+  f16* y;
+  const float* coef;
+  int ldx, ldr, ldy, C, act;
+  long npix;
+};
+
+__global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a) {
+  const int cpp = a.C >> 3;
+  const long total = a.npix * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int part = (int)(idx - pix * cpp), c0 = part * 8;
+    const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
+    half8 rv;
+    if (a.res) rv = *reinterpret_cast<const half8*>(a.res + pix * a.ldr + c0);
+    half8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float z = (float)xv[j] * a.coef[c0 + j] + a.coef[a.C + c0 + j];
+      z = act_fwd(z, a.act);
+      if (a.res) z += (float)rv[j];
+      out[j] = (f16)z;
+    }
+    *reinterpret_cast<half8*>(a.y + pix * a.ldy + c0) = out;
+  }
+}
+
+extern "C" int dy_bn_act_apply(const void* x, int ldx, const void* res, int ldr, void* y, int ldy, const float* coef,
+                               long npix, int C, int act, hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (ldy & 7) || (res && (ldr & 7))) return DY_ERR_ALIGN;
+  ApplyArgs a{(const f16*)x, (const f16*)res, (f16*)y, coef, ldx, ldr, ldy, C, act, npix};
+  long blocks = (npix * (C >> 3) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(bn_act_apply_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+// pass 1: per-channel partial sums of g = dy * act'(z) and g * xhat
+struct BwdRedArgs {
+  const f16* dy;
+  const f16* x;
+  const float* coef;
+  float* partials;  // [gridDim.x][2][C]
+  int lddy, ldx, C, act;
+  long npix;
+};
+
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
+  const int cpp = a.C >> 3, rows = 256 / cpp, tid = threadIdx.x;
+  const int part = tid % cpp, row = tid / cpp, c0 = part * 8;
+  float sg[8], sgx[8], sc[8], sh[8], mean[8], inv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sg[j] = sgx[j] = 0.f;
+    sc[j] = a.coef[c0 + j];
+    sh[j] = a.coef[a.C + c0 + j];
+    mean[j] = a.coef[2 * a.C + c0 + j];
+    inv[j] = a.coef[3 * a.C + c0 + j];
+  }
+  if (row < rows) {
+    for (long pix = (long)blockIdx.x * rows + row; pix < a.npix; pix += (long)gridDim.x * rows) {
+      const half8 dv = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0);
+      const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xf = (float)xv[j];
+        const float g = (float)dv[j] * act_grad(xf * sc[j] + sh[j], a.act);
+        sg[j] += g;
+        sgx[j] += g * (xf - mean[j]) * inv[j];
+      }
+    }
+  }
+  __shared__ float red[2][256][8 + 1];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[0][tid][j] = sg[j];
+    red[1][tid][j] = sgx[j];
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * a.C; i += 256) {
+    const int which = i / a.C, c = i - which * a.C, pp = c >> 3, j = c & 7;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += red[which][r * cpp + pp][j];
+    a.partials[((size_t)blockIdx.x * 2 + which) * a.C + c] = s;
+  }
+}
+
+extern "C" int dy_bn_act_bwd_reduce(const void* dy, int lddy, const void* x, int ldx, const float* coef,
+                                    float* partials, int max_partials, long npix, int C, int act, int* nparts,
+                                    hipStream_t stream) {
+  if ((C & 7) || C > 2048 || (ldx & 7) || (lddy & 7)) return DY_ERR_ALIGN;
+  const int cpp = C >> 3;
+  if (cpp > 256) return DY_ERR_ARG;
+  const int rows = 256 / cpp;
+  long blocks = (npix + (long)rows * 8 - 1) / ((long)rows * 8);
+  if (blocks > max_partials) blocks = max_partials;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (nparts) *nparts = (int)blocks;
+  BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, partials, lddy, ldx, C, act, npix};
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// pass 1b: reduce partials -> dgamma, dbeta (fp32 grads, scaled by the loss scale like every gradient) and the two
+// per-channel means pass 2 needs.  bwdcoef = [2][C]: mean_g, mean_gxhat.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partials, int nparts, float* dgamma,
+                                                              float* dbeta, float* bwdcoef, int C, float count,
+                                                              int accumulate) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = tid; i < nparts; i += 256) {
+    s1 += partials[((size_t)i * 2 + 0) * C + c];
+    s2 += partials[((size_t)i * 2 + 1) * C + c];
+  }
+  __shared__ double r1[256], r2[256];
+  r1[tid] = s1;
+  r2[tid] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      r1[tid] += r1[tid + o];
+      r2[tid] += r2[tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)r1[0];
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)r2[0];
+    bwdcoef[c] = (float)(r1[0] / count);
+    bwdcoef[C + c] = (float)(r2[0] / count);
+  }
+}
+
+extern "C" int dy_bn_bwd_finalize(const float* partials, int nparts, float* dgamma, float* dbeta, float* bwdcoef, int C,
+                                  float count, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, partials, nparts, dgamma, dbeta, bwdcoef, C,
+                     count, accumulate);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// pass 2: dx_raw = scale * (g - mean_g - xhat * mean_gxhat); optional second output: residual gradient pass-through
+struct BwdApplyArgs {
+  const f16* dy;
+  const f16* x;
+  f16* dx;
+  const float* coef;
+  const float* bwdcoef;
+  int lddy, ldx, lddx, C, act, frozen_stats;
+  long npix;
+};
+
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BwdApplyArgs a) {
+  const int cpp = a.C >> 3;
+  const long total = a.npix * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int part = (int)(idx - pix * cpp), c0 = part * 8;
+    const half8 dv = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0);
+    const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
+    half8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      const float sc = a.coef[c], xf = (float)xv[j];
+      const float g = (float)dv[j] * act_grad(xf * sc + a.coef[a.C + c], a.act);
+      float r = g;
+      if (!a.frozen_stats) {
+        const float xh = (xf - a.coef[2 * a.C + c]) * a.coef[3 * a.C + c];
+        r = g - a.bwdcoef[c] - xh * a.bwdcoef[a.C + c];
+      }
+      out[j] = (f16)(sc * r);
+    }
+    *reinterpret_cast<half8*>(a.dx + pix * a.lddx + c0) = out;
+  }
+}
+
+extern "C" int dy_bn_act_bwd_apply(const void* dy, int lddy, const void* x, int ldx, void* dx, int lddx,
+                                   const float* coef, const float* bwdcoef, long npix, int C, int act, int frozen_stats,
+                                   hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7)) return DY_ERR_ALIGN;
+  BwdApplyArgs a{(const f16*)dy, (const f16*)x, (f16*)dx, coef, bwdcoef, lddy, ldx, lddx, C, act, frozen_stats, npix};
+  long blocks = (npix * (C >> 3) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}

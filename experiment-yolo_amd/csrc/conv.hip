@@ -1,0 +1,372 @@
+// Implicit-GEMM convolution on MFMA (v_mfma_f32_16x16x32_f16) for NHWC fp16 activations.
+//
+// Replaces the ATen sequence of Conv.forward (reference nn/modules/conv.py:49-55): conv2d -> (stats for)
+// BatchNorm2d -> SiLU, and -- with transposed/flipped packed weights -- the input-gradient half of
+// convolution_backward.  GEMM orientation is M = Cout (A = packed weights, straight from L2), N = pixels
+// (B = activation halo tile staged in LDS), K = taps x Cin flattened in 8-channel granules, so each lane ends
+// up holding 4*MT *contiguous* output channels of one pixel and stores them with one or two 16-byte writes.
+#include "common.h"
+#include "dealyolo_hip.h"
+
+struct ConvArgs {
+  const f16* x;
+  const f16* w;
+  const float* bias;
+  void* y;
+  float* partials;
+  int ldx, ldy;
+  int N, H, W;    // (virtual) input extent used for bounds
+  int Hr, Wr;     // real input extent (== H, W unless dil == 2)
+  int Ho, Wo;
+  int cout;       // real output channels (stores beyond are masked)
+  int nch;        // number of Cin chunks of CC channels
+  int epi;        // DY_EPI_* flags
+  int dil;        // 1, or 2 = zero-dilated virtual input (stride-2 dgrad)
+  int tiles_x, tiles_y;
+  int npix;       // FLAT (1x1) only: N*Ho*Wo
+};
+
+template <int CC, int MT, int KS, int STRIDE, int TROWS>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+  constexpr bool FLAT = (KS == 1);
+  constexpr int NT = FLAT ? 4 : 2 * TROWS;
+  constexpr int TH = 4 * TROWS, TW = 32;
+  constexpr int HW_ = FLAT ? 256 : (TW - 1) * STRIDE + KS;
+  constexpr int HH_ = FLAT ? 1 : (TH - 1) * STRIDE + KS;
+  constexpr int PS = CC * 2 + 16;  // LDS bytes per pixel (16 B pad de-phases the banks)
+  constexpr int KSTEPS = (KS * KS * CC + 31) / 32;
+  constexpr int CPP = CC / 8;
+  constexpr int PAD = KS / 2;
+  constexpr int TILE_BYTES = HH_ * HW_ * PS;
+  constexpr int RED_BYTES = 4 * 2 * 16 * MT * 4;
+  __shared__ __attribute__((aligned(16))) char smem[TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
+  int n = 0, oy0 = 0, ox0 = 0, pix0 = 0;
+  if (FLAT) {
+    pix0 = blockIdx.x * 256;
+  } else {
+    const int bx = blockIdx.x % a.tiles_x;
+    const int t2 = blockIdx.x / a.tiles_x;
+    const int by = t2 % a.tiles_y;
+    n = t2 / a.tiles_y;
+    oy0 = by * TH;
+    ox0 = bx * TW;
+  }
+
+  // per-lane LDS byte offset of its pixel in each N-tile
+  int boff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (FLAT) {
+      boff[t] = (wave * 64 + t * 16 + p) * PS;
+    } else {
+      const int ty = wave * TROWS + (t >> 1), tx = (t & 1) * 16 + p;
+      boff[t] = ((ty * STRIDE) * HW_ + tx * STRIDE) * PS;
+    }
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int h = 0; h < a.nch; ++h) {
+    // ---- stage the halo tile of Cin chunk h (zero outside the image)
+    for (int id = tid; id < HH_ * HW_ * CPP; id += 256) {
+      const int pixel = id / CPP, part = id - pixel * CPP;
+      const f16* src = nullptr;
+      if (FLAT) {
+        const int gp = pix0 + pixel;
+        if (gp < a.npix) src = a.x + (size_t)gp * a.ldx + h * CC + part * 8;
+      } else {
+        const int hy = pixel / HW_, hx = pixel - hy * HW_;
+        int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
+        bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        if (a.dil == 2) {
+          ok = ok && !((iy | ix) & 1);
+          iy >>= 1;
+          ix >>= 1;
+        }
+        if (ok) src = a.x + ((size_t)(n * a.Hr + iy) * a.Wr + ix) * a.ldx + h * CC + part * 8;
+      }
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (src) v = *reinterpret_cast<const uint4*>(src);
+      *reinterpret_cast<uint4*>(smem + pixel * PS + part * 16) = v;
+    }
+    __syncthreads();
+    const f16* wh = a.w + (size_t)((blockIdx.y * a.nch + h) * KSTEPS) * (16 * MT) * 32;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int kk = ks * 32 + q * 8;
+      int tap = kk / CC;
+      const int c = kk - tap * CC;
+      if (tap > KS * KS - 1) tap = KS * KS - 1;  // K padding: weights are zero there, keep the read in range
+      const int toff = ((tap / KS) * HW_ + (tap % KS)) * PS + c * 2;
+      half8 af[MT], bf[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        af[m] = *reinterpret_cast<const half8*>(wh + ((ks * (16 * MT) + m * 16 + p) * 32 + q * 8));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const half8*>(smem + boff[t] + toff);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf[t], acc[m][t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds channels [co0, co0 + 4*MT) of one pixel per N-tile
+  constexpr int NC = 4 * MT;
+  const int co0 = blockIdx.y * (16 * MT) + q * NC;
+  float bias[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) bias[j] = ((a.epi & DY_EPI_BIAS) && co0 + j < a.cout) ? a.bias[co0 + j] : 0.f;
+  float s1[NC], s2[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) s1[j] = s2[j] = 0.f;
+
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    bool valid;
+    size_t yoff;
+    if (FLAT) {
+      const int gp = pix0 + wave * 64 + t * 16 + p;
+      valid = gp < a.npix;
+      yoff = (size_t)gp * a.ldy;
+    } else {
+      const int oy = oy0 + wave * TROWS + (t >> 1), ox = ox0 + (t & 1) * 16 + p;
+      valid = oy < a.Ho && ox < a.Wo;
+      yoff = ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.ldy;
+    }
+    float v[NC];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[m][t][r] + bias[m * 4 + r];
+    if (a.epi & DY_EPI_SILU) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) v[j] = silu_f(v[j]);
+    }
+    if (a.epi & DY_EPI_F32OUT) {
+      float* yp = reinterpret_cast<float*>(a.y) + yoff + co0;
+      if (valid) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+          if (co0 + j < a.cout) yp[j] = (a.epi & DY_EPI_ACCUM) ? yp[j] + v[j] : v[j];
+      }
+    } else {
+      f16* yp = reinterpret_cast<f16*>(a.y) + yoff + co0;
+      f16 hv[NC];
+      if (valid && (a.epi & DY_EPI_ACCUM)) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+          if (co0 + j < a.cout) v[j] += (float)yp[j];
+      }
+#pragma unroll
+      for (int j = 0; j < NC; ++j) hv[j] = (f16)v[j];
+      if (valid) {
+        if (co0 + NC <= a.cout) {
+          if (NC == 4) {
+            *reinterpret_cast<uint2*>(yp) = *reinterpret_cast<uint2*>(hv);
+          } else {
+#pragma unroll
+            for (int j = 0; j < NC; j += 8) *reinterpret_cast<uint4*>(yp + j) = *reinterpret_cast<uint4*>(hv + j);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NC; ++j)
+            if (co0 + j < a.cout) yp[j] = hv[j];
+        }
+        if (a.epi & DY_EPI_STATS) {
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            const float r = (float)hv[j];
+            s1[j] += r;
+            s2[j] += r * r;
+          }
+        }
+      }
+    }
+  }
+
+  if (a.epi & DY_EPI_STATS) {
+    float* red = reinterpret_cast<float*>(smem);  // [wave][2][16*MT]
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      s1[j] = quad16_sum(s1[j]);
+      s2[j] = quad16_sum(s2[j]);
+    }
+    if (p == 0) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        red[(wave * 2 + 0) * (16 * MT) + q * NC + j] = s1[j];
+        red[(wave * 2 + 1) * (16 * MT) + q * NC + j] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * 16 * MT) {
+      const int which = tid / (16 * MT), ch = tid - which * (16 * MT);
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * (16 * MT) + ch];
+      const int ctot = gridDim.y * 16 * MT;
+      a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + ch] = s;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Weight packing: fp32 OIHW master -> fp16 [cout chunk][cin chunk][k-step][16*MT rows][32], rows permuted so that the
+// MFMA D rows held by one lane are consecutive output channels; optional per-Cout scale (BN folding) and the
+// transposed + spatially flipped form used by the input-gradient pass.
+struct PackArgs {
+  const float* w;      // (Cout, Cin, KS, KS)
+  const float* scale;  // per-Cout multiplier or null
+  f16* out;
+  int cout, cin, ks, cc, nch, mt, ngroups, ksteps, transposed;
+};
+
+__global__ void pack_weights_kernel(PackArgs a) {
+  const int total = a.ngroups * a.nch * a.ksteps * 16 * a.mt * 32;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int r = idx;
+    const int kk = r & 31;
+    r >>= 5;
+    const int m = r % (16 * a.mt);
+    r /= (16 * a.mt);
+    const int ks = r % a.ksteps;
+    r /= a.ksteps;
+    const int h = r % a.nch;
+    const int g = r / a.nch;
+    const int mt = m >> 4, i = m & 15, qq = i >> 2, rr = i & 3;
+    const int o = g * 16 * a.mt + qq * 4 * a.mt + mt * 4 + rr;  // GEMM row = conv output channel of this pass
+    const int flat = ks * 32 + kk;
+    const int tap = flat / a.cc, c = h * a.cc + (flat - tap * a.cc);
+    float v = 0.f;
+    const int ntap = a.ks * a.ks;
+    if (tap < ntap) {
+      if (!a.transposed) {
+        if (o < a.cout && c < a.cin) {
+          v = a.w[((size_t)o * a.cin + c) * ntap + tap];
+          if (a.scale) v *= a.scale[o];
+        }
+      } else {  // pass output channel o = original Cin index, reduction channel c = original Cout index
+        if (o < a.cin && c < a.cout) {
+          v = a.w[((size_t)c * a.cin + o) * ntap + (ntap - 1 - tap)];
+          if (a.scale) v *= a.scale[c];
+        }
+      }
+    }
+    a.out[idx] = (f16)v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+static int pick_cc(int cin_p, int ks, int stride) {
+  const int cap = (ks == 3 && stride == 2) ? 32 : 64;
+  if (cin_p <= cap && (cin_p == 8 || cin_p == 16 || cin_p == 32 || cin_p == 64)) return cin_p;
+  if (cin_p % 64 == 0 && cap >= 64) return 64;
+  if (cin_p % 32 == 0) return 32;
+  if (cin_p % 16 == 0) return 16;
+  return 8;
+}
+static int pick_mt(int cout_p) { return cout_p % 64 == 0 ? 4 : (cout_p % 32 == 0 ? 2 : 1); }
+
+extern "C" int dy_conv_geometry(int cin, int cout, int ks, int stride, int* cin_p, int* cout_p, int* cc, int* nch,
+                                int* mt, int* ngroups, int* ksteps, int* packed_elems) {
+  if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || (ks == 1 && stride != 1)) return DY_ERR_ARG;
+  const int cp = (cin + 7) / 8 * 8, op = (cout + 15) / 16 * 16;
+  const int c = pick_cc(cp, ks, stride), m = pick_mt(op);
+  *cin_p = cp;
+  *cout_p = op;
+  *cc = c;
+  *nch = cp / c;
+  *mt = m;
+  *ngroups = op / (16 * m);
+  *ksteps = (ks * ks * c + 31) / 32;
+  *packed_elems = (*ngroups) * (*nch) * (*ksteps) * 16 * m * 32;
+  return DY_OK;
+}
+
+extern "C" int dy_pack_weights(const float* w, const float* scale, void* out, int cout, int cin, int ks, int stride,
+                               int transposed, hipStream_t stream) {
+  // geometry is that of the pass that will consume the pack: (cin -> cout) forward, or (cout -> cin) stride-1 dgrad
+  int cp, op, cc, nch, mt, ng, kst, pe;
+  const int pin = transposed ? cout : cin, pout = transposed ? cin : cout;
+  if (dy_conv_geometry(pin, pout, ks, transposed ? 1 : stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK)
+    return DY_ERR_ARG;
+  PackArgs a{w, scale, (f16*)out, cout, cin, ks, cc, nch, mt, ng, kst, transposed};
+  const int blocks = cdiv(pe, 256) < 1024 ? cdiv(pe, 256) : 1024;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+template <int CC, int MT, int KS, int STRIDE, int TROWS>
+static int launch_conv(const ConvArgs& a, int grid_x, int grid_y, hipStream_t s) {
+  hipLaunchKernelGGL((conv_mfma_kernel<CC, MT, KS, STRIDE, TROWS>), dim3(grid_x, grid_y), dim3(256), 0, s, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+template <int KS, int STRIDE, int TROWS>
+static int dispatch_cc_mt(int cc, int mt, const ConvArgs& a, int gx, int gy, hipStream_t s) {
+#define DY_CASE(C, M) \
+  if (cc == C && mt == M) return launch_conv<C, M, KS, STRIDE, TROWS>(a, gx, gy, s);
+  DY_CASE(8, 1) DY_CASE(8, 2) DY_CASE(8, 4)
+  DY_CASE(16, 1) DY_CASE(16, 2) DY_CASE(16, 4)
+  DY_CASE(32, 1) DY_CASE(32, 2) DY_CASE(32, 4)
+  if (STRIDE == 1) { DY_CASE(64, 1) DY_CASE(64, 2) DY_CASE(64, 4) }
+#undef DY_CASE
+  return DY_ERR_ARG;
+}
+
+extern "C" int dy_conv_forward(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                               float* partials, int n, int h, int w, int cin, int cout, int ks, int stride, int dil,
+                               int out_h, int out_w, int epi, int* num_partials, hipStream_t stream) {
+  int cp, op, cc, nch, mt, ng, kst, pe;
+  if (dy_conv_geometry(cin, cout, ks, stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return DY_ERR_ARG;
+  if (cin != cp || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return DY_ERR_ALIGN;
+  if (!(epi & DY_EPI_F32OUT) && (((uintptr_t)y & 15) || (ldy & 3))) return DY_ERR_ALIGN;
+  if (dil != 1 && !(dil == 2 && ks == 3 && stride == 1)) return DY_ERR_ARG;
+  ConvArgs a{};
+  a.x = (const f16*)x; a.w = (const f16*)w_packed; a.bias = bias; a.y = y; a.partials = partials;
+  a.ldx = ldx; a.ldy = ldy; a.N = n; a.Hr = h; a.Wr = w;
+  a.H = dil == 2 ? 2 * h : h; a.W = dil == 2 ? 2 * w : w;
+  const int pad = ks / 2;
+  a.Ho = (a.H + 2 * pad - ks) / stride + 1;
+  a.Wo = (a.W + 2 * pad - ks) / stride + 1;
+  if (out_h > 0 && out_w > 0) {  // stride-2 dgrad: the forward input extent (2*h or 2*h-1) cannot be derived from h
+    if (out_h > a.Ho || out_w > a.Wo) return DY_ERR_ARG;
+    a.Ho = out_h;
+    a.Wo = out_w;
+  }
+  a.cout = cout; a.nch = nch; a.epi = epi; a.dil = dil;
+  int gx;
+  if (ks == 1) {
+    a.npix = n * a.Ho * a.Wo;
+    gx = cdiv(a.npix, 256);
+  } else {
+    const int th = stride == 1 ? 8 : 4;
+    a.tiles_x = cdiv(a.Wo, 32);
+    a.tiles_y = cdiv(a.Ho, th);
+    gx = a.tiles_x * a.tiles_y * n;
+  }
+  if (num_partials) *num_partials = gx;
+  if ((epi & DY_EPI_STATS) && !partials) return DY_ERR_ARG;
+  if (gx <= 0) return DY_ERR_ARG;
+  if (ks == 1) return dispatch_cc_mt<1, 1, 2>(cc, mt, a, gx, ng, stream);
+  if (stride == 1) return dispatch_cc_mt<3, 1, 2>(cc, mt, a, gx, ng, stream);
+  return dispatch_cc_mt<3, 2, 1>(cc, mt, a, gx, ng, stream);
+}
+
+// number of partial rows dy_conv_forward will write for a given problem (host-side planning helper)
+extern "C" int dy_conv_num_partials(int n, int h, int w, int ks, int stride, int dil) {
+  const int H = dil == 2 ? 2 * h : h, W = dil == 2 ? 2 * w : w, pad = ks / 2;
+  const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+  if (ks == 1) return cdiv(n * Ho * Wo, 256);
+  return cdiv(Wo, 32) * cdiv(Ho, stride == 1 ? 8 : 4) * n;
+}

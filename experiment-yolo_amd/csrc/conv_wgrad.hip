@@ -1,0 +1,261 @@
+// Weight gradient of the convolution on MFMA: dW[tap][co][ci] = sum_pixels dY[pix][co] * X[pix + tap][ci].
+//
+// Replaces the weight half of ATen convolution_backward for Conv (reference nn/modules/conv.py:41-55).  The GEMM
+// reduces over PIXELS, so both MFMA operands need 8 consecutive pixels of one channel per lane while the tensors are
+// pixel-major (NHWC): fragments come from LDS through ds_read_b64_tr_b16 (hardware transpose), two reads per
+// fragment.  Workgroups are persistent over pixel tiles and keep dW in accumulators; each writes ONE fp32 slab,
+// reduced (deterministically, no atomics) by dy_wgrad_reduce into the OIHW fp32 gradient.
+#include "common.h"
+#include "dealyolo_hip.h"
+
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+struct WgArgs {
+  const f16* x;
+  const f16* dy;
+  float* slabs;
+  int ldx, lddy;
+  int N, H, W, Ho, Wo;
+  int cin_p, cout_p;  // padded to multiples of 16
+  int cin_r8, cout_r8;  // physical channel counts of x / dy (multiples of 8); granules beyond are read as zero
+  int nci_chunks;     // blockIdx.y = co_chunk * nci_chunks + ci_chunk
+  int tiles_x, tiles_y, ntiles;
+  long npix;  // FLAT only
+};
+
+static __device__ __forceinline__ half8 tr_frag(const char* base0, const char* base1) {
+  // two 4-row x 16-column transposed reads -> 8 consecutive k (pixels) of this lane's channel
+  union {
+    short4v s[2];
+    half8 h;
+  } u;
+  u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS short4v*)(base0));
+  u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS short4v*)(base1));
+  return u.h;
+}
+
+template <int KS, int STRIDE, int NCI, int MTC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
+  constexpr bool FLAT = (KS == 1);
+  constexpr int TAPS = KS * KS;
+  constexpr int NCOL = NCI * TAPS;          // (ci tile, tap) columns of this workgroup
+  constexpr int CPW = (NCOL + 3) / 4;       // columns per wave (round-robin)
+  constexpr int TH = FLAT ? 4 : (STRIDE == 1 ? 4 : 2), TW = 32;
+  constexpr int HWX = FLAT ? TH * TW : (TW - 1) * STRIDE + KS;
+  constexpr int HHX = FLAT ? 1 : (TH - 1) * STRIDE + KS;
+  constexpr int PAD = KS / 2;
+  constexpr int CIN_C = 16 * NCI, COUT_C = 16 * MTC;
+  constexpr int PSX = CIN_C * 2 + 16, PSY = COUT_C * 2 + 16;
+  constexpr int XBYTES = HHX * HWX * PSX, YBYTES = TH * TW * PSY;
+  __shared__ __attribute__((aligned(16))) char smem[XBYTES + YBYTES];
+  char* const sx = smem;
+  char* const sy = smem + XBYTES;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
+  const int qq = p >> 2, pp = p & 3;  // address-supplier role inside the 16-lane group
+  const int co_chunk = blockIdx.y / a.nci_chunks, ci_chunk = blockIdx.y - co_chunk * a.nci_chunks;
+  const int ci0 = ci_chunk * CIN_C, co0 = co_chunk * COUT_C;
+
+  f32x4 acc[MTC][CPW];
+#pragma unroll
+  for (int m = 0; m < MTC; ++m)
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) acc[m][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    int n = 0, oy0 = 0, ox0 = 0;
+    long pix0 = 0;
+    if (FLAT) {
+      pix0 = (long)tile * (TH * TW);
+    } else {
+      const int bx = tile % a.tiles_x;
+      const int t2 = tile / a.tiles_x;
+      const int by = t2 % a.tiles_y;
+      n = t2 / a.tiles_y;
+      oy0 = by * TH;
+      ox0 = bx * TW;
+    }
+    // ---- stage X halo (this ci chunk) and dY tile (this co chunk); zero outside the image
+    for (int id = tid; id < HHX * HWX * (CIN_C / 8); id += 256) {
+      const int pixel = id / (CIN_C / 8), part = id - pixel * (CIN_C / 8);
+      const f16* src = nullptr;
+      const bool cok = ci0 + part * 8 < a.cin_r8;
+      if (!cok) {
+      } else if (FLAT) {
+        const long gp = pix0 + pixel;
+        if (gp < a.npix) src = a.x + gp * a.ldx + ci0 + part * 8;
+      } else {
+        const int hy = pixel / HWX, hx = pixel - hy * HWX;
+        const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) src = a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.ldx + ci0 + part * 8;
+      }
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (src) v = *reinterpret_cast<const uint4*>(src);
+      *reinterpret_cast<uint4*>(sx + pixel * PSX + part * 16) = v;
+    }
+    for (int id = tid; id < TH * TW * (COUT_C / 8); id += 256) {
+      const int pixel = id / (COUT_C / 8), part = id - pixel * (COUT_C / 8);
+      const f16* src = nullptr;
+      const bool cok = co0 + part * 8 < a.cout_r8;
+      if (!cok) {
+      } else if (FLAT) {
+        const long gp = pix0 + pixel;
+        if (gp < a.npix) src = a.dy + gp * a.lddy + co0 + part * 8;
+      } else {
+        const int ty = pixel / TW, tx = pixel - ty * TW;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        if (oy < a.Ho && ox < a.Wo) src = a.dy + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.lddy + co0 + part * 8;
+      }
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (src) v = *reinterpret_cast<const uint4*>(src);
+      *reinterpret_cast<uint4*>(sy + pixel * PSY + part * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {  // one k-step = 32 consecutive output pixels of tile row r
+      const int kpix = 8 * q + qq;  // first-read row of this lane inside the k-step
+      half8 af[MTC];
+#pragma unroll
+      for (int m = 0; m < MTC; ++m) {
+        const char* b0 = sy + (r * TW + kpix) * PSY + (m * 16 + 4 * pp) * 2;
+        af[m] = tr_frag(b0, b0 + 4 * PSY);
+      }
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        const int col = wave + 4 * c;  // wave-uniform
+        if (col < NCOL) {
+          const int cit = col / TAPS, tap = col - cit * TAPS;
+          const int dy = tap / KS, dx = tap - dy * KS;
+          const char* b0;
+          int step;
+          if (FLAT) {
+            b0 = sx + (r * TW + kpix) * PSX + (cit * 16 + 4 * pp) * 2;
+            step = 4 * PSX;
+          } else {
+            b0 = sx + ((r * STRIDE + dy) * HWX + kpix * STRIDE + dx) * PSX + (cit * 16 + 4 * pp) * 2;
+            step = 4 * STRIDE * PSX;
+          }
+          const half8 bf = tr_frag(b0, b0 + step);
+#pragma unroll
+          for (int m = 0; m < MTC; ++m) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf, acc[m][c], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- one slab per workgroup: [tap][cout_p][cin_p] fp32 (16 lanes -> 64 contiguous bytes)
+  float* slab = a.slabs + (size_t)blockIdx.x * TAPS * a.cout_p * a.cin_p;
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    const int col = wave + 4 * c;
+    if (col < NCOL) {
+      const int cit = col / TAPS, tap = col - cit * TAPS;
+#pragma unroll
+      for (int m = 0; m < MTC; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + m * 16 + q * 4 + r, ci = ci0 + cit * 16 + p;
+          slab[((size_t)tap * a.cout_p + co) * a.cin_p + ci] = acc[m][c][r];
+        }
+    }
+  }
+}
+
+// dW[co][ci][tap] (+)= sum_wg slab[wg][tap][co][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int nslabs, float* dw, int cout, int cin,
+                                                           int taps, int cout_p, int cin_p, int accumulate) {
+  const int total = cout * cin * taps;
+  const size_t slab_elems = (size_t)taps * cout_p * cin_p;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int tap = idx % taps;
+    const int t = idx / taps;
+    const int ci = t % cin, co = t / cin;
+    const size_t off = ((size_t)tap * cout_p + co) * cin_p + ci;
+    float s = 0.f;
+    for (int k = 0; k < nslabs; ++k) s += slabs[k * slab_elems + off];
+    dw[idx] = accumulate ? dw[idx] + s : s;
+  }
+}
+
+template <int KS, int STRIDE, int NCI, int MTC>
+static int launch_wgrad(const WgArgs& a, int gx, int gy, hipStream_t s) {
+  hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC>), dim3(gx, gy), dim3(256), 0, s, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+template <int KS, int STRIDE>
+static int dispatch_wgrad(int nci, int mtc, const WgArgs& a, int gx, int gy, hipStream_t s) {
+#define DY_CASE(I, M) \
+  if (nci == I && mtc == M) return launch_wgrad<KS, STRIDE, I, M>(a, gx, gy, s);
+  DY_CASE(1, 1) DY_CASE(1, 2) DY_CASE(1, 4)
+  DY_CASE(2, 1) DY_CASE(2, 2) DY_CASE(2, 4)
+  if (!(KS == 3 && STRIDE == 2)) { DY_CASE(4, 1) DY_CASE(4, 2) DY_CASE(4, 4) }
+#undef DY_CASE
+  return DY_ERR_ARG;
+}
+
+static void wgrad_geometry(int cin, int cout, int ks, int stride, int* cin_p, int* cout_p, int* nci, int* mtc) {
+  *cin_p = (cin + 15) / 16 * 16;
+  *cout_p = (cout + 15) / 16 * 16;
+  const int cit = *cin_p / 16, cot = *cout_p / 16;
+  const int cap = (ks == 3 && stride == 2) ? 2 : 4;
+  *nci = (cit % 4 == 0 && cap >= 4) ? 4 : (cit % 2 == 0 ? 2 : 1);
+  *mtc = cot % 4 == 0 ? 4 : (cot % 2 == 0 ? 2 : 1);
+}
+
+extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int stride, int* nslabs,
+                                  long* slab_elems) {
+  int cp, op, nci, mtc;
+  wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc);
+  const int pad = ks / 2, Ho = (h + 2 * pad - ks) / stride + 1, Wo = (w + 2 * pad - ks) / stride + 1;
+  int ntiles;
+  if (ks == 1) ntiles = (int)(((long)n * Ho * Wo + 127) / 128);
+  else ntiles = cdiv(Wo, 32) * cdiv(Ho, stride == 1 ? 4 : 2) * n;
+  int gx = ntiles / 8;
+  if (gx > 512) gx = 512;
+  if (gx < 1) gx = 1;
+  *nslabs = gx;
+  *slab_elems = (long)ks * ks * cp * op;
+  return DY_OK;
+}
+
+extern "C" int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h,
+                             int w, int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream) {
+  if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || (ks == 1 && stride != 1)) return DY_ERR_ARG;
+  if ((ldx & 7) || (lddy & 7) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return DY_ERR_ALIGN;
+  int cp, op, nci, mtc;
+  wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc);
+  WgArgs a{};
+  a.x = (const f16*)x; a.dy = (const f16*)dy; a.slabs = slabs; a.ldx = ldx; a.lddy = lddy;
+  a.N = n; a.H = h; a.W = w;
+  const int pad = ks / 2;
+  a.Ho = (h + 2 * pad - ks) / stride + 1;
+  a.Wo = (w + 2 * pad - ks) / stride + 1;
+  a.cin_p = cp; a.cout_p = op;
+  a.cin_r8 = (cin + 7) / 8 * 8; a.cout_r8 = (cout + 7) / 8 * 8;
+  a.nci_chunks = cp / (16 * nci);
+  const int nco_chunks = op / (16 * mtc);
+  if (ks == 1) {
+    a.npix = (long)n * a.Ho * a.Wo;
+    a.ntiles = (int)((a.npix + 127) / 128);
+  } else {
+    a.tiles_x = cdiv(a.Wo, 32);
+    a.tiles_y = cdiv(a.Ho, stride == 1 ? 4 : 2);
+    a.ntiles = a.tiles_x * a.tiles_y * n;
+  }
+  int nslabs;
+  long slab_elems;
+  dy_wgrad_workspace(n, h, w, cin, cout, ks, stride, &nslabs, &slab_elems);
+  const int gy = a.nci_chunks * nco_chunks;
+  int rc;
+  if (ks == 1) rc = dispatch_wgrad<1, 1>(nci, mtc, a, nslabs, gy, stream);
+  else if (stride == 1) rc = dispatch_wgrad<3, 1>(nci, mtc, a, nslabs, gy, stream);
+  else rc = dispatch_wgrad<3, 2>(nci, mtc, a, nslabs, gy, stream);
+  if (rc != DY_OK) return rc;
+  const int total = cout * cin * ks * ks;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256) < 512 ? cdiv(total, 256) : 512), dim3(256), 0, stream,
+                     slabs, nslabs, dw, cout, cin, ks * ks, op, cp, accumulate);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}

@@ -1,0 +1,169 @@
+// Flat-buffer optimizer step: unscale + inf check + global-norm clip + SGD(nesterov) | AdamW + EMA in two launches
+// over ONE contiguous fp32 parameter buffer laid out as [bias group | decayed weights | norm weights].
+// Replaces BaseTrainer.optimizer_step (reference engine/trainer.py:949-957: GradScaler.unscale_, clip_grad_norm_(10),
+// optimizer.step over ~190 tensors, scaler.update) and ModelEMA.update's Python loop over the state_dict
+// (utils/torch_utils.py:447-458).  The GradScaler policy (halve on inf/nan, double after 2000 clean steps) runs on
+// device, so no host synchronisation is needed to decide whether to skip a step.
+#include "common.h"
+#include "dealyolo_hip.h"
+
+// hyper[] (float, written by the host before each step): 0..2 lr per group, 3 momentum/beta1, 4..6 weight decay per
+// group, 7 ema decay, 8 max grad norm, 9 adam beta2, 10 adam eps
+// state[] (float, device-resident): 0 loss scale, 1 growth tracker, 2 found_inf (this step), 3 grad norm (unscaled),
+// 4 clip coefficient, 5 optimizer steps taken, 6 skipped steps
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* g, long n, float* partials) {
+  float s = 0.f;
+  int bad = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = g[i];
+    if (!(fabsf(v) <= 3.0e38f)) bad = 1;  // inf or nan
+    s += v * v;
+  }
+  __shared__ float red[256];
+  __shared__ int rbad[256];
+  red[threadIdx.x] = s;
+  rbad[threadIdx.x] = bad;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      red[threadIdx.x] += red[threadIdx.x + o];
+      rbad[threadIdx.x] |= rbad[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x * 2] = red[0];
+    partials[blockIdx.x * 2 + 1] = (float)rbad[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void grad_norm_final_kernel(const float* partials, int np, const float* hyper,
+                                                              float* state) {
+  __shared__ double red[256];
+  __shared__ int rbad[256];
+  double s = 0.0;
+  int bad = 0;
+  for (int i = threadIdx.x; i < np; i += 256) {
+    s += partials[i * 2];
+    bad |= partials[i * 2 + 1] != 0.f;
+  }
+  red[threadIdx.x] = s;
+  rbad[threadIdx.x] = bad;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      red[threadIdx.x] += red[threadIdx.x + o];
+      rbad[threadIdx.x] |= rbad[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float scale = state[0];
+    const int found = rbad[0] || !(red[0] <= 1.0e300);
+    const float norm = found ? 0.f : (float)(sqrt(red[0]) / (double)scale);
+    state[2] = (float)found;
+    state[3] = norm;
+    const float coef = hyper[8] / (norm + 1e-6f);  // clip_grad_norm_: clamp(max_norm / (total + 1e-6), max=1)
+    state[4] = coef < 1.f ? coef : 1.f;
+  }
+}
+
+struct StepArgs {
+  float* p;
+  const float* g;
+  float* m;   // momentum buffer / adam exp_avg
+  float* v;   // adam exp_avg_sq (null for SGD)
+  float* ema; // may be null
+  const float* hyper;
+  float* state;
+  long n, g0_end, g1_end;  // group boundaries: [0,g0_end) bias, [g0_end,g1_end) decayed weights, rest norm weights
+  const uint8_t* frozen;   // optional per-element mask (1 = requires_grad False)
+  int adam;                // 0 SGD-nesterov, 1 Adam (L2 decay), 2 AdamW (decoupled)
+};
+
+__global__ __launch_bounds__(256) void optim_step_kernel(StepArgs a) {
+  const float found = a.state[2];
+  const float inv_scale = 1.f / a.state[0], coef = a.state[4];
+  const float mom = a.hyper[3], d = a.hyper[7];
+  const bool first = a.state[5] == 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256) {
+    const int grp = i < a.g0_end ? 0 : (i < a.g1_end ? 1 : 2);
+    float p = a.p[i];
+    if (found == 0.f && !(a.frozen && a.frozen[i])) {
+      const float lr = a.hyper[grp], wd = a.hyper[4 + grp];
+      float g = a.g[i] * inv_scale * coef;
+      if (a.adam == 0) {
+        if (wd != 0.f) g += wd * p;
+        float buf = first ? g : mom * a.m[i] + g;
+        a.m[i] = buf;
+        p -= lr * (g + mom * buf);
+      } else {
+        if (a.adam == 2) p *= 1.f - lr * wd;
+        else if (wd != 0.f) g += wd * p;
+        const float b2 = a.hyper[9];
+        const float m = mom * (first ? 0.f : a.m[i]) + (1.f - mom) * g;
+        const float v = b2 * (first ? 0.f : a.v[i]) + (1.f - b2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        const float t = a.state[5] + 1.f;  // steps actually taken (skipped steps do not advance Adam's clock)
+        const float bc1 = 1.f - powf(mom, t), bc2 = 1.f - powf(b2, t);
+        p -= lr / bc1 * m / (sqrtf(v) / sqrtf(bc2) + a.hyper[10]);
+      }
+      a.p[i] = p;
+    }
+    if (a.ema) a.ema[i] = d * a.ema[i] + (1.f - d) * p;  // ModelEMA.update runs whether or not the step was skipped
+  }
+}
+
+// EMA of the floating-point buffers (BN running statistics) + GradScaler.update bookkeeping
+__global__ __launch_bounds__(256) void ema_buffers_kernel(const float* s, float* es, long n, const float* hyper,
+                                                          float* state, int update_scaler) {
+  const float d = hyper[7], found = state[2];
+  if (es)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+      es[i] = d * es[i] + (1.f - d) * s[i];
+  if (update_scaler && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (found != 0.f) {
+      state[0] *= 0.5f;
+      state[1] = 0.f;
+      state[6] += 1.f;
+    } else {
+      state[5] += 1.f;
+      state[1] += 1.f;
+      if (state[1] >= 2000.f) {
+        state[0] *= 2.f;
+        state[1] = 0.f;
+      }
+    }
+  }
+}
+
+extern "C" int dy_optimizer_step(float* params, const float* grads, float* mom, float* adam_v, float* ema, long n,
+                                 long g0_end, long g1_end, const unsigned char* frozen, const float* buffers,
+                                 float* ema_buffers, long n_buffers, const float* hyper, float* state,
+                                 float* partials, int mode, hipStream_t stream) {
+  if (n <= 0 || mode < 0 || mode > 2 || (mode > 0 && !adam_v)) return DY_ERR_ARG;
+  int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(blocks), dim3(256), 0, stream, grads, n, partials);
+  hipLaunchKernelGGL(grad_norm_final_kernel, dim3(1), dim3(256), 0, stream, partials, blocks, hyper, state);
+  StepArgs a{params, grads, mom, adam_v, ema, hyper, state, n, g0_end, g1_end, frozen, mode};
+  hipLaunchKernelGGL(optim_step_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  int b2 = (int)((n_buffers + 255) / 256);
+  if (b2 < 1) b2 = 1;
+  if (b2 > 256) b2 = 256;
+  hipLaunchKernelGGL(ema_buffers_kernel, dim3(b2), dim3(256), 0, stream, buffers, ema_buffers, n_buffers, hyper, state,
+                     1);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// y += a * x (fp32), used for gradient accumulation across micro-steps
+__global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, float a, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
+}
+extern "C" int dy_axpy_f32(float* y, const float* x, float a, long n, hipStream_t stream) {
+  int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, stream, y, x, a, n);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}

@@ -1,0 +1,453 @@
+// Data-movement operators of the DEAL-YOLO graph on NHWC fp16 tensors addressed as (pointer, pixel stride):
+// image import, nearest 2x up-sampling (nn.Upsample in the model YAMLs), the 5x5 stride-1 max-pool chain of SPPF
+// (reference nn/modules/block.py:166-171), element-wise adds (Add / Bottleneck shortcut, gradient fan-in) and strided
+// channel-slice copies (Concat, reference nn/modules/conv.py:338-348, when a producer cannot write in place).
+// All are HBM-bound byte movers: 16 bytes per lane, pixel-major so that wave accesses are contiguous.
+#include "common.h"
+#include "dealyolo_hip.h"
+
+static inline int grid_for(long total) {
+  long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- NCHW fp32 image -> NHWC fp16 with channels zero-padded to Cp (stem input)
+__global__ __launch_bounds__(256) void import_image_kernel(const float* x, f16* y, int N, int C, int H, int W, int Cp,
+                                                           float mul) {
+  const long hw = (long)H * W, total = (long)N * hw;
+  for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long)gridDim.x * 256) {
+    const long n = pix / hw, r = pix - n * hw;
+    for (int c0 = 0; c0 < Cp; c0 += 8) {
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (c0 + j < C) ? (f16)(x[(n * C + c0 + j) * hw + r] * mul) : (f16)0.f;
+      *reinterpret_cast<half8*>(y + pix * Cp + c0) = v;
+    }
+  }
+}
+extern "C" int dy_import_image(const float* x, void* y, int n, int c, int h, int w, int cp, float mul,
+                               hipStream_t stream) {
+  if (cp & 7) return DY_ERR_ALIGN;
+  hipLaunchKernelGGL(import_image_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, stream, x, (f16*)y, n, c, h, w,
+                     cp, mul);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// ---- generic 8-channel-granule element-wise kernels
+struct EwArgs {
+  const f16* a;
+  const f16* b;
+  const f16* c;
+  f16* y;
+  int lda, ldb, ldc, ldy, C;
+  long npix;
+};
+// y = a (+ b) (+ c)
+__global__ __launch_bounds__(256) void add_kernel(EwArgs e) {
+  const int cpp = e.C >> 3;
+  const long total = e.npix * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int c0 = (int)(idx - pix * cpp) * 8;
+    half8 v = *reinterpret_cast<const half8*>(e.a + pix * e.lda + c0);
+    if (e.b) {
+      const half8 w = *reinterpret_cast<const half8*>(e.b + pix * e.ldb + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (f16)((float)v[j] + (float)w[j]);
+    }
+    if (e.c) {
+      const half8 w = *reinterpret_cast<const half8*>(e.c + pix * e.ldc + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (f16)((float)v[j] + (float)w[j]);
+    }
+    *reinterpret_cast<half8*>(e.y + pix * e.ldy + c0) = v;
+  }
+}
+extern "C" int dy_add(const void* a, int lda, const void* b, int ldb, const void* c, int ldc, void* y, int ldy,
+                      long npix, int C, hipStream_t stream) {
+  if ((C & 7) || (lda & 7) || (ldy & 7) || (b && (ldb & 7)) || (c && (ldc & 7))) return DY_ERR_ALIGN;
+  EwArgs e{(const f16*)a, (const f16*)b, (const f16*)c, (f16*)y, lda, ldb, ldc, ldy, C, npix};
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(npix * (C >> 3))), dim3(256), 0, stream, e);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// ---- nearest 2x up-sampling, forward (y[2h+i, 2w+j] = x[h, w]) and backward (sum of the 2x2 block)
+struct UpArgs {
+  const f16* x;
+  f16* y;
+  int ldx, ldy, C, N, H, W, accumulate;  // H, W: low-resolution extent
+};
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(UpArgs u) {
+  const int cpp = u.C >> 3, Ho = 2 * u.H, Wo = 2 * u.W;
+  const long total = (long)u.N * Ho * Wo * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int c0 = (int)(idx - pix * cpp) * 8;
+    const int ox = (int)(pix % Wo);
+    const long t = pix / Wo;
+    const int oy = (int)(t % Ho);
+    const long n = t / Ho;
+    const long src = (n * u.H + (oy >> 1)) * u.W + (ox >> 1);
+    *reinterpret_cast<uint4*>(u.y + pix * u.ldy + c0) = *reinterpret_cast<const uint4*>(u.x + src * u.ldx + c0);
+  }
+}
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(UpArgs u) {  // x = dY (high res), y = dX (low res)
+  const int cpp = u.C >> 3, Ho = 2 * u.H, Wo = 2 * u.W;
+  const long total = (long)u.N * u.H * u.W * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int c0 = (int)(idx - pix * cpp) * 8;
+    const int lx = (int)(pix % u.W);
+    const long t = pix / u.W;
+    const int ly = (int)(t % u.H);
+    const long n = t / u.H;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    if (u.accumulate) {
+      const half8 o = *reinterpret_cast<const half8*>(u.y + pix * u.ldy + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] = (float)o[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long src = (n * Ho + 2 * ly + (i >> 1)) * Wo + 2 * lx + (i & 1);
+      const half8 v = *reinterpret_cast<const half8*>(u.x + src * u.ldx + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)s[j];
+    *reinterpret_cast<half8*>(u.y + pix * u.ldy + c0) = o;
+  }
+}
+extern "C" int dy_upsample2x(const void* x, int ldx, void* y, int ldy, int n, int h, int w, int C, int backward,
+                             int accumulate, hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (ldy & 7)) return DY_ERR_ALIGN;
+  UpArgs u{(const f16*)x, (f16*)y, ldx, ldy, C, n, h, w, accumulate};
+  if (!backward)
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((long)n * 4 * h * w * (C >> 3))), dim3(256), 0, stream, u);
+  else
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long)n * h * w * (C >> 3))), dim3(256), 0, stream, u);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// ---- 5x5 / stride 1 / pad 2 max-pool with recorded arg-max (first maximum in row-major window order, as ATen)
+struct PoolArgs {
+  const f16* x;
+  f16* y;
+  uint8_t* arg;  // [N*H*W][C] window position 0..24
+  const f16* dy;
+  int ldx, ldy, lddy, C, N, H, W, accumulate;
+};
+__global__ __launch_bounds__(256) void maxpool5_fwd_kernel(PoolArgs a) {
+  const int cpp = a.C >> 3;
+  const long total = (long)a.N * a.H * a.W * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int c0 = (int)(idx - pix * cpp) * 8;
+    const int x0 = (int)(pix % a.W);
+    const long t = pix / a.W;
+    const int y0 = (int)(t % a.H);
+    const long n = t / a.H;
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      best[j] = -INFINITY;
+      bi[j] = 0;
+    }
+    for (int dy = 0; dy < 5; ++dy) {
+      const int yy = y0 + dy - 2;
+      if (yy < 0 || yy >= a.H) continue;
+      for (int dx = 0; dx < 5; ++dx) {
+        const int xx = x0 + dx - 2;
+        if (xx < 0 || xx >= a.W) continue;
+        const half8 v = *reinterpret_cast<const half8*>(a.x + ((n * a.H + yy) * a.W + xx) * a.ldx + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = (float)v[j];
+          if (f > best[j] || f != f) {
+            best[j] = f;
+            bi[j] = dy * 5 + dx;
+          }
+        }
+      }
+    }
+    half8 o;
+    uint8_t ai[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o[j] = (f16)best[j];
+      ai[j] = (uint8_t)bi[j];
+    }
+    *reinterpret_cast<half8*>(a.y + pix * a.ldy + c0) = o;
+    if (a.arg) *reinterpret_cast<uint2*>(a.arg + pix * a.C + c0) = *reinterpret_cast<uint2*>(ai);
+  }
+}
+// dX[p] (+)= sum over the <=25 windows w containing p with argmax(w) == p of dY[w]   (gather form, no atomics)
+__global__ __launch_bounds__(256) void maxpool5_bwd_kernel(PoolArgs a) {
+  const int cpp = a.C >> 3;
+  const long total = (long)a.N * a.H * a.W * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int c0 = (int)(idx - pix * cpp) * 8;
+    const int x0 = (int)(pix % a.W);
+    const long t = pix / a.W;
+    const int y0 = (int)(t % a.H);
+    const long n = t / a.H;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    if (a.accumulate) {
+      const half8 o = *reinterpret_cast<const half8*>(a.y + pix * a.ldy + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] = (float)o[j];
+    }
+    for (int dy = 0; dy < 5; ++dy) {
+      const int wy = y0 - (dy - 2);  // window centre whose tap (dy,dx) lands on this pixel
+      if (wy < 0 || wy >= a.H) continue;
+      for (int dx = 0; dx < 5; ++dx) {
+        const int wx = x0 - (dx - 2);
+        if (wx < 0 || wx >= a.W) continue;
+        const long wp = (n * a.H + wy) * a.W + wx;
+        uint2 raw = *reinterpret_cast<const uint2*>(a.arg + wp * a.C + c0);
+        const uint8_t* ai = reinterpret_cast<const uint8_t*>(&raw);
+        const half8 g = *reinterpret_cast<const half8*>(a.dy + wp * a.lddy + c0);
+        const int code = dy * 5 + dx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (ai[j] == code) s[j] += (float)g[j];
+      }
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)s[j];
+    *reinterpret_cast<half8*>(a.y + pix * a.ldy + c0) = o;
+  }
+}
+extern "C" int dy_maxpool5(const void* x, int ldx, void* y, int ldy, void* argmax, int n, int h, int w, int C,
+                           hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (ldy & 7)) return DY_ERR_ALIGN;
+  PoolArgs a{(const f16*)x, (f16*)y, (uint8_t*)argmax, nullptr, ldx, ldy, 0, C, n, h, w, 0};
+  hipLaunchKernelGGL(maxpool5_fwd_kernel, dim3(grid_for((long)n * h * w * (C >> 3))), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+extern "C" int dy_maxpool5_backward(const void* dy, int lddy, const void* argmax, void* dx, int lddx, int n, int h,
+                                    int w, int C, int accumulate, hipStream_t stream) {
+  if ((C & 7) || (lddy & 7) || (lddx & 7)) return DY_ERR_ALIGN;
+  PoolArgs a{nullptr, (f16*)dx, (uint8_t*)argmax, (const f16*)dy, 0, lddx, lddy, C, n, h, w, accumulate};
+  hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(grid_for((long)n * h * w * (C >> 3))), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// ---- ScalSeq tail (reference nn/extra_modules/block.py:3437-3443): the Conv3d(1x1x1)+bias outputs r0 (full res),
+// r1 (1/2), r2 (1/4) are normalised with the shared BatchNorm3d coefficients, LeakyReLU(0.1), max over the three
+// scales with nearest up-sampling done by indexing; optional fused `Add` of a residual map (:3483-3484).
+struct SsArgs {
+  const f16* r[3];
+  int ld[3];
+  const f16* res;
+  int ldres;
+  f16* y;
+  int ldy;
+  const float* coef;
+  int C, N, H, W;
+};
+__global__ __launch_bounds__(256) void scalseq_tail_kernel(SsArgs a) {
+  const int cpp = a.C >> 3;
+  const long total = (long)a.N * a.H * a.W * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int c0 = (int)(idx - pix * cpp) * 8;
+    const int x0 = (int)(pix % a.W);
+    const long t = pix / a.W;
+    const int y0 = (int)(t % a.H);
+    const long n = t / a.H;
+    float best[8];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      const int hl = a.H >> l, wl = a.W >> l;
+      const long src = (n * hl + (y0 >> l)) * wl + (x0 >> l);
+      const half8 v = *reinterpret_cast<const half8*>(a.r[l] + src * a.ld[l] + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float z = (float)v[j] * a.coef[c0 + j] + a.coef[a.C + c0 + j];
+        z = z > 0.f ? z : 0.1f * z;
+        best[j] = (l == 0) ? z : fmaxf(best[j], z);
+      }
+    }
+    half8 o;
+    if (a.res) {
+      const half8 rv = *reinterpret_cast<const half8*>(a.res + pix * a.ldres + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) best[j] = (float)(f16)best[j] + (float)rv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)best[j];
+    *reinterpret_cast<half8*>(a.y + pix * a.ldy + c0) = o;
+  }
+}
+extern "C" int dy_scalseq_tail(const void* r0, int ld0, const void* r1, int ld1, const void* r2, int ld2,
+                               const void* res, int ldres, void* y, int ldy, const float* coef, int n, int h, int w,
+                               int C, hipStream_t stream) {
+  if ((C & 7) || (ld0 & 7) || (ld1 & 7) || (ld2 & 7) || (ldy & 7) || (h & 3) || (w & 3)) return DY_ERR_ALIGN;
+  SsArgs a{{(const f16*)r0, (const f16*)r1, (const f16*)r2}, {ld0, ld1, ld2}, (const f16*)res, ldres, (f16*)y, ldy,
+           coef, C, n, h, w};
+  hipLaunchKernelGGL(scalseq_tail_kernel, dim3(grid_for((long)n * h * w * (C >> 3))), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// Backward of the tail.  Level l (block edge s = 1 << l) owns one low-resolution pixel per thread-granule and visits
+// the s*s full-resolution positions it was replicated to.  g_l(pos) = dY(pos) * leaky'(z_l) where level l is the
+// arg-max at pos (first maximum wins, as max_pool3d), else 0.
+//   mode 0: partial sums of g and g*xhat over the whole (B,3,H,W) volume  -> partials [grid][2][C]
+//   mode 1: dr_l = scale * (sum_block g_l - cnt*mean_g - cnt*xhat_l*mean_gxhat)
+struct SsBwdArgs {
+  const f16* r[3];
+  int ld[3];
+  const f16* dy;
+  int lddy;
+  f16* dr;
+  int lddr;
+  const float* coef;
+  const float* bwdcoef;
+  float* partials;
+  int C, N, H, W, level, mode;
+};
+__global__ __launch_bounds__(256) void scalseq_bwd_kernel(SsBwdArgs a) {
+  const int cpp = a.C >> 3, l = a.level, s = 1 << l;
+  const int hl = a.H >> l, wl = a.W >> l;
+  const long total = (long)a.N * hl * wl * cpp;
+  float ps[8], px[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ps[j] = px[j] = 0.f;
+  // a thread keeps one channel granule for the whole grid-stride loop so that mode-0 sums stay per channel
+  const int part = threadIdx.x % cpp, c0 = part * 8;
+  const int rows = 256 / cpp, row = threadIdx.x / cpp;
+  const long npix_l = (long)a.N * hl * wl;
+  if (row < rows) {
+    for (long lp = (long)blockIdx.x * rows + row; lp < npix_l; lp += (long)gridDim.x * rows) {
+      const int lx = (int)(lp % wl);
+      const long t = lp / wl;
+      const int ly = (int)(t % hl);
+      const long n = t / hl;
+      const half8 own = *reinterpret_cast<const half8*>(a.r[l] + lp * a.ld[l] + c0);
+      float gsum[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gsum[j] = 0.f;
+      for (int i = 0; i < s * s; ++i) {
+        const int y0 = ly * s + i / s, x0 = lx * s + i % s;
+        const long pos = (n * a.H + y0) * a.W + x0;
+        const half8 g = *reinterpret_cast<const half8*>(a.dy + pos * a.lddy + c0);
+        half8 v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (k == l) {
+            v[k] = own;
+          } else {
+            const int hk = a.H >> k, wk = a.W >> k;
+            v[k] = *reinterpret_cast<const half8*>(a.r[k] + ((n * hk + (y0 >> k)) * wk + (x0 >> k)) * a.ld[k] + c0);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float sc = a.coef[c0 + j], sh = a.coef[a.C + c0 + j];
+          float z[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float zz = (float)v[k][j] * sc + sh;
+            z[k] = zz > 0.f ? zz : 0.1f * zz;
+          }
+          int am = 0;
+          if (z[1] > z[am]) am = 1;
+          if (z[2] > z[am]) am = 2;
+          if (am == l) {
+            const float zz = (float)own[j] * sc + sh;
+            gsum[j] += (float)g[j] * (zz > 0.f ? 1.f : 0.1f);
+          }
+        }
+      }
+      if (a.mode == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = ((float)own[j] - a.coef[2 * a.C + c0 + j]) * a.coef[3 * a.C + c0 + j];
+          ps[j] += gsum[j];
+          px[j] += gsum[j] * xh;
+        }
+      } else {
+        half8 o;
+        const float cnt = (float)(s * s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = ((float)own[j] - a.coef[2 * a.C + c0 + j]) * a.coef[3 * a.C + c0 + j];
+          o[j] = (f16)(a.coef[c0 + j] * (gsum[j] - cnt * a.bwdcoef[c0 + j] - cnt * xh * a.bwdcoef[a.C + c0 + j]));
+        }
+        *reinterpret_cast<half8*>(a.dr + lp * a.lddr + c0) = o;
+      }
+    }
+  }
+  if (a.mode == 0) {
+    __shared__ float red[2][256][9];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[0][threadIdx.x][j] = ps[j];
+      red[1][threadIdx.x][j] = px[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
+      const int which = i / a.C, c = i - which * a.C, pp = c >> 3, j = c & 7;
+      float sum = 0.f;
+      for (int r = 0; r < rows; ++r) sum += red[which][r * cpp + pp][j];
+      a.partials[((size_t)blockIdx.x * 2 + which) * a.C + c] = sum;
+    }
+  }
+  (void)total;
+}
+extern "C" int dy_scalseq_tail_backward(const void* r0, int ld0, const void* r1, int ld1, const void* r2, int ld2,
+                                        const void* dy, int lddy, void* dr, int lddr, const float* coef,
+                                        const float* bwdcoef, float* partials, int max_partials, int n, int h, int w,
+                                        int C, int level, int mode, int* nparts, hipStream_t stream) {
+  if ((C & 7) || (C >> 3) > 256 || (h & 3) || (w & 3) || level < 0 || level > 2) return DY_ERR_ARG;
+  SsBwdArgs a{{(const f16*)r0, (const f16*)r1, (const f16*)r2}, {ld0, ld1, ld2}, (const f16*)dy, lddy, (f16*)dr, lddr,
+              coef, bwdcoef, partials, C, n, h, w, level, mode};
+  const int rows = 256 / (C >> 3);
+  long blocks = ((long)n * (h >> level) * (w >> level) + rows - 1) / rows;
+  if (blocks > 1024) blocks = 1024;
+  if (mode == 0 && blocks > max_partials) blocks = max_partials;
+  if (blocks < 1) blocks = 1;
+  if (nparts) *nparts = (int)blocks;
+  hipLaunchKernelGGL(scalseq_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// ---- strided channel-slice copy (Concat fallback) and zero fill
+__global__ __launch_bounds__(256) void copy_slice_kernel(EwArgs e) {
+  const int cpp = e.C >> 3;
+  const long total = e.npix * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int c0 = (int)(idx - pix * cpp) * 8;
+    *reinterpret_cast<uint4*>(e.y + pix * e.ldy + c0) = *reinterpret_cast<const uint4*>(e.a + pix * e.lda + c0);
+  }
+}
+extern "C" int dy_copy_slice(const void* x, int ldx, void* y, int ldy, long npix, int C, hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (ldy & 7)) return DY_ERR_ALIGN;
+  EwArgs e{(const f16*)x, nullptr, nullptr, (f16*)y, ldx, 0, 0, ldy, C, npix};
+  hipLaunchKernelGGL(copy_slice_kernel, dim3(grid_for(npix * (C >> 3))), dim3(256), 0, stream, e);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+extern "C" int dy_fill_zero(void* p, size_t bytes, hipStream_t stream) {
+  return hipMemsetAsync(p, 0, bytes, stream) == hipSuccess ? DY_OK : DY_ERR_LAUNCH;
+}

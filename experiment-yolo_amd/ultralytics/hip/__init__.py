@@ -1,0 +1,87 @@
+"""ctypes binding of libdealyolo_hip.so (the C ABI declared in include/dealyolo_hip.h).
+
+The product path has NO fallback: if the library is missing or a kernel returns an error code, a RuntimeError is
+raised.  PyTorch is used only for device memory, streams and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libdealyolo_hip.so"))
+
+DY_EPI_STATS, DY_EPI_BIAS, DY_EPI_SILU, DY_EPI_F32OUT, DY_EPI_ACCUM = 1, 2, 4, 8, 16
+DY_ACT_NONE, DY_ACT_SILU, DY_ACT_LEAKY = 0, 1, 2
+_ERR = {-1: "DY_ERR_ARG (unsupported shape/argument)", -2: "DY_ERR_LAUNCH (HIP launch failed)",
+        -3: "DY_ERR_ALIGN (pointer/stride alignment)"}
+
+vp, i32, f32, i64, sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
+ip = C.POINTER(C.c_int)
+lp = C.POINTER(C.c_long)
+
+
+class DyLossArgs(C.Structure):
+    _fields_ = [("nl", i32), ("B", i32), ("nc", i32), ("ncp", i32), ("nmax", i32),
+                ("box", vp * 4), ("cls", vp * 4), ("dbox", vp * 4), ("dcls", vp * 4),
+                ("H", i32 * 4), ("W", i32 * 4), ("stride", f32 * 4),
+                ("t_batch_idx", vp), ("t_cls", vp), ("t_boxes", vp), ("n_targets", i32), ("n_targets_dev", vp),
+                ("img_w", f32), ("img_h", f32), ("hyp_box", f32), ("hyp_cls", f32), ("hyp_dfl", f32),
+                ("use_wiou", i32), ("use_nwd", i32), ("iou_ratio", f32), ("gscale", vp), ("scalars", vp),
+                ("workspace", vp)]
+
+
+# name -> (restype, argtypes); every exported symbol of include/dealyolo_hip.h appears here (tests/test_abi.py)
+SIGNATURES = {
+    "dy_abi_version": (i32, []),
+    "dy_conv_geometry": (i32, [i32, i32, i32, i32, ip, ip, ip, ip, ip, ip, ip, ip]),
+    "dy_pack_weights": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dy_conv_forward": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, ip, vp]),
+    "dy_conv_num_partials": (i32, [i32, i32, i32, i32, i32, i32]),
+    "dy_wgrad_workspace": (i32, [i32, i32, i32, i32, i32, i32, i32, ip, lp]),
+    "dy_conv_wgrad": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_bn_finalize": (i32, [vp, i32, f32, vp, i32, f32, vp, i32, f32, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp]),
+    "dy_bn_eval_coef": (i32, [vp, vp, vp, vp, vp, i32, f32, vp]),
+    "dy_bn_act_apply": (i32, [vp, i32, vp, i32, vp, i32, vp, i64, i32, i32, vp]),
+    "dy_bn_act_bwd_reduce": (i32, [vp, i32, vp, i32, vp, vp, i32, i64, i32, i32, ip, vp]),
+    "dy_bn_bwd_finalize": (i32, [vp, i32, vp, vp, vp, i32, f32, i32, vp]),
+    "dy_bn_act_bwd_apply": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, i64, i32, i32, i32, vp]),
+    "dy_import_image": (i32, [vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "dy_add": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]),
+    "dy_upsample2x": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_maxpool5": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "dy_maxpool5_backward": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_scalseq_tail": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "dy_scalseq_tail_backward": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32,
+                                       i32, i32, ip, vp]),
+    "dy_copy_slice": (i32, [vp, i32, vp, i32, i64, i32, vp]),
+    "dy_fill_zero": (i32, [vp, sz, vp]),
+    "dy_loss_workspace_bytes": (sz, [i32, i32, i32]),
+    "dy_loss_workspace_layout": (i32, [i32, i32, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+    "dy_detection_loss": (i32, [C.POINTER(DyLossArgs), vp]),
+    "dy_optimizer_step": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, i64, vp, vp, vp, i32, vp]),
+    "dy_axpy_f32": (i32, [vp, vp, f32, i64, vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found. The DEAL-YOLO hot path has no CPU/PyTorch fallback: build the HIP library "
+                f"first (python -c 'import __graft_entry__ as g; g.build()' or `make -C experiment-yolo_amd/csrc`).")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,489 @@
+"""Execution engine of the MI355X DEAL-YOLO path: NHWC fp16 activations, a tape of hand-written backward launches,
+and record/replay of the whole step as a static launch list (capturable into one hipGraph).
+
+Design:
+  * ``Storage`` = one contiguous (N,H,W,C) fp16 device buffer plus a lazily created gradient twin; ``Act`` = a channel
+    slice [c0, c0+C) of a Storage.  Concat/chunk are therefore free: producers write into slices, consumers read them.
+  * every kernel launch goes through ``Engine.call``; while a ``Recorder`` is active the (function, ctypes args) pair
+    is also appended to a list, so the first (traced) step leaves behind the exact launch sequence of forward, loss,
+    backward and optimizer, which later steps replay without touching Python module code or the allocator.
+  * backward is NOT torch autograd: each forward op pushes a closure that issues the backward kernels; gradient fan-in
+    is resolved statically (first writer stores, later writers accumulate).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import (DY_ACT_LEAKY, DY_ACT_NONE, DY_ACT_SILU, DY_EPI_ACCUM, DY_EPI_BIAS, DY_EPI_F32OUT, DY_EPI_SILU,
+               DY_EPI_STATS, check, lib)
+
+BN2D_EPS, BN2D_MOM = 1e-3, 0.03  # reference utils/torch_utils.py:347-349
+BN3D_EPS, BN3D_MOM = 1e-5, 0.1  # nn.BatchNorm3d defaults (ScalSeq), untouched by initialize_weights
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class Storage:
+    """(N,H,W,C) fp16 buffer with an optional gradient twin and a record of which channel ranges of the twin hold data."""
+
+    def __init__(self, eng, N, H, W, C, dtype=torch.float16):
+        assert C % 8 == 0, f"channel count {C} must be a multiple of 8"
+        self.eng, self.N, self.H, self.W, self.C = eng, N, H, W, C
+        self.buf = torch.empty((N, H, W, C), dtype=dtype, device=eng.device)
+        self.gbuf = None
+        self.gwritten = []  # list of (c0, c1) already holding gradient
+
+    def act(self, c0=0, C=None):
+        return Act(self, c0, self.C - c0 if C is None else C)
+
+
+class Act:
+    """Channel slice of a Storage; the unit every op consumes/produces."""
+    __slots__ = ("st", "c0", "C", "needs_grad")
+
+    def __init__(self, st, c0, C, needs_grad=True):
+        assert c0 % 8 == 0 and C % 8 == 0 and c0 + C <= st.C
+        self.st, self.c0, self.C, self.needs_grad = st, c0, C, needs_grad
+
+    N = property(lambda s: s.st.N)
+    H = property(lambda s: s.st.H)
+    W = property(lambda s: s.st.W)
+    ld = property(lambda s: s.st.C)
+    npix = property(lambda s: s.st.N * s.st.H * s.st.W)
+
+    @property
+    def ptr(self):
+        return self.st.buf.data_ptr() + self.c0 * self.st.buf.element_size()
+
+    def sub(self, c0, C):
+        return Act(self.st, self.c0 + c0, C, self.needs_grad)
+
+    # ---- gradient twin -------------------------------------------------------------------------------------------
+    def _gbuf(self):
+        st = self.st
+        if st.gbuf is None:
+            st.gbuf = torch.empty_like(st.buf)
+            st.eng.keep.append(st.gbuf)
+        return st.gbuf
+
+    @property
+    def gptr(self):
+        g = self._gbuf()
+        return g.data_ptr() + self.c0 * g.element_size()
+
+    def grad_ready(self):
+        """True when every channel of this slice has received gradient."""
+        c0, c1 = self.c0, self.c0 + self.C
+        cov = sorted(self.st.gwritten)
+        pos = c0
+        for a, b in cov:
+            if a > pos:
+                break
+            pos = max(pos, b)
+            if pos >= c1:
+                return True
+        return pos >= c1
+
+    def grad_target(self):
+        """-> accumulate flag for a writer of this slice's gradient; marks the range as written."""
+        c0, c1 = self.c0, self.c0 + self.C
+        self._gbuf()
+        overl = [(a, b) for a, b in self.st.gwritten if a < c1 and b > c0]
+        if not overl:
+            self.st.gwritten.append((c0, c1))
+            return 0
+        if self.grad_ready():
+            return 1
+        # partially covered: zero the uncovered granules, then accumulate
+        covered = torch.zeros(self.st.C, dtype=torch.bool)
+        for a, b in self.st.gwritten:
+            covered[a:b] = True
+        c = c0
+        while c < c1:
+            if not covered[c]:
+                e = c
+                while e < c1 and not covered[e]:
+                    e += 1
+                self.st.eng.zero_grad_slice(self.st, c, e)
+                c = e
+            else:
+                c += 1
+        self.st.gwritten.append((c0, c1))
+        return 1
+
+
+class Recorder:
+    def __init__(self):
+        self.ops = []  # (cfunc, argtuple, name)
+
+
+class ConvSpec:
+    """Device-side view of one convolution (+ optional BatchNorm) of the model: master fp32 parameters (views into
+    the flat parameter buffer), their gradient views, MFMA-packed fp16 weights and BN coefficient buffers."""
+
+    def __init__(self, name, weight, bias, bn, ks, stride, act, bn_eps=BN2D_EPS, bn_mom=BN2D_MOM):
+        self.name, self.weight, self.bias, self.bn = name, weight, bias, bn  # bn: dict(weight,bias,running_mean,running_var,nbt)|None
+        self.ks, self.stride, self.act = ks, stride, act
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.bn_eps, self.bn_mom = bn_eps, bn_mom
+        self.wpack = self.wpack_t = self.coef = self.bwdcoef = None
+        self.gweight = self.gbias = self.gbn_w = self.gbn_b = None  # fp32 gradient views
+
+
+class Engine:
+    """Owns scratch memory, the tape, the recorder and the stream handle; all ops are methods."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the DEAL-YOLO HIP engine needs a GPU device (no CPU fallback exists by design)")
+        self.L = lib()
+        self.keep = []  # keep-alive list for buffers referenced by recorded launches
+        self.tape = None  # list of backward closures while training-tracing
+        self.rec = None  # active Recorder
+        self._scratch = {}
+        self._ident = {}
+        self.training = False
+        self._tmp_int = C.c_int(0)
+
+    # ---- launch plumbing ------------------------------------------------------------------------------------------
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def call(self, name, *args):
+        fn = getattr(self.L, name)
+        full = args + (self.stream,)
+        rc = fn(*full)
+        check(rc, name)
+        if self.rec is not None:
+            self.rec.ops.append((fn, args, name))
+
+    def replay(self, rec):
+        """Re-issue a recorded launch list on the CURRENT stream (which may be a capturing stream)."""
+        s = self.stream
+        for fn, args, name in rec.ops:
+            rc = fn(*args, s)
+            if rc != 0:
+                check(rc, name)
+
+    def scratch(self, key, nbytes):
+        """Stream-ordered scratch reused across layers (partials, slabs, raw-gradient staging)."""
+        t = self._scratch.get(key)
+        if t is None or t.numel() < nbytes:
+            # growing is safe while recording: launches already recorded keep using the old (kept-alive) buffer, and
+            # scratch carries no state from one op to the next
+            t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+            self._scratch[key] = t
+            self.keep.append(t)
+        return t
+
+    def new_storage(self, N, H, W, C, dtype=torch.float16):
+        st = Storage(self, N, H, W, C, dtype)
+        self.keep.append(st.buf)
+        return st
+
+    def new_act(self, N, H, W, C):
+        return self.new_storage(N, H, W, C).act()
+
+    def f32(self, n, fill=None):
+        t = torch.empty(n, dtype=torch.float32, device=self.device) if fill is None else torch.full(
+            (n,), float(fill), dtype=torch.float32, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def zero_grad_slice(self, st, c0, c1):
+        # zero one channel range of a gradient twin: add(zeros) is not available, so use copy from a zero storage
+        need = st.N * st.H * st.W * (c1 - c0) * 2
+        z = getattr(self, "_zeros", None)
+        if z is None or z.numel() < need:
+            z = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            self._zeros = z
+            self.keep.append(z)
+        self.call("dy_copy_slice", z.data_ptr(), c1 - c0, st.gbuf.data_ptr() + 2 * c0, st.C, st.N * st.H * st.W, c1 - c0)
+
+    # ---- parameter plumbing ---------------------------------------------------------------------------------------
+    def prepare_conv(self, spec: ConvSpec):
+        """Allocate packed-weight / coefficient buffers of a ConvSpec (idempotent)."""
+        if spec.wpack is not None:
+            return
+        g = [C.c_int() for _ in range(8)]
+        cin_phys = (spec.cin + 7) // 8 * 8
+        check(self.L.dy_conv_geometry(spec.cin, spec.cout, spec.ks, spec.stride, *[C.byref(x) for x in g]), "dy_conv_geometry")
+        spec.wpack = torch.zeros(g[7].value, dtype=torch.float16, device=self.device)
+        cout_phys = (spec.cout + 7) // 8 * 8
+        check(self.L.dy_conv_geometry(cout_phys, spec.cin, spec.ks, 1, *[C.byref(x) for x in g]), "dy_conv_geometry")
+        spec.wpack_t = torch.zeros(g[7].value, dtype=torch.float16, device=self.device)
+        spec.cin_phys, spec.cout_phys = cin_phys, cout_phys
+        if spec.bn is not None:
+            spec.coef = self.f32(4 * spec.cout)
+            spec.bwdcoef = self.f32(2 * spec.cout)
+        self.keep += [spec.wpack, spec.wpack_t]
+
+    def pack(self, spec: ConvSpec, fold_scale=None, transposed=True):
+        self.prepare_conv(spec)
+        self.call("dy_pack_weights", spec.weight.data_ptr(), _ptr(fold_scale), spec.wpack.data_ptr(), spec.cout, spec.cin,
+                  spec.ks, spec.stride, 0)
+        if transposed:
+            self.call("dy_pack_weights", spec.weight.data_ptr(), 0, spec.wpack_t.data_ptr(), spec.cout, spec.cin, spec.ks,
+                      spec.stride, 1)
+
+    def ident_coef(self, Cn):
+        t = self._ident.get(Cn)
+        if t is None:
+            t = torch.cat([torch.ones(Cn), torch.zeros(Cn), torch.zeros(Cn), torch.ones(Cn)]).to(self.device)
+            self._ident[Cn] = t
+            self.keep.append(t)
+        return t
+
+    # ---- ops ------------------------------------------------------------------------------------------------------
+    def import_image(self, img, cp=8, mul=1.0):
+        """NCHW fp32 image batch -> NHWC fp16 Act with channels zero-padded to ``cp`` (no gradient)."""
+        N, Cc, H, W = img.shape
+        assert img.dtype == torch.float32 and img.is_contiguous()
+        out = self.new_act(N, H, W, cp)
+        out.needs_grad = False
+        self.call("dy_import_image", img.data_ptr(), out.ptr, N, Cc, H, W, cp, float(mul))
+        return out
+
+    def _conv_raw(self, spec, x, y_ptr, ldy, epi, partials_ptr=0, bias=None):
+        self.call("dy_conv_forward", x.ptr, x.ld, spec.wpack.data_ptr(), _ptr(bias), y_ptr, ldy, partials_ptr, x.N, x.H, x.W,
+                  x.C, spec.cout, spec.ks, spec.stride, 1, 0, 0, epi, None)
+
+    def out_hw(self, spec, x):
+        p = spec.ks // 2
+        return (x.H + 2 * p - spec.ks) // spec.stride + 1, (x.W + 2 * p - spec.ks) // spec.stride + 1
+
+    def conv_bn_act(self, spec: ConvSpec, x: Act, out: Act | None = None, res: Act | None = None):
+        """Conv.forward (reference nn/modules/conv.py:49-55) with training-mode BatchNorm; optional fused residual
+        (Bottleneck.forward, nn/modules/block.py:333-335).  In eval mode BN uses running statistics."""
+        assert x.C == spec.cin_phys, (spec.name, x.C, spec.cin_phys)
+        Ho, Wo = self.out_hw(spec, x)
+        raw = self.new_act(x.N, Ho, Wo, spec.cout)
+        y = out if out is not None else self.new_act(x.N, Ho, Wo, spec.cout)
+        assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, spec.cout), (spec.name, (y.N, y.H, y.W, y.C), (x.N, Ho, Wo, spec.cout))
+        npix = x.N * Ho * Wo
+        bn = spec.bn
+        if self.training:
+            nparts = self.L.dy_conv_num_partials(x.N, x.H, x.W, spec.ks, spec.stride, 1)
+            part = self.scratch("partials", nparts * 2 * ((spec.cout + 15) // 16 * 16) * 4 + 4096)
+            self._conv_raw(spec, x, raw.ptr, raw.ld, DY_EPI_STATS, part.data_ptr())
+            cp16 = (spec.cout + 15) // 16 * 16
+            assert cp16 == spec.cout, "BN channel counts must be multiples of 16"
+            self.call("dy_bn_finalize", part.data_ptr(), nparts, 1.0, 0, 0, 0.0, 0, 0, 0.0, bn["weight"].data_ptr(),
+                      bn["bias"].data_ptr(), bn["running_mean"].data_ptr(), bn["running_var"].data_ptr(),
+                      spec.coef.data_ptr(), spec.cout, float(npix), spec.bn_eps, spec.bn_mom, 1)
+        else:
+            self._conv_raw(spec, x, raw.ptr, raw.ld, 0)
+            self.call("dy_bn_eval_coef", bn["weight"].data_ptr(), bn["bias"].data_ptr(), bn["running_mean"].data_ptr(),
+                      bn["running_var"].data_ptr(), spec.coef.data_ptr(), spec.cout, spec.bn_eps)
+        self.call("dy_bn_act_apply", raw.ptr, raw.ld, 0 if res is None else res.ptr, 0 if res is None else res.ld, y.ptr, y.ld,
+                  spec.coef.data_ptr(), npix, spec.cout, spec.act)
+        if self.tape is not None:
+            self.tape.append(lambda: self._conv_bn_act_bwd(spec, x, raw, y, res))
+        return y
+
+    def _conv_bn_act_bwd(self, spec, x, raw, y, res):
+        assert y.grad_ready(), f"gradient of {spec.name} output incomplete"
+        npix = y.npix
+        if res is not None and res.needs_grad:
+            acc = res.grad_target()
+            if acc:
+                self.call("dy_add", res.gptr, res.ld, y.gptr, y.ld, 0, 0, res.gptr, res.ld, npix, res.C)
+            else:
+                self.call("dy_copy_slice", y.gptr, y.ld, res.gptr, res.ld, npix, res.C)
+        part = self.scratch("partials", 2048 * 2 * spec.cout * 4 + 4096)
+        n = C.c_int(0)
+        self.call("dy_bn_act_bwd_reduce", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), part.data_ptr(), 2048, npix,
+                  spec.cout, spec.act, C.byref(n))
+        self.call("dy_bn_bwd_finalize", part.data_ptr(), n.value, spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(),
+                  spec.bwdcoef.data_ptr(), spec.cout, float(npix), 0)
+        draw = self.scratch("draw", npix * spec.cout * 2)
+        self.call("dy_bn_act_bwd_apply", y.gptr, y.ld, raw.ptr, raw.ld, draw.data_ptr(), spec.cout, spec.coef.data_ptr(),
+                  spec.bwdcoef.data_ptr(), npix, spec.cout, spec.act, 0)
+        self._conv_bwd(spec, x, draw.data_ptr(), spec.cout, y.H, y.W)
+
+    def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0):
+        """weight gradient + input gradient of one convolution given d(raw output) (fp16, (N,Ho,Wo,lddy))."""
+        ns, se = C.c_int(), C.c_long()
+        self.L.dy_wgrad_workspace(x.N, x.H, x.W, spec.cin, spec.cout, spec.ks, spec.stride, C.byref(ns), C.byref(se))
+        slabs = self.scratch("slabs", ns.value * se.value * 4)
+        self.call("dy_conv_wgrad", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), spec.gweight.data_ptr(), x.N, x.H, x.W,
+                  spec.cin, spec.cout, spec.ks, spec.stride, accumulate_w)
+        if x.needs_grad:
+            acc = x.grad_target()
+            self.call("dy_conv_forward", dy_ptr, lddy, spec.wpack_t.data_ptr(), 0, x.gptr, x.ld, 0, x.N, Ho, Wo,
+                      spec.cout_phys, spec.cin, spec.ks, 1, spec.stride, x.H, x.W, DY_EPI_ACCUM if acc else 0, None)
+
+    def conv_fused(self, spec: ConvSpec, x: Act, out: Act | None = None, res: Act | None = None):
+        """Conv.forward_fuse (reference nn/modules/conv.py:57-59): BN folded into weights + bias, SiLU in the epilogue."""
+        Ho, Wo = self.out_hw(spec, x)
+        y = out if out is not None else self.new_act(x.N, Ho, Wo, spec.cout)
+        epi = DY_EPI_BIAS | (DY_EPI_SILU if spec.act == DY_ACT_SILU else 0)
+        self._conv_raw(spec, x, y.ptr, y.ld, epi, 0, spec.bias)
+        if res is not None:
+            self.call("dy_add", y.ptr, y.ld, res.ptr, res.ld, 0, 0, y.ptr, y.ld, y.npix, y.C)
+        return y
+
+    def conv_bias(self, spec: ConvSpec, x: Act, y_ptr, ldy, f32out=True, dy_ptr_fn=None, out_hw=None):
+        """Plain conv + bias (Detect's final nn.Conv2d 1x1, reference nn/modules/head.py:38-42).  ``dy_ptr_fn`` returns
+        (ptr, ld) of the fp16 gradient w.r.t. the output at backward time."""
+        self._conv_raw(spec, x, y_ptr, ldy, DY_EPI_BIAS | (DY_EPI_F32OUT if f32out else 0), 0, spec.bias)
+        if self.tape is not None:
+            self.tape.append(lambda: self._conv_bias_bwd(spec, x, dy_ptr_fn))
+
+    def _conv_bias_bwd(self, spec, x, dy_ptr_fn, accumulate=0):
+        dyp, ld = dy_ptr_fn()
+        Ho, Wo = self.out_hw(spec, x)
+        npix = x.N * Ho * Wo
+        cp = spec.cout_phys
+        part = self.scratch("partials", 2048 * 2 * cp * 4 + 4096)
+        n = C.c_int(0)
+        ident = self.ident_coef(cp)
+        self.call("dy_bn_act_bwd_reduce", dyp, ld, dyp, ld, ident.data_ptr(), part.data_ptr(), 2048, npix, cp, DY_ACT_NONE,
+                  C.byref(n))
+        tmp = self.scratch("bwdcoef_tmp", 2 * cp * 4)
+        self.call("dy_bn_bwd_finalize", part.data_ptr(), n.value, 0, spec.gbias.data_ptr(), tmp.data_ptr(), cp, 1.0, accumulate)
+        self._conv_bwd(spec, x, dyp, ld, Ho, Wo, accumulate)
+
+    def upsample2x(self, x: Act, out: Act | None = None):
+        y = out if out is not None else self.new_act(x.N, 2 * x.H, 2 * x.W, x.C)
+        self.call("dy_upsample2x", x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, 0, 0)
+        if self.tape is not None:
+            def bwd():
+                acc = x.grad_target()
+                self.call("dy_upsample2x", y.gptr, y.ld, x.gptr, x.ld, x.N, x.H, x.W, x.C, 1, acc)
+            self.tape.append(bwd)
+        return y
+
+    def maxpool5(self, x: Act, out: Act):
+        arg = torch.empty(x.npix * x.C, dtype=torch.uint8, device=self.device)
+        self.keep.append(arg)
+        self.call("dy_maxpool5", x.ptr, x.ld, out.ptr, out.ld, arg.data_ptr(), x.N, x.H, x.W, x.C)
+        if self.tape is not None:
+            def bwd():
+                acc = x.grad_target()
+                self.call("dy_maxpool5_backward", out.gptr, out.ld, arg.data_ptr(), x.gptr, x.ld, x.N, x.H, x.W, x.C, acc)
+            self.tape.append(bwd)
+        return out
+
+    def add(self, xs, out: Act | None = None):
+        a = xs[0]
+        y = out if out is not None else self.new_act(a.N, a.H, a.W, a.C)
+        b = xs[1]
+        c = xs[2] if len(xs) > 2 else None
+        assert len(xs) <= 3
+        self.call("dy_add", a.ptr, a.ld, b.ptr, b.ld, 0 if c is None else c.ptr, 0 if c is None else c.ld, y.ptr, y.ld, a.npix, a.C)
+        if self.tape is not None:
+            def bwd():
+                for t in xs:
+                    if not t.needs_grad:
+                        continue
+                    acc = t.grad_target()
+                    if acc:
+                        self.call("dy_add", t.gptr, t.ld, y.gptr, y.ld, 0, 0, t.gptr, t.ld, t.npix, t.C)
+                    else:
+                        self.call("dy_copy_slice", y.gptr, y.ld, t.gptr, t.ld, t.npix, t.C)
+            self.tape.append(bwd)
+        return y
+
+    def concat(self, xs, out_storage=None):
+        """Concat (reference nn/modules/conv.py:338-348).  Inputs already living in consecutive slices of one Storage
+        are returned as a view; anything else is copied."""
+        st = xs[0].st
+        pos = xs[0].c0
+        inplace = True
+        for t in xs:
+            if t.st is not st or t.c0 != pos:
+                inplace = False
+                break
+            pos += t.C
+        if inplace:
+            return Act(st, xs[0].c0, pos - xs[0].c0)
+        a = xs[0]
+        y = self.new_act(a.N, a.H, a.W, sum(t.C for t in xs))
+        off = 0
+        parts = []
+        for t in xs:
+            self.call("dy_copy_slice", t.ptr, t.ld, y.ptr + 2 * off, y.ld, t.npix, t.C)
+            parts.append((t, off))
+            off += t.C
+        if self.tape is not None:
+            def bwd():
+                for t, o in parts:
+                    if not t.needs_grad:
+                        continue
+                    acc = t.grad_target()
+                    gsrc = y.gptr + 2 * o
+                    if acc:
+                        self.call("dy_add", t.gptr, t.ld, gsrc, y.ld, 0, 0, t.gptr, t.ld, t.npix, t.C)
+                    else:
+                        self.call("dy_copy_slice", gsrc, y.ld, t.gptr, t.ld, t.npix, t.C)
+            self.tape.append(bwd)
+        return y
+
+    # ---- ScalSeq (reference nn/extra_modules/block.py:3426-3443) --------------------------------------------------
+    def scalseq(self, conv3d: ConvSpec, bn3d, coef, bwdcoef, gbn, ps, out: Act | None = None):
+        """ps = [p3 (full res), p4 (1/2), p5 (1/4)] already channel-matched.  conv3d: 1x1x1 conv with bias applied to
+        every scale at its native resolution (a 1x1 conv commutes with nearest up-sampling); BatchNorm3d statistics
+        are those of the up-sampled (B,3,H,W) volume, i.e. level l weighs 4**l."""
+        p3 = ps[0]
+        N, H, W, Cc = p3.N, p3.H, p3.W, conv3d.cout
+        assert ps[1].H * 2 == H and ps[2].H * 4 == H and ps[1].W * 2 == W and ps[2].W * 4 == W, "ScalSeq needs exact 2x/4x pyramids"
+        raws, nps, offs = [], [], []
+        cp16 = (Cc + 15) // 16 * 16
+        total = 0
+        for l, p in enumerate(ps):
+            n = self.L.dy_conv_num_partials(p.N, p.H, p.W, 1, 1, 1)
+            nps.append(n)
+            offs.append(total)
+            total += n * 2 * cp16 * 4
+        part = self.scratch("partials_ss", total + 4096)
+        for l, p in enumerate(ps):
+            r = self.new_act(p.N, p.H, p.W, Cc)
+            epi = DY_EPI_BIAS | (DY_EPI_STATS if self.training else 0)
+            self._conv_raw(conv3d, p, r.ptr, r.ld, epi, part.data_ptr() + offs[l], conv3d.bias)
+            raws.append(r)
+        if self.training:
+            self.call("dy_bn_finalize", part.data_ptr() + offs[0], nps[0], 1.0, part.data_ptr() + offs[1], nps[1], 4.0,
+                      part.data_ptr() + offs[2], nps[2], 16.0, bn3d["weight"].data_ptr(), bn3d["bias"].data_ptr(),
+                      bn3d["running_mean"].data_ptr(), bn3d["running_var"].data_ptr(), coef.data_ptr(), Cc,
+                      float(3 * N * H * W), BN3D_EPS, BN3D_MOM, 1)
+        else:
+            self.call("dy_bn_eval_coef", bn3d["weight"].data_ptr(), bn3d["bias"].data_ptr(), bn3d["running_mean"].data_ptr(),
+                      bn3d["running_var"].data_ptr(), coef.data_ptr(), Cc, BN3D_EPS)
+        y = out if out is not None else self.new_act(N, H, W, Cc)
+        self.call("dy_scalseq_tail", raws[0].ptr, raws[0].ld, raws[1].ptr, raws[1].ld, raws[2].ptr, raws[2].ld, 0, 0, y.ptr,
+                  y.ld, coef.data_ptr(), N, H, W, Cc)
+        if self.tape is not None:
+            self.tape.append(lambda: self._scalseq_bwd(conv3d, coef, bwdcoef, gbn, ps, raws, y))
+        return y
+
+    def _scalseq_bwd(self, conv3d, coef, bwdcoef, gbn, ps, raws, y):
+        assert y.grad_ready()
+        N, H, W, Cc = y.N, y.H, y.W, y.C
+        part = self.scratch("partials_ss", 3 * 1024 * 2 * Cc * 4 + 4096)
+        base = part.data_ptr()
+        rargs = (raws[0].ptr, raws[0].ld, raws[1].ptr, raws[1].ld, raws[2].ptr, raws[2].ld, y.gptr, y.ld)
+        tot = 0
+        for l in range(3):
+            n = C.c_int(0)
+            self.call("dy_scalseq_tail_backward", *rargs, 0, 0, coef.data_ptr(), 0, base + tot * 2 * Cc * 4, 1024, N, H, W, Cc, l, 0,
+                      C.byref(n))
+            tot += n.value
+        self.call("dy_bn_bwd_finalize", base, tot, gbn[0].data_ptr(), gbn[1].data_ptr(), bwdcoef.data_ptr(), Cc, float(3 * N * H * W), 0)
+        for l in range(3):
+            p = ps[l]
+            dr = self.scratch("draw", p.npix * Cc * 2)
+            self.call("dy_scalseq_tail_backward", *rargs, dr.data_ptr(), Cc, coef.data_ptr(), bwdcoef.data_ptr(), 0, 0, N, H, W, Cc, l, 1,
+                      None)
+            # shared conv3d weights/bias: the three scales accumulate into one gradient
+            self._conv_bias_bwd(conv3d, p, lambda dr=dr, Cc=Cc: (dr.data_ptr(), Cc), accumulate=1 if l else 0)
+
+    # ---- loss -----------------------------------------------------------------------------------------------------
+    def zero_f32(self, t):
+        self.call("dy_fill_zero", t.data_ptr(), t.numel() * t.element_size())

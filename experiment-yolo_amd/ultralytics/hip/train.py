@@ -1,0 +1,161 @@
+"""One training step of DEAL-YOLO as a static launch plan (reference hot loop engine/trainer.py:780-815, 949-957).
+
+The first call traces forward + loss + backward (+ optimizer) through the Python modules while every launch is
+recorded; later calls replay the recorded lists -- optionally captured into hipGraphs -- so steady-state steps touch no
+module code, no allocator and no host synchronisation.  Gradients of all ranks are summed with ONE RCCL all-reduce over
+the flat fp32 gradient buffer (the reference multiplies the loss by world_size and lets DDP average: same result).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import check
+from .engine import Recorder
+
+
+class StepPlan:
+    def __init__(self, model, batch_size, imgsz, nmax=16, optimizer="SGD", hyp=None, world_size=1, use_graph=False,
+                 init_scale=65536.0):
+        self.model = model
+        dev = next(model.parameters()).device
+        self.rt = model._runtime(dev)
+        self.eng = self.rt.eng
+        self.B, self.imgsz, self.nmax = batch_size, (imgsz, imgsz) if isinstance(imgsz, int) else tuple(imgsz), nmax
+        self.world_size = world_size
+        self.use_graph = use_graph
+        self.mode = {"SGD": 0, "Adam": 1, "AdamW": 2}[optimizer]
+        self.crit = model.criterion if hasattr(model, "criterion") else model.init_criterion()
+        model.criterion = self.crit
+        n = self.rt.n_params_flat
+        f = lambda: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
+        self.mom = f()
+        self.adam_v = f() if self.mode else None
+        self.ema = self.rt.flat_p.clone()
+        self.ema_b = self.rt.flat_b.clone()
+        self.hyper_host = torch.zeros(16, dtype=torch.float32).pin_memory()
+        self.hyper = torch.zeros(16, dtype=torch.float32, device=dev)
+        self.state = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.state[0] = init_scale
+        self.partials = torch.zeros(4096, dtype=torch.float32, device=dev)
+        self.img = torch.zeros((batch_size, 3, *self.imgsz), dtype=torch.float32, device=dev)
+        self.rec_fb = None
+        self.rec_opt, self.graph_opt = {}, {}
+        self.graph_fb = None
+        self.gsum, self._micro = None, 0
+        self.ema_updates = 0
+        self.rt.refresh_frozen()
+
+    # ---- host-side schedule ------------------------------------------------------------------------------------
+    def set_hyper(self, lr, momentum, wd, ema_decay=None, max_norm=10.0, beta2=0.999, eps=1e-8):
+        h = self.hyper_host
+        h[0:3] = torch.tensor(lr, dtype=torch.float32)
+        h[3] = momentum
+        h[4:7] = torch.tensor(wd, dtype=torch.float32)
+        if ema_decay is None:
+            ema_decay = 0.9999 * (1 - math.exp(-(self.ema_updates + 1) / 2000))
+        h[7], h[8], h[9], h[10] = ema_decay, max_norm, beta2, eps
+        self.hyper.copy_(h, non_blocking=True)
+
+    # ---- forward + loss + backward ----------------------------------------------------------------------------
+    def _trace_fb(self, batch):
+        eng, rt, model, crit = self.eng, self.rt, self.model, self.crit
+        eng.rec = Recorder()
+        eng.tape = []
+        eng.training = True
+        try:
+            rt.pack_all(transposed=True)
+            x = eng.import_image(self.img, 8)
+            ho = model.forward_act(x)
+            crit.bind(ho, self.nmax, gscale=self.state[0:1])
+            crit.sync_modes()
+            eng.call("dy_detection_loss", C.byref(crit._args))
+            for f in reversed(eng.tape):
+                f()
+        finally:
+            rec, eng.rec, eng.tape = eng.rec, None, None
+        self.ho = ho
+        return rec
+
+    def forward_backward(self, batch):
+        """Stage the batch, run fwd+loss+bwd; gradients (scaled by the loss scale) land in rt.flat_g."""
+        img = batch["img"]
+        if img.dtype == torch.uint8:
+            img = img.float() / 255
+        self.img.copy_(img, non_blocking=True)
+        n = self.crit.set_targets(batch, cap=self.B * self.nmax)
+        if n > self.B * self.nmax:
+            raise RuntimeError(f"{n} targets exceed the plan capacity {self.B}x{self.nmax}")
+        self.crit.sync_modes()
+        if self.rec_fb is None:
+            self.rec_fb = self._trace_fb(batch)
+            if self.use_graph:
+                torch.cuda.synchronize()
+                self.graph_fb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_fb):
+                    self.eng.replay(self.rec_fb)
+        elif self.graph_fb is not None:
+            self.graph_fb.replay()
+        else:
+            self.eng.replay(self.rec_fb)
+        return self.crit.scalars
+
+    # ---- optimizer ----------------------------------------------------------------------------------------------
+    def all_reduce(self):
+        if self.world_size > 1:
+            dist.all_reduce(self.rt.flat_g, op=dist.ReduceOp.SUM)
+
+    def accumulate(self):
+        """Gradient accumulation across micro-batches (reference engine/trainer.py:812: step only every ``accumulate``
+        iterations): fold this micro-step's gradients into the running sum the optimizer will read."""
+        if self.gsum is None:
+            self.gsum = torch.zeros_like(self.rt.flat_g)
+        if self._micro == 0:
+            self.gsum.copy_(self.rt.flat_g)
+        else:
+            self.eng.call("dy_axpy_f32", self.gsum.data_ptr(), self.rt.flat_g.data_ptr(), 1.0, self.rt.n_params_flat)
+        self._micro += 1
+
+    def optimizer_step(self):
+        rt, eng = self.rt, self.eng
+        grads = self.gsum if self._micro else rt.flat_g
+        key = grads.data_ptr()
+        if key not in self.rec_opt:
+            eng.rec = Recorder()
+            try:
+                b = rt.group_bounds
+                eng.call("dy_optimizer_step", rt.flat_p.data_ptr(), grads.data_ptr(), self.mom.data_ptr(),
+                         0 if self.adam_v is None else self.adam_v.data_ptr(), self.ema.data_ptr(), rt.n_params_flat, b[0], b[1],
+                         rt.frozen.data_ptr(), rt.flat_b.data_ptr(), self.ema_b.data_ptr(), rt.n_buffers_flat,
+                         self.hyper.data_ptr(), self.state.data_ptr(), self.partials.data_ptr(), self.mode)
+            finally:
+                self.rec_opt[key], eng.rec = eng.rec, None
+            if self.use_graph:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    eng.replay(self.rec_opt[key])
+                self.graph_opt[key] = g
+        elif key in self.graph_opt:
+            self.graph_opt[key].replay()
+        else:
+            eng.replay(self.rec_opt[key])
+        self.ema_updates += 1
+        self._micro = 0
+        rt.mark_dirty()
+
+    def step(self, batch, lr, momentum, wd):
+        """forward/backward + gradient all-reduce + optimizer/EMA: one iteration at accumulate == 1."""
+        self.set_hyper(lr, momentum, wd)
+        self.forward_backward(batch)
+        self.all_reduce()
+        self.optimizer_step()
+
+    def loss_items(self):
+        """(loss*B, [box, cls, dfl]) -- synchronises."""
+        s = self.crit.scalars.cpu()
+        return float(s[8]), s[5:8].clone()

@@ -1,0 +1,82 @@
+"""Block modules of the DEAL-YOLO graph: DFL, SPPF, C2f, Bottleneck (drop-in for reference nn/modules/block.py)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ...hip.runtime import HipModule
+from .conv import Conv
+
+__all__ = ("DFL", "SPPF", "C2f", "Bottleneck")
+
+
+class DFL(nn.Module):
+    """Integral of the distribution-focal-loss bins (reference nn/modules/block.py:37-55).  Only a parameter holder here:
+    the frozen arange 'conv' is applied inside the decode / loss kernels."""
+
+    def __init__(self, c1=16):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, 1, 1, bias=False).requires_grad_(False)
+        self.conv.weight.data[:] = torch.arange(c1, dtype=torch.float).view(1, c1, 1, 1)
+        self.c1 = c1
+
+
+class Bottleneck(HipModule):
+    """3x3 -> 3x3 with optional shortcut (reference nn/modules/block.py:320-335)."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, k=(3, 3), e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        k0 = k[0][0] if isinstance(k[0], (tuple, list)) else k[0]
+        k1 = k[1][0] if isinstance(k[1], (tuple, list)) else k[1]
+        self.cv1 = Conv(c1, c_, k0, 1)
+        self.cv2 = Conv(c_, c2, k1, 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def forward_act(self, x, out=None):
+        return self.cv2.forward_act(self.cv1.forward_act(x), out, x if self.add else None)
+
+
+class C2f(HipModule):
+    """CSP bottleneck with two convolutions (reference nn/modules/block.py:209-232).  chunk/cat are free: cv1 writes its
+    two halves and every Bottleneck its output straight into channel slices of ONE buffer that cv2 then reads."""
+
+    def __init__(self, c1, c2, n=1, shortcut=False, g=1, e=0.5):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
+
+    def forward_act(self, x, out=None):
+        eng, c, n = self.rt.eng, self.c, len(self.m)
+        cat = eng.new_storage(x.N, x.H, x.W, (2 + n) * c)
+        self.cv1.forward_act(x, cat.act(0, 2 * c))
+        prev = cat.act(c, c)
+        for j, b in enumerate(self.m):
+            prev = b.forward_act(prev, cat.act((2 + j) * c, c))
+        return self.cv2.forward_act(cat.act(), out)
+
+    forward_split = HipModule.forward
+
+
+class SPPF(HipModule):
+    """Spatial pyramid pooling - fast (reference nn/modules/block.py:151-171)."""
+
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        if k != 5:
+            raise NotImplementedError("SPPF: only k=5 pooling is implemented on the HIP path")
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1)
+        self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
+
+    def forward_act(self, x, out=None):
+        eng = self.rt.eng
+        c_ = self.cv1.conv.out_channels
+        cat = eng.new_storage(x.N, x.H, x.W, 4 * c_)
+        self.cv1.forward_act(x, cat.act(0, c_))
+        for j in range(3):
+            eng.maxpool5(cat.act(j * c_, c_), cat.act((j + 1) * c_, c_))
+        return self.cv2.forward_act(cat.act(), out)

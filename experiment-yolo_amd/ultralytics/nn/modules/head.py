@@ -1,0 +1,94 @@
+"""Detect head (drop-in for reference nn/modules/head.py:19-87)."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from ...hip import DY_ACT_NONE
+from ...hip.runtime import HipModule
+from .block import DFL
+from .conv import Conv
+
+__all__ = ("Detect",)
+
+
+class HeadOut:
+    """Raw head outputs of one forward: per level fp32 (B,H,W,64) DFL logits and (B,H,W,ncp) class logits (ncp = nc
+    rounded up to 8), plus lazily created fp16 gradient buffers of the same shapes (filled by the loss kernels)."""
+
+    def __init__(self, box, cls, nc, strides):
+        self.box, self.cls, self.nc, self.strides = box, cls, nc, strides
+        self.dbox = self.dcls = None
+
+    def alloc_grads(self):
+        if self.dbox is None:
+            self.dbox = [torch.zeros(b.shape, dtype=torch.float16, device=b.device) for b in self.box]
+            self.dcls = [torch.zeros(c.shape, dtype=torch.float16, device=c.device) for c in self.cls]
+
+    def as_reference_list(self):
+        """[(B, no, H, W)] fp32 views/copies in the reference's training-output format (head.py:45-48)."""
+        return [torch.cat((b, c[..., : self.nc]), -1).permute(0, 3, 1, 2) for b, c in zip(self.box, self.cls)]
+
+
+class Detect(HipModule):
+    """YOLOv8 Detect head: per level cv2 = Conv3x3 -> Conv3x3 -> Conv2d1x1(64), cv3 = ... -> Conv2d1x1(nc)."""
+    dynamic = False
+    export = False
+    shape = None
+    anchors = torch.empty(0)
+    strides = torch.empty(0)
+
+    def __init__(self, nc=80, ch=()):
+        super().__init__()
+        self.nc = nc
+        self.nl = len(ch)
+        self.reg_max = 16
+        self.no = nc + self.reg_max * 4
+        self.stride = torch.zeros(self.nl)
+        c2, c3 = max((16, ch[0] // 4, self.reg_max * 4)), max(ch[0], min(self.nc, 100))
+        self.cv2 = nn.ModuleList(nn.Sequential(Conv(x, c2, 3), Conv(c2, c2, 3), nn.Conv2d(c2, 4 * self.reg_max, 1)) for x in ch)
+        self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, self.nc, 1)) for x in ch)
+        self.dfl = DFL(self.reg_max) if self.reg_max > 1 else nn.Identity()
+
+    def _build_specs(self, rt):
+        for br in ("cv2", "cv3"):
+            for l, seq in enumerate(getattr(self, br)):
+                rt.make_spec((id(self), br, l), seq[2], None, DY_ACT_NONE, 1, 1, name=f"Detect.{br}.{l}.2")
+
+    def bias_init(self):
+        """Reference head.py:76-83 (requires stride)."""
+        for a, b, s in zip(self.cv2, self.cv3, self.stride):
+            a[-1].bias.data[:] = 1.0
+            b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / s) ** 2)
+
+    def forward_act(self, xs, out=None):
+        rt = self.rt
+        eng = rt.eng
+        ncp = (self.nc + 7) // 8 * 8
+        nb = 4 * self.reg_max
+        boxes = [torch.empty((x.N, x.H, x.W, nb), dtype=torch.float32, device=eng.device) for x in xs]
+        clss = [torch.zeros((x.N, x.H, x.W, ncp), dtype=torch.float32, device=eng.device) for x in xs]
+        eng.keep += boxes + clss
+        ho = HeadOut(boxes, clss, self.nc, [float(s) for s in self.stride])
+        if eng.tape is not None:
+            ho.alloc_grads()
+            eng.keep += ho.dbox + ho.dcls
+        for l, x in enumerate(xs):
+            a = self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(x))
+            c = self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(x))
+            eng.conv_bias(rt.specs[(id(self), "cv2", l)], a, boxes[l].data_ptr(), nb, True,
+                          lambda l=l: (ho.dbox[l].data_ptr(), nb))
+            eng.conv_bias(rt.specs[(id(self), "cv3", l)], c, clss[l].data_ptr(), ncp, True,
+                          lambda l=l: (ho.dcls[l].data_ptr(), ncp))
+        return ho
+
+    def _export(self, rt, y):
+        if isinstance(y, HeadOut):
+            feats = y.as_reference_list()
+            if self.training:
+                return feats
+            from ...utils.ops import decode_predictions
+            return decode_predictions(y), feats
+        return super()._export(rt, y)

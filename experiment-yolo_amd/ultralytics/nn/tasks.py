@@ -1,0 +1,312 @@
+"""Model graph: YAML -> module list -> DetectionModel (drop-in for the detection part of reference nn/tasks.py).
+
+Differences from the reference that are deliberate:
+  * strides are derived statically from the graph instead of a zeros(2,3,640,640) probe forward (tasks.py:309-317), so a
+    model can be built on a host without GPU;
+  * the forward runs on the HIP engine (NHWC fp16 Acts); ``model(batch_dict)`` returns ``(loss*B, loss_items)`` exactly as
+    ``BaseModel.forward`` does (tasks.py:63-65) with both tensors living on the device and no host synchronisation.
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+import re
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+import yaml
+
+from ..hip.engine import Act
+from ..hip.runtime import HipModule, Runtime
+from .extra_modules.block import Add, ScalSeq, Zoom_cat
+from .modules import SPPF, C2f, Concat, Conv, Detect, LDConv
+
+CFG_MODELS = Path(__file__).resolve().parent.parent / "cfg" / "models"
+
+
+def make_divisible(x, divisor=8):
+    return int(math.ceil(x / divisor) * divisor)
+
+
+class Upsample(HipModule):
+    """nn.Upsample(None, 2, 'nearest') of the model YAMLs, on the HIP engine."""
+
+    def __init__(self, size=None, scale_factor=None, mode="nearest"):
+        super().__init__()
+        if size is not None or int(scale_factor) != 2 or mode != "nearest":
+            raise NotImplementedError("only nn.Upsample(None, 2, 'nearest') is on the hot path")
+        self.size, self.scale_factor, self.mode = size, float(scale_factor), mode
+
+    def forward_act(self, x, out=None):
+        return self.rt.eng.upsample2x(x, out)
+
+
+_MODULES = {"Conv": Conv, "LDConv": LDConv, "C2f": C2f, "SPPF": SPPF, "Concat": Concat, "nn.Upsample": Upsample,
+            "ScalSeq": ScalSeq, "Add": Add, "Zoom_cat": Zoom_cat, "Detect": Detect}
+
+
+def guess_model_scale(model_path):
+    """Scale letter from 'yolov8[nslmx]...' (reference tasks.py:1083-1099)."""
+    with contextlib.suppress(AttributeError):
+        return re.search(r"yolov\d+([nslmx])", Path(model_path).stem).group(1)
+    return ""
+
+
+def yaml_model_load(path):
+    """'yolov8n-X.yaml' is served by 'yolov8-X.yaml' with scale 'n' (reference tasks.py:1065-1080); bare names resolve
+    under ultralytics/cfg/models."""
+    path = Path(path)
+    unified = Path(re.sub(r"(\d+)([nslmx])(.+)?$", r"\1\3", str(path)))
+    cands = [unified, path, CFG_MODELS / unified.name, CFG_MODELS / path.name]
+    src = next((c for c in cands if c.is_file()), None)
+    if src is None:
+        raise FileNotFoundError(f"model YAML '{path}' not found (searched {[str(c) for c in cands]})")
+    d = yaml.safe_load(src.read_text(errors="ignore"))
+    d["scale"] = guess_model_scale(path)
+    d["yaml_file"] = str(path)
+    return d
+
+
+def parse_model(d, ch, verbose=True):
+    """YAML dict -> (nn.Sequential, savelist, per-layer down-sampling) for the hot-path module names
+    (reference tasks.py:780-1062, branches :825-864, :905-911, :1001-1008)."""
+    nc, scales = d.get("nc"), d.get("scales")
+    depth, width, max_channels = d.get("depth_multiple", 1.0), d.get("width_multiple", 1.0), float("inf")
+    if scales:
+        scale = d.get("scale") or tuple(scales.keys())[0]
+        depth, width, max_channels = scales[scale]
+    chs, down = [ch], [1.0]
+    layers, save = [], []
+    for i, (f, n, mname, args) in enumerate(d["backbone"] + d["head"]):
+        if mname not in _MODULES:
+            raise NotImplementedError(f"module '{mname}' is outside the DEAL-YOLO hot path (supported: {sorted(_MODULES)})")
+        m = _MODULES[mname]
+        args = [nc if a == "nc" else (None if a == "None" else a) for a in args]
+        n_ = n = max(round(n * depth), 1) if n > 1 else n
+        fl = [f] if isinstance(f, int) else list(f)
+        if m in (Conv, LDConv, C2f, SPPF):
+            c1, c2 = chs[f], args[0]
+            if c2 != nc:
+                c2 = make_divisible(min(c2, max_channels) * width, 8)
+            args = [c1, c2, *args[1:]]
+            if m is C2f:
+                args.insert(2, n)
+                n = 1
+            s = args[3] if (m in (Conv, LDConv) and len(args) > 3) else 1
+            ds = down[f] * s
+        elif m is Upsample:
+            c2, ds = chs[f], down[f] / int(args[1])
+        elif m is Concat:
+            c2, ds = sum(chs[x] for x in fl), down[fl[0]]
+        elif m is Zoom_cat:
+            c2, ds = sum(chs[x] for x in fl), down[fl[1]]
+        elif m is Add:
+            c2, ds = chs[fl[-1]], down[fl[-1]]
+        elif m is ScalSeq:
+            c1 = [chs[x] for x in fl]
+            c2 = make_divisible(args[0] * width, 8)
+            args, ds = [c1, c2], down[fl[0]]
+        elif m is Detect:
+            args.append([chs[x] for x in fl])
+            c2, ds = sum(args[1]) if False else nc + 64, down[fl[0]]
+        m_ = nn.Sequential(*(m(*args) for _ in range(n))) if n > 1 else m(*args)
+        t = f"{m.__module__}.{m.__name__}" if m is not Upsample else "torch.nn.modules.upsampling.Upsample"
+        m_.np = sum(x.numel() for x in m_.parameters())
+        m_.i, m_.f, m_.type = i, f, t
+        if m is Detect:
+            m_.stride = torch.tensor([down[x] for x in fl], dtype=torch.float32)
+        save.extend(x % i for x in fl if x != -1)
+        layers.append(m_)
+        if i == 0:
+            chs, down = [], []
+        chs.append(c2)
+        down.append(ds)
+        _ = n_
+    return nn.Sequential(*layers), sorted(save)
+
+
+def initialize_weights(model):
+    """BN eps/momentum and in-place activations (reference utils/torch_utils.py:342-352; BatchNorm3d is untouched)."""
+    for m in model.modules():
+        t = type(m)
+        if t is nn.BatchNorm2d:
+            m.eps, m.momentum = 1e-3, 0.03
+        elif t in (nn.Hardswish, nn.LeakyReLU, nn.ReLU, nn.ReLU6, nn.SiLU):
+            m.inplace = True
+
+
+class BaseModel(HipModule):
+    """forward / predict / fuse / loss protocol of reference tasks.py:52-270."""
+
+    def forward(self, x, *args, **kwargs):
+        if isinstance(x, dict):
+            return self.loss(x, *args, **kwargs)
+        return self.predict(x, *args, **kwargs)
+
+    def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
+        return HipModule.forward(self, x)
+
+    def _concat_plan(self):
+        """layer index -> (concat layer index, channel offset, total channels): producers that can write straight into a
+        Concat's buffer (each producer is claimed by its first Concat consumer)."""
+        plan, chans = {}, []
+        for m in self.model:
+            chans.append(None)
+        for m in self.model:
+            if isinstance(m, Concat):
+                fl = [m.i + j if j < 0 else j for j in m.f]
+                if len(set(fl)) != len(fl) or any(j in plan for j in fl):
+                    continue
+                ok = all(isinstance(self.model[j], (Conv, LDConv, C2f, SPPF, Upsample, Add, ScalSeq)) for j in fl)
+                if ok:
+                    for pos, j in enumerate(fl):
+                        plan[j] = (m.i, pos)
+        return plan
+
+    def forward_act(self, x, out=None):
+        """BaseModel._predict_once (reference tasks.py:85-126) over engine Acts."""
+        eng = self.rt.eng
+        plan = self._concat_plan()
+        ys, cats = [], {}
+        for m in self.model:
+            if m.f != -1:
+                x = ys[m.f] if isinstance(m.f, int) else [x if j == -1 else ys[j] for j in m.f]
+            dst = None
+            if m.i in plan:
+                ci, pos = plan[m.i]
+                cat_m = self.model[ci]
+                fl = [cat_m.i + j if j < 0 else j for j in cat_m.f]
+                src0 = x[0] if isinstance(x, (list, tuple)) else x
+                if isinstance(m, Upsample):
+                    oh, ow = 2 * src0.H, 2 * src0.W
+                elif hasattr(m, "out_hw"):
+                    oh, ow = m.out_hw(src0.H, src0.W)
+                else:
+                    oh, ow = src0.H, src0.W
+                if ci not in cats:
+                    widths = [self._cout[j] for j in fl]
+                    cats[ci] = (eng.new_storage(src0.N, oh, ow, sum(widths)), widths)
+                st, widths = cats[ci]
+                dst = st.act(sum(widths[:pos]), widths[pos])
+            x = m.forward_act(x, dst) if dst is not None else m.forward_act(x)
+            ys.append(x if m.i in self.save else None)
+        return x
+
+    def fuse(self, verbose=True):
+        """Fold BatchNorm into every ``Conv`` (reference tasks.py:168-195, utils/torch_utils.py:171-198).  LDConv's inner BN
+        and ScalSeq's BatchNorm3d are left alone, as in the reference."""
+        if not self.is_fused():
+            for m in self.modules():
+                if isinstance(m, Conv) and hasattr(m, "bn"):
+                    conv, bn = m.conv, m.bn
+                    fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                                      bias=True).requires_grad_(False).to(conv.weight.device)
+                    scale = bn.weight.detach().float() / torch.sqrt(bn.eps + bn.running_var.detach().float())
+                    fused.weight.copy_(conv.weight.detach().float() * scale.view(-1, 1, 1, 1))
+                    fused.bias.copy_(bn.bias.detach().float() - bn.running_mean.detach().float() * scale)
+                    m.conv = fused
+                    delattr(m, "bn")
+            for m in self.modules():
+                if isinstance(m, HipModule):
+                    m.__dict__.pop("rt", None)
+        return self
+
+    def is_fused(self, thresh=10):
+        bn = tuple(v for k, v in nn.__dict__.items() if "Norm" in k and isinstance(v, type))
+        return sum(isinstance(v, bn) for v in self.modules()) < thresh
+
+    def info(self, detailed=False, verbose=True, imgsz=640):
+        n_p = sum(x.numel() for x in self.parameters())
+        n_l = len(list(self.modules()))
+        if verbose:
+            print(f"{type(self).__name__} summary: {n_l} layers, {n_p} parameters")
+        return n_l, n_p
+
+    def load(self, weights, verbose=True):
+        model = weights["model"] if isinstance(weights, dict) else weights
+        csd = model.float().state_dict() if hasattr(model, "state_dict") else model
+        own = self.state_dict()
+        csd = {k: v for k, v in csd.items() if k in own and own[k].shape == v.shape}
+        self.load_state_dict(csd, strict=False)
+        return len(csd)
+
+    def loss(self, batch, preds=None):
+        """Reference tasks.py:256-268: lazily build the criterion, run forward + loss."""
+        if not hasattr(self, "criterion"):
+            self.criterion = self.init_criterion()
+        return self.criterion(self, batch, preds)
+
+    def init_criterion(self):
+        raise NotImplementedError
+
+
+class DetectionModel(BaseModel):
+    """YOLOv8-style detection model built from a YAML (reference tasks.py:275-378)."""
+
+    def __init__(self, cfg="yolov8n.yaml", ch=3, nc=None, verbose=True):
+        super().__init__()
+        self.yaml = cfg if isinstance(cfg, dict) else yaml_model_load(cfg)
+        ch = self.yaml["ch"] = self.yaml.get("ch", ch)
+        if nc and nc != self.yaml["nc"]:
+            self.yaml["nc"] = nc
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=ch, verbose=verbose)
+        self.names = {i: f"{i}" for i in range(self.yaml["nc"])}
+        self.inplace = self.yaml.get("inplace", True)
+        self._cout = self._layer_channels(ch)
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.inplace = self.inplace
+            self.stride = m.stride
+            m.bias_init()
+        else:
+            self.stride = torch.Tensor([32])
+        initialize_weights(self)
+        if verbose:
+            self.info()
+
+    def _layer_channels(self, ch):
+        out = []
+        for m in self.model:
+            if isinstance(m, Conv):
+                out.append(m.conv.out_channels)
+            elif isinstance(m, LDConv):
+                out.append(m.conv[0].out_channels)
+            elif isinstance(m, (C2f, SPPF)):
+                out.append(m.cv2.conv.out_channels)
+            elif isinstance(m, Upsample):
+                out.append(out[m.i + m.f if m.f < 0 else m.f])
+            elif isinstance(m, (Concat, Zoom_cat)):
+                out.append(sum(out[m.i + j if j < 0 else j] for j in m.f))
+            elif isinstance(m, Add):
+                out.append(out[m.i + m.f[-1] if m.f[-1] < 0 else m.f[-1]])
+            elif isinstance(m, ScalSeq):
+                out.append(m.conv3d.out_channels)
+            else:
+                out.append(getattr(m, "no", 0))
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.stride = fn(m.stride)
+            self.stride = m.stride
+        return out
+
+    def init_criterion(self):
+        from ..utils.loss import v8DetectionLoss
+        return v8DetectionLoss(self)
+
+
+def attempt_load_weights(weights, device=None, inplace=True, fuse=False):
+    """Load a checkpoint written by the trainer (reference tasks.py:706-746): whole-module pickles or state dicts."""
+    ckpt = torch.load(weights, map_location="cpu", weights_only=False)
+    model = (ckpt.get("ema") or ckpt["model"]) if isinstance(ckpt, dict) else ckpt
+    model = model.float()
+    if device is not None:
+        model = model.to(device)
+    if fuse and hasattr(model, "fuse"):
+        model = model.fuse()
+    return model.eval()

@@ -1,0 +1,154 @@
+"""Detection criterion (drop-in for reference utils/loss.py:187-250, 294-457) issued as HIP kernels.
+
+``v8DetectionLoss(model)(preds, batch)`` keeps the reference protocol and attribute names -- ``crit.bbox_loss.use_wiseiou``,
+``crit.bbox_loss.nwd_loss``, ``crit.bbox_loss.iou_ratio`` toggle WIoU-v3 / NWD exactly as editing the two literals at
+loss.py:194,197 does in the reference, and ``crit.bbox_loss.wiou_loss.iou_mean`` is the WIoU running mean -- but the
+whole computation (target packing, DFL decode, task-aligned assignment, BCE/CIoU|WIoU/NWD/DFL and the gradients w.r.t.
+the head logits) is one C-ABI call, ``dy_detection_loss``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ..hip import DyLossArgs, check
+
+
+class _WiouState:
+    """Stands in for ``WiseIouLoss``: only its running mean is state (reference utils/metrics.py:573-589)."""
+    momentum, alpha, delta = 1e-2, 1.7, 2.7
+
+    def __init__(self, scalars):
+        self._s = scalars
+
+    @property
+    def iou_mean(self):
+        return self._s[4]
+
+    @iou_mean.setter
+    def iou_mean(self, v):
+        self._s[4] = float(v)
+
+
+class BboxLoss:
+    """Toggle holder mirroring reference ``BboxLoss.__init__`` (utils/loss.py:189-200)."""
+
+    def __init__(self, reg_max, use_dfl, scalars):
+        self.reg_max, self.use_dfl = reg_max, use_dfl
+        self.nwd_loss = False
+        self.iou_ratio = 0.5
+        self.use_wiseiou = False
+        self.wiou_loss = _WiouState(scalars)
+
+
+class v8DetectionLoss:
+    def __init__(self, model):
+        m = model.model[-1]
+        h = getattr(model, "args", None)
+        self.hyp = h
+        self.box_gain = float(getattr(h, "box", 7.5)) if h is not None else 7.5
+        self.cls_gain = float(getattr(h, "cls", 0.5)) if h is not None else 0.5
+        self.dfl_gain = float(getattr(h, "dfl", 1.5)) if h is not None else 1.5
+        self.stride, self.nc, self.no, self.reg_max = m.stride, m.nc, m.no, m.reg_max
+        self.device = next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("v8DetectionLoss: the HIP loss kernels need the model on a GPU (no CPU fallback)")
+        self.use_dfl = m.reg_max > 1
+        self.scalars = torch.zeros(16, dtype=torch.float32, device=self.device)
+        self.scalars[4] = 1.0  # WIoU iou_mean buffer initial value
+        self.bbox_loss = BboxLoss(m.reg_max - 1, self.use_dfl, self.scalars)
+        self.nmax = 0
+        self._ws = None
+        self._args = DyLossArgs()
+        self._one = torch.ones(1, dtype=torch.float32, device=self.device)
+        self._tgt = None
+        self._ncount = None
+
+    # ---- argument block ----------------------------------------------------------------------------------------
+    def bind(self, ho, nmax, gscale=None):
+        """Fill the DyLossArgs block for one HeadOut geometry; returns it (kept alive by self)."""
+        from ..hip import lib
+        L = lib()
+        a = self._args
+        a.nl, a.B, a.nc, a.ncp = len(ho.box), ho.box[0].shape[0], self.nc, ho.cls[0].shape[-1]
+        a.nmax = nmax
+        A = 0
+        for l in range(a.nl):
+            a.box[l], a.cls[l] = ho.box[l].data_ptr(), ho.cls[l].data_ptr()
+            a.dbox[l] = ho.dbox[l].data_ptr() if ho.dbox is not None else 0
+            a.dcls[l] = ho.dcls[l].data_ptr() if ho.dcls is not None else 0
+            a.H[l], a.W[l], a.stride[l] = ho.box[l].shape[1], ho.box[l].shape[2], float(ho.strides[l])
+            A += a.H[l] * a.W[l]
+        a.img_w, a.img_h = a.W[0] * a.stride[0], a.H[0] * a.stride[0]
+        a.gscale = (gscale if gscale is not None else self._one).data_ptr()
+        a.scalars = self.scalars.data_ptr()
+        need = L.dy_loss_workspace_bytes(a.B, A, nmax)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        a.workspace = self._ws.data_ptr()
+        self.A = A
+        return a
+
+    def set_targets(self, batch, cap=None):
+        """Stage the (n,6)-style targets of the dataloader batch dict on the device (static buffers of capacity ``cap``)."""
+        bi = batch["batch_idx"].reshape(-1).float()
+        n = bi.numel()
+        cap = max(cap or 0, n, 8)
+        if self._tgt is None or self._tgt[0].numel() < cap:
+            self._tgt = (torch.zeros(cap, device=self.device), torch.zeros(cap, device=self.device),
+                         torch.zeros(cap, 4, device=self.device))
+        if n:
+            self._tgt[0][:n].copy_(bi, non_blocking=True)
+            self._tgt[1][:n].copy_(batch["cls"].reshape(-1).float(), non_blocking=True)
+            self._tgt[2][:n].copy_(batch["bboxes"].reshape(-1, 4).float(), non_blocking=True)
+        a = self._args
+        a.t_batch_idx, a.t_cls, a.t_boxes = (t.data_ptr() for t in self._tgt)
+        a.n_targets = n
+        if self._ncount is None:
+            self._ncount = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._ncount_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._ncount_host[0] = n
+        self._ncount.copy_(self._ncount_host, non_blocking=True)
+        a.n_targets_dev = self._ncount.data_ptr()
+        return n
+
+    def sync_modes(self):
+        a, b = self._args, self.bbox_loss
+        a.hyp_box, a.hyp_cls, a.hyp_dfl = self.box_gain, self.cls_gain, self.dfl_gain
+        a.use_wiou, a.use_nwd, a.iou_ratio = int(b.use_wiseiou), int(b.nwd_loss), float(b.iou_ratio)
+
+    @staticmethod
+    def capacity_for(batch, B):
+        bi = batch["batch_idx"].reshape(-1)
+        if bi.numel() == 0:
+            return 8
+        counts = torch.bincount(bi.long().cpu(), minlength=B)
+        return max(8, (int(counts.max()) + 7) // 8 * 8)
+
+    def __call__(self, preds, batch):
+        """(loss.sum()*B, loss_items[box, cls, dfl]) as device tensors (reference utils/loss.py:356-361)."""
+        from ..nn.modules.head import HeadOut
+        if not isinstance(preds, HeadOut):
+            raise TypeError("v8DetectionLoss expects the HeadOut produced by Detect on the HIP path")
+        eng_stream = torch.cuda.current_stream(self.device).cuda_stream
+        B = preds.box[0].shape[0]
+        self.bind(preds, self.capacity_for(batch, B))
+        self.set_targets(batch)
+        self.sync_modes()
+        from ..hip import lib
+        check(lib().dy_detection_loss(C.byref(self._args), eng_stream), "dy_detection_loss")
+        return self.scalars[8].clone(), self.scalars[5:8].clone()
+
+    def debug_assignment(self):
+        """(target_gt_idx (B,A) with -1 for background, target score (B,A), pred boxes (B,A,4)) of the last call."""
+        from ..hip import lib
+        a = self._args
+        o = [C.c_size_t() for _ in range(3)]
+        lib().dy_loss_workspace_layout(a.B, self.A, a.nmax, *[C.byref(x) for x in o])
+        BA = a.B * self.A
+        ws = self._ws
+        pb = ws[o[0].value:o[0].value + BA * 16].view(torch.float32).view(a.B, self.A, 4)
+        gt = ws[o[1].value:o[1].value + BA * 4].view(torch.int32).view(a.B, self.A)
+        ts = ws[o[2].value:o[2].value + BA * 4].view(torch.float32).view(a.B, self.A)
+        return gt.clone(), ts.clone(), pb.clone()

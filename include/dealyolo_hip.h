@@ -1,0 +1,152 @@
+/* libdealyolo_hip.so -- C ABI of the MI355X (gfx950) DEAL-YOLO hot path.
+ *
+ * The reference (adityaX1412/Experiment-YOLO, an Ultralytics-YOLOv8 fork) has NO native code and no FFI on this
+ * path: every operator below replaces a *sequence of ATen calls* issued by the reference's Python modules.  Each
+ * entry therefore cites the reference Python interface (file:line under /root/reference/ultralytics) whose
+ * arithmetic it takes over; INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless named host_*;
+ *   - activations are NHWC fp16 ("f16"), addressed as (pointer, ld) where ld is the pixel stride in ELEMENTS, so a
+ *     channel slice of a wider buffer (Concat / chunk) is just an offset pointer with the parent's ld;
+ *     channel counts and ld are multiples of 8, pointers 16-byte aligned;
+ *   - every function enqueues work on `stream` and returns immediately: no allocation, no synchronisation, no
+ *     global state; workspaces are caller-owned;  return value: DY_OK (0) or a negative DY_ERR_* code.
+ */
+#ifndef DEALYOLO_HIP_H
+#define DEALYOLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define DY_OK 0
+#define DY_ERR_ARG (-1)
+#define DY_ERR_LAUNCH (-2)
+#define DY_ERR_ALIGN (-3)
+
+/* conv epilogue flags */
+#define DY_EPI_STATS 1   /* write per-workgroup sum / sum-of-squares partials of the (fp16-rounded) output */
+#define DY_EPI_BIAS 2    /* add bias[cout] */
+#define DY_EPI_SILU 4    /* apply SiLU */
+#define DY_EPI_F32OUT 8  /* y is fp32 (Detect's final 1x1 convs feed the loss in fp32) */
+#define DY_EPI_ACCUM 16  /* y += result (gradient fan-in) */
+
+#define DY_ACT_NONE 0
+#define DY_ACT_SILU 1
+#define DY_ACT_LEAKY 2 /* LeakyReLU(0.1), ScalSeq */
+
+int dy_abi_version(void);
+
+/* ---- Conv.forward / forward_fuse, nn/modules/conv.py:41-59; nn.Conv2d heads nn/modules/head.py:38-42;
+ *      LDConv.p_conv nn/modules/conv.py:356; input-gradient half of aten::convolution_backward. ------------------ */
+int dy_conv_geometry(int cin, int cout, int ks, int stride, int* cin_p, int* cout_p, int* cc, int* nch, int* mt,
+                     int* ngroups, int* ksteps, int* packed_elems);
+/* fp32 OIHW master weights -> fp16 MFMA-packed; scale: optional per-Cout factor (BN folding, utils/torch_utils.py:171-198);
+ * transposed=1 builds the (Cout->Cin, flipped taps) pack consumed by the stride-1 input-gradient pass. */
+int dy_pack_weights(const float* w, const float* scale, void* out, int cout, int cin, int ks, int stride,
+                    int transposed, hipStream_t stream);
+/* y[n,ho,wo,:cout] = conv(x)[...]; x: (n,h,w,cin) with cin a multiple of 8 (zero-padded channels).
+ * dil=2: x is read as a zero-dilated map of size (2h,2w) -- the input gradient of a stride-2 conv; out_h/out_w (>0)
+ * then give the extent of the forward input (2h or 2h-1), otherwise pass 0 to derive the output extent.
+ * partials: [num_partials][2][cout_p] floats, required with DY_EPI_STATS. */
+int dy_conv_forward(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy, float* partials,
+                    int n, int h, int w, int cin, int cout, int ks, int stride, int dil, int out_h, int out_w, int epi,
+                    int* num_partials, hipStream_t stream);
+int dy_conv_num_partials(int n, int h, int w, int ks, int stride, int dil);
+
+/* ---- weight-gradient half of aten::convolution_backward for the same modules. dw: fp32 OIHW (cout,cin,ks,ks). -- */
+int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int stride, int* nslabs, long* slab_elems);
+int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
+                  int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream);
+
+/* ---- nn.BatchNorm2d / BatchNorm3d (training statistics) + SiLU / LeakyReLU, nn/modules/conv.py:49-55,
+ *      nn/extra_modules/block.py:3440-3441, utils/torch_utils.py:347-349, and their autograd backward. ------------- */
+/* coef: [4][C] = scale, shift, mean, invstd.  Up to three weighted partial sets (ScalSeq: three resolutions). */
+int dy_bn_finalize(const float* p0, int n0, float w0, const float* p1, int n1, float w1, const float* p2, int n2,
+                   float w2, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   float* coef, int C, float count, float eps, float momentum, int update_running, hipStream_t stream);
+int dy_bn_eval_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                    float* coef, int C, float eps, hipStream_t stream);
+/* y = act(x*scale+shift) (+ res) */
+int dy_bn_act_apply(const void* x, int ldx, const void* res, int ldr, void* y, int ldy, const float* coef, long npix,
+                    int C, int act, hipStream_t stream);
+int dy_bn_act_bwd_reduce(const void* dy, int lddy, const void* x, int ldx, const float* coef, float* partials,
+                         int max_partials, long npix, int C, int act, int* nparts, hipStream_t stream);
+/* bwdcoef: [2][C] = mean(g), mean(g*xhat); dgamma/dbeta fp32 (may be NULL) */
+int dy_bn_bwd_finalize(const float* partials, int nparts, float* dgamma, float* dbeta, float* bwdcoef, int C,
+                       float count, int accumulate, hipStream_t stream);
+int dy_bn_act_bwd_apply(const void* dy, int lddy, const void* x, int ldx, void* dx, int lddx, const float* coef,
+                        const float* bwdcoef, long npix, int C, int act, int frozen_stats, hipStream_t stream);
+
+/* ---- data movement: image import (models/yolo/detect/train.py:57-59), nn.Upsample(2,'nearest') (model YAMLs),
+ *      SPPF's MaxPool2d(5,1,2) chain nn/modules/block.py:166-171, Add nn/extra_modules/block.py:3483-3484,
+ *      Concat nn/modules/conv.py:338-348, ScalSeq tail nn/extra_modules/block.py:3437-3443. -------------------------- */
+int dy_import_image(const float* x_nchw, void* y, int n, int c, int h, int w, int cp, float mul, hipStream_t stream);
+int dy_add(const void* a, int lda, const void* b, int ldb, const void* c, int ldc, void* y, int ldy, long npix, int C,
+           hipStream_t stream);
+int dy_upsample2x(const void* x, int ldx, void* y, int ldy, int n, int h, int w, int C, int backward, int accumulate,
+                  hipStream_t stream);
+int dy_maxpool5(const void* x, int ldx, void* y, int ldy, void* argmax, int n, int h, int w, int C, hipStream_t stream);
+int dy_maxpool5_backward(const void* dy, int lddy, const void* argmax, void* dx, int lddx, int n, int h, int w, int C,
+                         int accumulate, hipStream_t stream);
+int dy_scalseq_tail(const void* r0, int ld0, const void* r1, int ld1, const void* r2, int ld2, const void* res,
+                    int ldres, void* y, int ldy, const float* coef, int n, int h, int w, int C, hipStream_t stream);
+/* mode 0: BN3d backward partial sums for `level`; mode 1: dr_level */
+int dy_scalseq_tail_backward(const void* r0, int ld0, const void* r1, int ld1, const void* r2, int ld2, const void* dy,
+                             int lddy, void* dr, int lddr, const float* coef, const float* bwdcoef, float* partials,
+                             int max_partials, int n, int h, int w, int C, int level, int mode, int* nparts,
+                             hipStream_t stream);
+int dy_copy_slice(const void* x, int ldx, void* y, int ldy, long npix, int C, hipStream_t stream);
+int dy_fill_zero(void* p, size_t bytes, hipStream_t stream);
+
+/* ---- v8DetectionLoss.__call__ utils/loss.py:356-457 + TaskAlignedAssigner utils/tal.py:39-258 + BboxLoss
+ *      utils/loss.py:202-250 + bbox_iou / wasserstein_loss / WiseIouLoss utils/metrics.py:75-126,540-565,591-645,
+ *      forward AND backward (gradients w.r.t. the head logits are written as fp16 * gscale). ------------------------ */
+typedef struct DyLossArgs {
+  int nl, B, nc, ncp, nmax;      /* levels (<=4), batch, classes, classes padded to 8, gt capacity per image */
+  const float* box[4];           /* (B,H,W,64) fp32 DFL logits per level */
+  const float* cls[4];           /* (B,H,W,ncp) fp32 class logits per level */
+  void* dbox[4];                 /* (B,H,W,64) fp16 out */
+  void* dcls[4];                 /* (B,H,W,ncp) fp16 out */
+  int H[4], W[4];
+  float stride[4];
+  const float* t_batch_idx;      /* (n,) targets as the dataloader emits them, data/dataset.py:207-224 */
+  const float* t_cls;            /* (n,) */
+  const float* t_boxes;          /* (n,4) normalised xywh */
+  int n_targets;
+  const int* n_targets_dev;      /* optional device copy of n_targets (read instead of n_targets when non-NULL, so a
+                                    captured hipGraph sees per-step counts) */
+  float img_w, img_h;
+  float hyp_box, hyp_cls, hyp_dfl; /* cfg/default.yaml box/cls/dfl gains */
+  int use_wiou, use_nwd;         /* BboxLoss.use_wiseiou / nwd_loss toggles, utils/loss.py:194,197 */
+  float iou_ratio;
+  const float* gscale;           /* device scalar: loss scale folded into every gradient */
+  float* scalars;                /* 16 persistent floats: [1] target_scores_sum [3] #fg [4] WIoU iou_mean (init 1)
+                                    [5..7] loss_items box,cls,dfl [8] loss.sum()*B [9] error flag */
+  void* workspace;               /* dy_loss_workspace_bytes(B, A, nmax) bytes */
+} DyLossArgs;
+size_t dy_loss_workspace_bytes(int B, int A, int nmax);
+/* byte offsets of pred_box (B,A,4 f32, grid units), assigned gt index (B,A i32, -1 = background) and target score
+ * (B,A f32) inside the workspace after a call -- used by the parity tests */
+int dy_loss_workspace_layout(int B, int A, int nmax, size_t* off_pred_box, size_t* off_asg_gt, size_t* off_tscore);
+int dy_detection_loss(const DyLossArgs* args, hipStream_t stream);
+
+/* ---- BaseTrainer.optimizer_step engine/trainer.py:949-957 + build_optimizer groups :1146-1174 + ModelEMA.update
+ *      utils/torch_utils.py:447-458 + GradScaler policy, over flat fp32 buffers. ------------------------------------ */
+int dy_optimizer_step(float* params, const float* grads, float* mom, float* adam_v, float* ema, long n, long g0_end,
+                      long g1_end, const unsigned char* frozen, const float* buffers, float* ema_buffers,
+                      long n_buffers, const float* hyper, float* state, float* partials, int mode, hipStream_t stream);
+int dy_axpy_f32(float* y, const float* x, float a, long n, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,163 @@
+"""-m gpu: each HIP kernel family against a plain PyTorch fp32 reference of the same op (inputs pre-rounded to fp16, the
+storage format of the path; accumulation is fp32 on both sides).  Tolerances are relative to the largest reference
+magnitude: 2e-3 covers the single fp16 rounding of the output, 5e-3 two roundings (bn/act chains)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import h16, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng():
+    from ultralytics.hip.engine import Engine
+    return Engine("cuda:0")
+
+
+def _spec(eng, w, bias, ks, s):
+    from ultralytics.hip.engine import ConvSpec
+    sp = ConvSpec("t", w.cuda().contiguous(), None if bias is None else bias.cuda(), None, ks, s, 0)
+    sp.gweight = torch.zeros_like(sp.weight)
+    sp.gbias = torch.zeros(((sp.cout + 7) // 8 * 8), device="cuda") if bias is not None else None
+    eng.prepare_conv(sp)
+    eng.pack(sp, transposed=True)
+    return sp
+
+
+def _act(eng, x):
+    from ultralytics.hip.engine import Storage
+    N, Cc, H, W = x.shape
+    cp = (Cc + 7) // 8 * 8
+    st = Storage(eng, N, H, W, cp)
+    st.buf.zero_()
+    st.buf[..., :Cc].copy_(x.cuda().permute(0, 2, 3, 1))
+    return st.act()
+
+
+CONV_CASES = [  # cin, cout, ks, s, H, W
+    (16, 32, 3, 1, 12, 20), (64, 64, 3, 1, 40, 40), (32, 64, 3, 2, 26, 34), (64, 128, 3, 2, 16, 16), (128, 64, 3, 1, 9, 11),
+    (3, 16, 3, 2, 32, 48), (16, 32, 3, 2, 13, 21), (48, 32, 1, 1, 7, 9), (256, 128, 1, 1, 10, 10), (96, 64, 1, 1, 13, 5), (32, 6, 1, 1, 8, 8),
+    (16, 16, 3, 1, 33, 35), (64, 80, 1, 1, 6, 6), (192, 128, 1, 1, 5, 7),
+]
+
+
+@pytest.mark.parametrize("cin,cout,ks,s,H,W", CONV_CASES)
+def test_conv_forward_dgrad_wgrad(cin, cout, ks, s, H, W):
+    torch.manual_seed(cin * 1000 + cout + ks + s)
+    eng = _eng()
+    N = 2
+    x = h16(torch.randn(N, cin, H, W))
+    w = h16(torch.randn(cout, cin, ks, ks) / (cin * ks * ks) ** 0.5)
+    b = torch.randn(cout)
+    sp = _spec(eng, w, b, ks, s)
+    xa = _act(eng, x)
+    Ho, Wo = eng.out_hw(sp, xa)
+    ref = F.conv2d(x, w, b, s, ks // 2)
+    # fp32 output path with bias (Detect heads)
+    y32 = torch.zeros(N, Ho, Wo, cout, device="cuda")
+    eng.conv_bias(sp, xa, y32.data_ptr(), cout, True)
+    torch.cuda.synchronize()
+    assert relerr(y32.permute(0, 3, 1, 2), ref) < 2e-5 * (cin * ks * ks) ** 0.5 + 1e-5
+    # fp16 output, no bias, with batch statistics partials
+    cp = (cout + 15) // 16 * 16
+    if cout % 8 == 0:
+        y16 = torch.zeros(N, Ho, Wo, cout, dtype=torch.float16, device="cuda")
+        nparts = eng.L.dy_conv_num_partials(N, H, W, ks, s, 1)
+        part = torch.zeros(nparts, 2, cp, device="cuda")
+        eng.call("dy_conv_forward", xa.ptr, xa.ld, sp.wpack.data_ptr(), 0, y16.data_ptr(), cout, part.data_ptr(), N, H, W, xa.C, cout,
+                 ks, s, 1, 0, 0, 1, None)
+        torch.cuda.synchronize()
+        ref0 = F.conv2d(x, w, None, s, ks // 2)
+        assert relerr(y16.float().permute(0, 3, 1, 2), ref0) < 2e-3
+        yq = y16.float()
+        assert relerr(part[:, 0, :cout].sum(0), yq.sum((0, 1, 2))) < 1e-4 + 1e-5
+        assert relerr(part[:, 1, :cout].sum(0), (yq * yq).sum((0, 1, 2))) < 1e-4
+    # gradients: dY random (fp16), dX via transposed pack (+ zero-dilation for stride 2), dW via the tr-read kernel
+    coutp = (cout + 7) // 8 * 8
+    dy = h16(torch.randn(N, cout, Ho, Wo))
+    dya = _act(eng, dy)
+    xa.needs_grad = cin != 3
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, s, ks // 2).backward(dy)
+    eng._conv_bwd(sp, xa, dya.ptr, dya.ld, Ho, Wo)
+    torch.cuda.synchronize()
+    assert relerr(sp.gweight, wr.grad) < 3e-4, "wgrad"
+    if xa.needs_grad:
+        gx = xa.st.gbuf[..., :cin].permute(0, 3, 1, 2).float()
+        assert relerr(gx, xr.grad) < 2e-3, "dgrad"
+        # accumulate path: a second writer adds on top
+        eng._conv_bwd(sp, xa, dya.ptr, dya.ld, Ho, Wo, accumulate_w=1)
+        torch.cuda.synchronize()
+        assert relerr(xa.st.gbuf[..., :cin].permute(0, 3, 1, 2).float(), 2 * xr.grad) < 3e-3
+        assert relerr(sp.gweight, 2 * wr.grad) < 3e-4
+    _ = coutp
+
+
+@pytest.mark.parametrize("C_,act", [(16, 1), (64, 1), (32, 2), (128, 0)])
+def test_bn_act_forward_backward(C_, act):
+    torch.manual_seed(C_ + act)
+    eng = _eng()
+    N, H, W = 3, 9, 14
+    x = h16(torch.randn(N, C_, H, W) * 1.5 + 0.3)
+    gamma, beta = torch.rand(C_) + 0.5, torch.randn(C_) * 0.2
+    rm, rv = torch.zeros(C_), torch.ones(C_)
+    dy = h16(torch.randn(N, C_, H, W))
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.03, 1e-3)
+    yr = F.silu(z) if act == 1 else (F.leaky_relu(z, 0.1) if act == 2 else z)
+    yr.backward(dy)
+    xa, dya = _act(eng, x), _act(eng, dy)
+    npix = N * H * W
+    # statistics from per-"workgroup" partials: emulate with one partial row
+    xq = xa.st.buf.float().view(-1, C_)
+    part = torch.stack([xq.sum(0), (xq * xq).sum(0)]).view(1, 2, C_).contiguous()
+    g_, b_, rm_, rv_ = gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda()
+    coef, bwd = torch.zeros(4 * C_, device="cuda"), torch.zeros(2 * C_, device="cuda")
+    eng.call("dy_bn_finalize", part.data_ptr(), 1, 1.0, 0, 0, 0.0, 0, 0, 0.0, g_.data_ptr(), b_.data_ptr(), rm_.data_ptr(),
+             rv_.data_ptr(), coef.data_ptr(), C_, float(npix), 1e-3, 0.03, 1)
+    y = torch.zeros(N, H, W, C_, dtype=torch.float16, device="cuda")
+    eng.call("dy_bn_act_apply", xa.ptr, xa.ld, 0, 0, y.data_ptr(), C_, coef.data_ptr(), npix, C_, act)
+    torch.cuda.synchronize()
+    assert relerr(y.float().permute(0, 3, 1, 2), yr) < 2e-3
+    assert relerr(rm_, rm_ref) < 1e-5 and relerr(rv_, rv_ref) < 1e-5
+    parts = torch.zeros(2048 * 2 * C_, device="cuda")
+    n = C.c_int(0)
+    eng.call("dy_bn_act_bwd_reduce", dya.ptr, dya.ld, xa.ptr, xa.ld, coef.data_ptr(), parts.data_ptr(), 2048, npix, C_, act,
+             C.byref(n))
+    dg, db = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+    eng.call("dy_bn_bwd_finalize", parts.data_ptr(), n.value, dg.data_ptr(), db.data_ptr(), bwd.data_ptr(), C_, float(npix), 0)
+    dx = torch.zeros(N, H, W, C_, dtype=torch.float16, device="cuda")
+    eng.call("dy_bn_act_bwd_apply", dya.ptr, dya.ld, xa.ptr, xa.ld, dx.data_ptr(), C_, coef.data_ptr(), bwd.data_ptr(), npix, C_, act, 0)
+    torch.cuda.synchronize()
+    assert relerr(dg, gr.grad) < 1e-3 and relerr(db, br.grad) < 1e-3
+    assert relerr(dx.float().permute(0, 3, 1, 2), xr.grad) < 3e-3
+
+
+def test_pool_upsample_add():
+    torch.manual_seed(5)
+    eng = _eng()
+    x = h16(torch.randn(2, 16, 11, 13))
+    xa = _act(eng, x)
+    eng.tape = []
+    out = eng.new_act(2, 11, 13, 16)
+    eng.maxpool5(xa, out)
+    up = eng.upsample2x(out)
+    s = eng.add([up, up])
+    gy = h16(torch.randn(2, 16, 22, 26))
+    s._gbuf()[...] = gy.cuda().permute(0, 2, 3, 1)
+    s.st.gwritten.append((0, 16))
+    for f in reversed(eng.tape):
+        f()
+    torch.cuda.synchronize()
+    xr = x.clone().requires_grad_(True)
+    p = F.max_pool2d(xr, 5, 1, 2)
+    u = F.interpolate(p, scale_factor=2.0, mode="nearest")
+    (u + u).backward(gy)
+    assert relerr(s.st.buf.float().permute(0, 3, 1, 2), u + u) < 1e-3
+    assert relerr(xa.st.gbuf.float().permute(0, 3, 1, 2), xr.grad) < 4e-3

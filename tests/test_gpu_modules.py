@@ -1,0 +1,95 @@
+"""-m gpu: hot-path modules (forward + hand-written backward through the engine tape) against the reference-generated
+golden fixtures (tests/golden/modules.npz) and the CPU oracle.  The HIP path stores activations in fp16, the goldens
+are fp32: tolerances are relative to the largest reference magnitude and grow with the number of stacked roundings."""
+import pytest
+import torch
+
+from gpu_util import act_grad_tensor, l2err, load_filled, relerr, run_fwd_bwd
+from golden.cases import module_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(name, layer):
+    from ultralytics.nn.extra_modules.block import Add, ScalSeq
+    from ultralytics.nn.modules import SPPF, C2f, Conv
+    a = layer.args
+    if layer.kind == "Conv":
+        return Conv(layer.cin, layer.cout, a["k"], a["s"])
+    if layer.kind == "C2f":
+        return C2f(layer.cin, layer.cout, a["n"], a["shortcut"])
+    if layer.kind == "SPPF":
+        return SPPF(layer.cin, layer.cout, a["k"])
+    if layer.kind == "ScalSeq":
+        return ScalSeq(layer.cin, layer.cout)
+    if layer.kind == "Add":
+        return Add()
+    raise KeyError(name)
+
+
+CASES = {k: v for k, v in module_cases().items() if v[0].kind in ("Conv", "C2f", "SPPF", "ScalSeq", "Add")}
+TOL = {"Conv": (3e-3, 6e-3, 4e-3), "C2f": (1.5e-2, 3e-2, 3e-2), "SPPF": (8e-3, 2e-2, 2e-2), "ScalSeq": (1e-2, 3e-2, 8e-2),
+       "Add": (2e-3, 2e-3, 1)}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_module_vs_golden(golden, name):
+    G = golden("modules")
+    layer, ci = CASES[name]
+    m = _make(name, layer)
+    if layer.kind != "Add":
+        load_filled(m, layer, 100 + ci)
+    xs = [G.t(k) for k in sorted(G.keys(f"{name}/x"))]
+    y, gxs, rt = run_fwd_bwd(m, xs, G.t(f"{name}/gy"))
+    ty, tx, tp = TOL[layer.kind]
+    # max-type modules (SPPF pooling, ScalSeq's max over scales): an fp16 rounding can flip an arg-max at isolated
+    # positions and re-route that position's gradient, so gradients are compared in the L2 sense there
+    err = l2err if layer.kind in ("SPPF", "ScalSeq") else relerr
+    assert relerr(y, G.t(f"{name}/y")) < ty, "forward"
+    for j, gx in enumerate(gxs):
+        if gx is not None:
+            assert err(gx, G.t(f"{name}/gx{j}")) < tx, f"grad input {j}"
+    params = dict(m.named_parameters())
+    for k in G.keys(f"{name}/gp/"):
+        if k.endswith("conv3d.bias"):
+            continue  # mathematically zero (BatchNorm3d removes a per-channel shift): both sides are rounding noise
+        p = params[k.split("/gp/")[1]]
+        ref = G.t(k)
+        assert err(p.grad.reshape(ref.shape), ref) < tp, f"grad {k}"
+    bufs = dict(m.named_buffers())
+    for k in G.keys(f"{name}/buf/"):
+        assert relerr(bufs[k.split("/buf/")[1]], G.t(k)) < 2e-3, k
+
+
+def test_detect_head_vs_golden(golden):
+    from oracle import graph as og
+    from ultralytics.nn.modules import Detect
+    from ultralytics.nn.tasks import initialize_weights
+    G = golden("modules")
+    layer = og.Layer(0, [0, 1, 2], "Detect", [16, 32, 64], 70, dict(nc=6))
+    det = Detect(6, (16, 32, 64))
+    load_filled(det, layer, 150)
+    det.stride = torch.tensor([4.0, 8.0, 16.0])
+    initialize_weights(det)
+    det.cuda().train()
+    rt = det._runtime(torch.device("cuda", 0))
+    eng = rt.eng
+    eng.training, eng.tape = True, []
+    rt.pack_all(True)
+    acts = [rt.to_act(G.t(f"detect/x{j}").cuda()) for j in range(3)]
+    ho = det.forward_act(acts)
+    for j, f in enumerate(ho.as_reference_list()):
+        assert relerr(f.float(), G.t(f"detect/y{j}")) < 8e-3, f"level {j}"
+    for j in range(3):
+        gy = G.t(f"detect/gy{j}").cuda().permute(0, 2, 3, 1)
+        ho.dbox[j].copy_(gy[..., :64])
+        ho.dcls[j][..., :6].copy_(gy[..., 64:])
+    for f in reversed(eng.tape):
+        f()
+    torch.cuda.synchronize()
+    for j in range(3):
+        assert relerr(act_grad_tensor(acts[j]), G.t(f"detect/gx{j}")) < 2e-2, f"grad input {j}"
+    params = dict(det.named_parameters())
+    for k in G.keys("detect/gp/"):
+        ref = G.t(k)
+        assert relerr(params[k.split("/gp/")[1]].grad.reshape(ref.shape), ref) < 2e-2, k
