@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the DEAL-YOLO training hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full training iteration of DEAL-YOLO-N (yolov8n-ASF-P2P2) at 640x640, per-GPU batch 64 (BASELINE.json
+configs[1]): image import, forward, detection loss (TAL + CIoU + DFL + BCE), hand-written backward, gradient all-reduce
+(RCCL, N>1), SGD-nesterov + EMA -- all through libdealyolo_hip.so.  Inputs are synthetic and already resident in HBM.
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     dominant kernel (the 64->64 3x3 @160x160 MFMA conv of the Detect head), algorithmic bytes / launch time
+               measured live with HIP events on the launch stream, against 8 TB/s HBM;
+  cpu_baseline the CPU oracle (a port of the reference's PyTorch CPU path) timed on the host cores, bs=2, bounded.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "experiment-yolo_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CFG = os.path.join(ROOT, "experiment-yolo_amd", "ultralytics", "cfg", "models", "yolov8n-ASF-P2P2.yaml")
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_batch(seed, B, imgsz, nc, n_per=8):
+    """SURVEY.md 8(d) recipe: U[0,1) image, 8 boxes/img, wh in [0.01,0.09), xy in [0.1,0.9), sorted batch_idx."""
+    rng = np.random.default_rng(seed)
+    n = B * n_per
+    return dict(img=torch.from_numpy(rng.random((B, 3, imgsz, imgsz), dtype=np.float32)),
+                batch_idx=torch.arange(B).repeat_interleave(n_per).float(),
+                cls=torch.from_numpy(rng.integers(0, nc, (n, 1)).astype(np.float32)),
+                bboxes=torch.from_numpy(np.concatenate([rng.random((n, 2)) * 0.8 + 0.1, rng.random((n, 2)) * 0.08 + 0.01], 1).astype(np.float32)))
+
+
+def cpu_baseline(imgsz, steps=6, warm=2, bs=2):
+    """CPU oracle (port of the reference PyTorch CPU trainer step: forward + loss + autograd backward + SGD + EMA)."""
+    from oracle import graph as og, trainer as otr
+    g = og.build_graph(og.load_yaml(CFG))
+    sd = og.default_init_state(g, 0)
+    ts = otr.TrainState(g, sd, otr.Hyp(), batch_size=bs, nb=8)
+    torch.set_num_threads(os.cpu_count() or 1)
+    t = []
+    for i in range(warm + steps):
+        batch = synth_batch(100 + i, bs, imgsz, g.nc)
+        t0 = time.perf_counter()
+        otr.train_step(ts, batch)
+        t.append(time.perf_counter() - t0)
+    dt = float(np.median(t[warm:]))
+    return {"value": bs / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} steps of bs={bs} {imgsz}x{imgsz} after {warm} warm-up (median), fp32, oracle/trainer.py"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--graph", type=int, default=1, help="capture the step into hipGraphs")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--probe", type=int, default=1, help="time the dominant kernel with HIP events")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from ultralytics.hip.train import StepPlan
+    from ultralytics.nn.tasks import DetectionModel
+
+    torch.manual_seed(0)
+    model = DetectionModel(CFG, verbose=False).to(dev).train()
+    for k, v in model.named_parameters():
+        v.requires_grad = ".dfl" not in k
+    plan = StepPlan(model, a.batch, a.imgsz, nmax=8, optimizer="SGD", world_size=world, use_graph=bool(a.graph))
+    batch = {k: v.to(dev) for k, v in synth_batch(1 + rank, a.batch, a.imgsz, 6).items()}
+    lr, mom, wd = [0.01, 0.01, 0.01], 0.937, [0.0, 0.0005 * a.batch * world / 64 if a.batch * world < 64 else 0.0005, 0.0]
+
+    def one_step():
+        plan.set_hyper(lr, mom, wd)
+        plan.forward_backward(batch)
+        if world > 1:
+            plan.all_reduce()
+        plan.optimizer_step()
+
+    for _ in range(a.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms = dt / a.steps * 1e3
+    value = a.batch * world * a.steps / dt
+
+    roof = None
+    if rank == 0 and a.probe:
+        roof = plan.probe_dominant_kernel(batch, reps=max(5, min(a.steps, 20)))
+        if roof:
+            roof = {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS,
+                    "traffic": None, "kernel": roof["kernel"], "avg_us": roof["us"], "bytes_per_launch": roof["bytes"]}
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu:
+        cpu = cpu_baseline(a.imgsz)
+    if rank == 0:
+        s = plan.crit.scalars.cpu()
+        out = {"metric": "images/sec (train) DEAL-YOLO-N 640x640 bs=64/GPU", "value": value, "unit": "images/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "config": {"workload": f"DEAL-YOLO-N (yolov8n-ASF-P2P2.yaml) train step {a.imgsz}x{a.imgsz}, per-GPU batch {a.batch}, "
+                                      f"fwd+TAL/CIoU/DFL/BCE loss+bwd+SGD+EMA, BASELINE.json configs[1]",
+                          "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
+                          "loss_items_last": [float(x) for x in s[5:8]], "loss_scale": float(plan.state[0]),
+                          "skipped_steps": float(plan.state[6]),
+                          "device_ms_by_call": plan.breakdown() if roof else None},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,19 +118,24 @@ struct ApplyArgs {
 };
 
 __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a) {
-  const int cpp = a.C >> 3;
-  const long total = a.npix * cpp;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const long pix = idx / cpp;
-    const int part = (int)(idx - pix * cpp), c0 = part * 8;
+  // a thread owns one 8-channel granule for the whole launch: scale/shift live in registers
+  const int cpp = a.C >> 3, rows = 256 / cpp;
+  const int part = threadIdx.x % cpp, row = threadIdx.x / cpp, c0 = part * 8;
+  if (row >= rows) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = a.coef[c0 + j];
+    sh[j] = a.coef[a.C + c0 + j];
+  }
+  for (long pix = (long)blockIdx.x * rows + row; pix < a.npix; pix += (long)gridDim.x * rows) {
     const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
     half8 rv;
     if (a.res) rv = *reinterpret_cast<const half8*>(a.res + pix * a.ldr + c0);
     half8 out;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float z = (float)xv[j] * a.coef[c0 + j] + a.coef[a.C + c0 + j];
-      z = act_fwd(z, a.act);
+      float z = act_fwd((float)xv[j] * sc[j] + sh[j], a.act);
       if (a.res) z += (float)rv[j];
       out[j] = (f16)z;
     }
@@ -138,14 +143,20 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a) {
   }
 }
 
+static inline int ew_blocks(long npix, int C) {
+  const int rows = 256 / (C >> 3);
+  long blocks = (npix + (long)rows * 4 - 1) / ((long)rows * 4);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
 extern "C" int dy_bn_act_apply(const void* x, int ldx, const void* res, int ldr, void* y, int ldy, const float* coef,
                                long npix, int C, int act, hipStream_t stream) {
   if ((C & 7) || (ldx & 7) || (ldy & 7) || (res && (ldr & 7))) return DY_ERR_ALIGN;
+  if ((C >> 3) > 256) return DY_ERR_ARG;
   ApplyArgs a{(const f16*)x, (const f16*)res, (f16*)y, coef, ldx, ldr, ldy, C, act, npix};
-  long blocks = (npix * (C >> 3) + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(bn_act_apply_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(bn_act_apply_kernel, dim3(ew_blocks(npix, C)), dim3(256), 0, stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
@@ -269,25 +280,29 @@ struct BwdApplyArgs {
 };
 
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BwdApplyArgs a) {
-  const int cpp = a.C >> 3;
-  const long total = a.npix * cpp;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const long pix = idx / cpp;
-    const int part = (int)(idx - pix * cpp), c0 = part * 8;
+  const int cpp = a.C >> 3, rows = 256 / cpp;
+  const int part = threadIdx.x % cpp, row = threadIdx.x / cpp, c0 = part * 8;
+  if (row >= rows) return;
+  float sc[8], sh[8], mean[8], inv[8], mg[8], mgx[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = a.coef[c0 + j];
+    sh[j] = a.coef[a.C + c0 + j];
+    mean[j] = a.coef[2 * a.C + c0 + j];
+    inv[j] = a.coef[3 * a.C + c0 + j];
+    mg[j] = a.frozen_stats ? 0.f : a.bwdcoef[c0 + j];
+    mgx[j] = a.frozen_stats ? 0.f : a.bwdcoef[a.C + c0 + j];
+  }
+  for (long pix = (long)blockIdx.x * rows + row; pix < a.npix; pix += (long)gridDim.x * rows) {
     const half8 dv = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0);
     const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
     half8 out;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = c0 + j;
-      const float sc = a.coef[c], xf = (float)xv[j];
-      const float g = (float)dv[j] * act_grad(xf * sc + a.coef[a.C + c], a.act);
-      float r = g;
-      if (!a.frozen_stats) {
-        const float xh = (xf - a.coef[2 * a.C + c]) * a.coef[3 * a.C + c];
-        r = g - a.bwdcoef[c] - xh * a.bwdcoef[a.C + c];
-      }
-      out[j] = (f16)(sc * r);
+      const float xf = (float)xv[j];
+      const float g = (float)dv[j] * act_grad(xf * sc[j] + sh[j], a.act);
+      const float xh = (xf - mean[j]) * inv[j];
+      out[j] = (f16)(sc[j] * (g - mg[j] - xh * mgx[j]));
     }
     *reinterpret_cast<half8*>(a.dx + pix * a.lddx + c0) = out;
   }
@@ -297,11 +312,9 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int lddy, const void* x, int 
                                    const float* coef, const float* bwdcoef, long npix, int C, int act, int frozen_stats,
                                    hipStream_t stream) {
   if ((C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7)) return DY_ERR_ALIGN;
+  if ((C >> 3) > 256) return DY_ERR_ARG;
   BwdApplyArgs a{(const f16*)dy, (const f16*)x, (f16*)dx, coef, bwdcoef, lddy, ldx, lddx, C, act, frozen_stats, npix};
-  long blocks = (npix * (C >> 3) + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_blocks(npix, C)), dim3(256), 0, stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

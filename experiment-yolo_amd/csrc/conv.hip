@@ -7,6 +7,7 @@
 // up holding 4*MT *contiguous* output channels of one pixel and stores them with one or two 16-byte writes.
 #include "common.h"
 #include "dealyolo_hip.h"
+#include <stdlib.h>
 
 struct ConvArgs {
   const f16* x;
@@ -153,17 +154,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     if (a.epi & DY_EPI_F32OUT) {
       float* yp = reinterpret_cast<float*>(a.y) + yoff + co0;
       if (valid) {
+        if (co0 + NC <= a.cout && !(a.ldy & 3)) {
 #pragma unroll
-        for (int j = 0; j < NC; ++j)
-          if (co0 + j < a.cout) yp[j] = (a.epi & DY_EPI_ACCUM) ? yp[j] + v[j] : v[j];
+          for (int j = 0; j < NC; j += 4) {
+            float4 o = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+            if (a.epi & DY_EPI_ACCUM) {
+              const float4 old = *reinterpret_cast<const float4*>(yp + j);
+              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *reinterpret_cast<float4*>(yp + j) = o;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NC; ++j)
+            if (co0 + j < a.cout) yp[j] = (a.epi & DY_EPI_ACCUM) ? yp[j] + v[j] : v[j];
+        }
       }
     } else {
       f16* yp = reinterpret_cast<f16*>(a.y) + yoff + co0;
-      f16 hv[NC];
+      __attribute__((aligned(16))) f16 hv[NC];
       if (valid && (a.epi & DY_EPI_ACCUM)) {
+        if (co0 + NC <= a.cout) {
+          __attribute__((aligned(16))) f16 old[NC];
+          if (NC == 4) {
+            *reinterpret_cast<uint2*>(old) = *reinterpret_cast<const uint2*>(yp);
+          } else {
 #pragma unroll
-        for (int j = 0; j < NC; ++j)
-          if (co0 + j < a.cout) v[j] += (float)yp[j];
+            for (int j = 0; j < NC; j += 8) *reinterpret_cast<uint4*>(old + j) = *reinterpret_cast<const uint4*>(yp + j);
+          }
+#pragma unroll
+          for (int j = 0; j < NC; ++j) v[j] += (float)old[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < NC; ++j)
+            if (co0 + j < a.cout) v[j] += (float)yp[j];
+        }
       }
 #pragma unroll
       for (int j = 0; j < NC; ++j) hv[j] = (f16)v[j];
@@ -212,6 +237,288 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * (16 * MT) + ch];
+      const int ctot = gridDim.y * 16 * MT;
+      a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + ch] = s;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// v3: persistent 8-wave workgroups (two waves per SIMD cover each other's stalls) with the cout group's packed weights
+// RESIDENT in LDS and the next activation tile prefetched into registers while the current one is multiplied.
+// Both LDS images are XOR-swizzled instead of padded (conflict-free ds_read_b128, and a 16x32-pixel halo tile plus
+// 72 KiB of weights fits the 160 KiB LDS).  All per-granule address arithmetic of the prefetch is hoisted out of the
+// tile loop.  v1 above re-fetches every A fragment from L2 inside the k-loop (an L2 round trip per k-step: rocprof
+// showed ~5 % MFMA utilisation on 64->64 3x3); it remains the path for weight sets that do not fit LDS.
+// activation tile image: pixel stride CC*2+16 bytes.  The 16-byte pad de-phases the banks (at most 2-way conflicts)
+// and -- unlike an XOR swizzle -- keeps every tap/k-step displacement a compile-time immediate of ds_read_b128, so the
+// k-loop spends no VALU or registers on addresses (an XOR-swizzled variant made hipcc hoist 72 per-lane addresses
+// out of the tile loop and spill).
+template <int CC>
+static __device__ __forceinline__ int swz(int pixel, int part) {
+  return pixel * (CC * 2 + 16) + (part << 4);
+}
+
+template <int CC, int MT, int KS, int STRIDE, int TROWS>
+__global__ __launch_bounds__(512) void conv_mfma_wlds_kernel(ConvArgs a, int ntiles) {
+  constexpr bool FLAT = (KS == 1);
+  constexpr int NW = 8;                                 // waves per workgroup
+  constexpr int NT = 2 * TROWS;                         // 16-pixel N-tiles per wave
+  constexpr int TH = NW * TROWS, TW = 32;
+  constexpr int HW_ = FLAT ? NW * NT * 16 : (TW - 1) * STRIDE + KS;
+  constexpr int HH_ = FLAT ? 1 : (TH - 1) * STRIDE + KS;
+  constexpr int KSTEPS = (KS * KS * CC + 31) / 32;
+  constexpr int CPP = CC / 8;
+  constexpr int PAD = KS / 2;
+  constexpr int NCHUNK16 = HH_ * HW_ * CPP;
+  constexpr int NPF = (NCHUNK16 + 511) / 512;
+  constexpr int NC = 4 * MT;
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int wrows = a.nch * KSTEPS * 16 * MT;
+  char* const sw = dsm;
+  char* const st = dsm + wrows * 64;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.w + (size_t)blockIdx.y * wrows * 32);
+    for (int c = tid; c < wrows * 4; c += 512) {
+      const int row = c >> 2, qq = c & 3;
+      *reinterpret_cast<uint4*>(sw + row * 64 + ((qq ^ ((row >> 2) & 3)) << 4)) = src[c];
+    }
+  }
+  constexpr int PS = CC * 2 + 16;
+  // LDS byte offset of this lane's pixel in each N-tile
+  int boff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (FLAT) {
+      boff[t] = (wave * (NT * 16) + t * 16 + p) * PS;
+    } else {
+      const int ty = wave * TROWS + (t >> 1), tx = (t & 1) * 16 + p;
+      boff[t] = ((ty * STRIDE) * HW_ + tx * STRIDE) * PS;
+    }
+  }
+  const int aoff = p * 64 + ((q ^ ((p >> 2) & 3)) << 4);
+
+  float bias[NC];
+  const int co0 = blockIdx.y * (16 * MT) + q * NC;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) bias[j] = ((a.epi & DY_EPI_BIAS) && co0 + j < a.cout) ? a.bias[co0 + j] : 0.f;
+  float s1[NC], s2[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) s1[j] = s2[j] = 0.f;
+
+  // ---- tile-invariant prefetch metadata of this thread's granules
+  int goff[NPF];   // element offset from the tile origin pointer
+  int gyx[NPF];    // packed (ry << 16) | (rx & 0xffff), relative real coordinates; -1 row marks "never valid"
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    const int id = tid + i * 512;
+    const int pixel = id / CPP, part = id - pixel * CPP;
+    if (FLAT) {
+      goff[i] = pixel * a.ldx + part * 8;
+      gyx[i] = id < NCHUNK16 ? pixel : -1;
+    } else {
+      const int hy = pixel / HW_, hx = pixel - hy * HW_;
+      int ry = hy, rx = hx;
+      bool ok = id < NCHUNK16;
+      if (a.dil == 2) {
+        ok = ok && !(((hy - PAD) | (hx - PAD)) & 1);
+        ry = (hy - PAD) >> 1;
+        rx = (hx - PAD) >> 1;
+      }
+      goff[i] = (ry * a.Wr + rx) * a.ldx + part * 8;
+      gyx[i] = ok ? ((ry << 16) | (rx & 0xffff)) : (int)0x80000000;
+    }
+  }
+
+  uint4 pf[NPF];
+  auto prefetch = [&](int tile, int h) {
+    if (FLAT) {
+      const int pix0 = tile * HW_;
+      const f16* base = a.x + (size_t)pix0 * a.ldx + h * CC;
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) {
+        const bool ok = gyx[i] >= 0 && pix0 + gyx[i] < a.npix;
+        pf[i] = ok ? *reinterpret_cast<const uint4*>(base + goff[i]) : make_uint4(0, 0, 0, 0);
+      }
+    } else {
+      const int bx = tile % a.tiles_x;
+      const int t2 = tile / a.tiles_x;
+      const int n = t2 / a.tiles_y;
+      const int oy0 = (t2 % a.tiles_y) * TH, ox0 = bx * TW;
+      const int ty0 = a.dil == 2 ? (oy0 >> 1) : oy0 * STRIDE - PAD;
+      const int tx0 = a.dil == 2 ? (ox0 >> 1) : ox0 * STRIDE - PAD;
+      const f16* base = a.x + ((long)(n * a.Hr + ty0) * a.Wr + tx0) * a.ldx + h * CC;
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) {
+        const int ry = gyx[i] >> 16, rx = (short)(gyx[i] & 0xffff);
+        const bool ok = gyx[i] != (int)0x80000000 && (unsigned)(ty0 + ry) < (unsigned)a.Hr && (unsigned)(tx0 + rx) < (unsigned)a.Wr;
+        pf[i] = ok ? *reinterpret_cast<const uint4*>(base + goff[i]) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) prefetch(tile, 0);
+  f32x4 acc[MT][NT];
+  while (tile < ntiles) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < a.nch; ++h) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NPF; ++i)
+        if (tid + i * 512 < NCHUNK16) {
+          const int id = tid + i * 512;
+          *reinterpret_cast<uint4*>(st + swz<CC>(id / CPP, id % CPP)) = pf[i];
+        }
+      __syncthreads();
+      if (h + 1 < a.nch) prefetch(tile, h + 1);
+      else if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x, 0);
+      const char* wh = sw + (size_t)(h * KSTEPS) * (16 * MT) * 64;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int kk = ks * 32 + q * 8;
+        int tap = kk / CC;
+        const int c = kk - tap * CC;
+        if (tap > KS * KS - 1) tap = KS * KS - 1;
+        const int toff = ((tap / KS) * HW_ + (tap % KS)) * PS + c * 2;
+        half8 af[MT], bf[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const half8*>(wh + (ks * (16 * MT) + m * 16) * 64 + aoff);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const half8*>(st + boff[t] + toff);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf[t], acc[m][t], 0, 0, 0);
+      }
+    }
+    // ---- epilogue of this tile
+    int n = 0, oy0 = 0, ox0 = 0, pix0 = 0;
+    if (FLAT) {
+      pix0 = tile * HW_;
+    } else {
+      const int bx = tile % a.tiles_x;
+      const int t2 = tile / a.tiles_x;
+      n = t2 / a.tiles_y;
+      oy0 = (t2 % a.tiles_y) * TH;
+      ox0 = bx * TW;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      bool valid;
+      size_t yoff;
+      if (FLAT) {
+        const int gp = pix0 + wave * (NT * 16) + t * 16 + p;
+        valid = gp < a.npix;
+        yoff = (size_t)gp * a.ldy;
+      } else {
+        const int oy = oy0 + wave * TROWS + (t >> 1), ox = ox0 + (t & 1) * 16 + p;
+        valid = oy < a.Ho && ox < a.Wo;
+        yoff = ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.ldy;
+      }
+      float v[NC];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[m][t][r] + bias[m * 4 + r];
+      if (a.epi & DY_EPI_SILU) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) v[j] = silu_f(v[j]);
+      }
+      if (a.epi & DY_EPI_F32OUT) {
+        float* yp = reinterpret_cast<float*>(a.y) + yoff + co0;
+        if (valid) {
+          if (co0 + NC <= a.cout && !(a.ldy & 3)) {
+#pragma unroll
+            for (int j = 0; j < NC; j += 4) {
+              float4 o = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+              if (a.epi & DY_EPI_ACCUM) {
+                const float4 old = *reinterpret_cast<const float4*>(yp + j);
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+              }
+              *reinterpret_cast<float4*>(yp + j) = o;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+              if (co0 + j < a.cout) yp[j] = (a.epi & DY_EPI_ACCUM) ? yp[j] + v[j] : v[j];
+          }
+        }
+      } else {
+        f16* yp = reinterpret_cast<f16*>(a.y) + yoff + co0;
+        __attribute__((aligned(16))) f16 hv[NC];
+        if (valid && (a.epi & DY_EPI_ACCUM)) {
+          if (co0 + NC <= a.cout) {
+            __attribute__((aligned(16))) f16 old[NC];
+            if (NC == 4) {
+              *reinterpret_cast<uint2*>(old) = *reinterpret_cast<const uint2*>(yp);
+            } else {
+#pragma unroll
+              for (int j = 0; j < NC; j += 8) *reinterpret_cast<uint4*>(old + j) = *reinterpret_cast<const uint4*>(yp + j);
+            }
+#pragma unroll
+            for (int j = 0; j < NC; ++j) v[j] += (float)old[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+              if (co0 + j < a.cout) v[j] += (float)yp[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) hv[j] = (f16)v[j];
+        if (valid) {
+          if (co0 + NC <= a.cout) {
+            if (NC == 4) {
+              *reinterpret_cast<uint2*>(yp) = *reinterpret_cast<uint2*>(hv);
+            } else {
+#pragma unroll
+              for (int j = 0; j < NC; j += 8) *reinterpret_cast<uint4*>(yp + j) = *reinterpret_cast<uint4*>(hv + j);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+              if (co0 + j < a.cout) yp[j] = hv[j];
+          }
+          if (a.epi & DY_EPI_STATS) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+              const float r = (float)hv[j];
+              s1[j] += r;
+              s2[j] += r * r;
+            }
+          }
+        }
+      }
+    }
+    tile += gridDim.x;
+  }
+
+  if (a.epi & DY_EPI_STATS) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(st);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      s1[j] = quad16_sum(s1[j]);
+      s2[j] = quad16_sum(s2[j]);
+    }
+    if (p == 0) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        red[(wave * 2 + 0) * (16 * MT) + q * NC + j] = s1[j];
+        red[(wave * 2 + 1) * (16 * MT) + q * NC + j] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * 16 * MT) {
+      const int which = tid / (16 * MT), ch = tid - which * (16 * MT);
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[(w * 2 + which) * (16 * MT) + ch];
       const int ctot = gridDim.y * 16 * MT;
       a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + ch] = s;
     }
@@ -305,8 +612,56 @@ extern "C" int dy_pack_weights(const float* w, const float* scale, void* out, in
   return DY_OK;
 }
 
+#define DY_WLDS_BUDGET (156 * 1024)
+#define DY_WLDS_MAX_WGS 512
+static bool g_force_v1 = getenv("DY_CONV_V1") != nullptr;
+
+// LDS bytes of the v3 kernel with `trows` output rows per wave (FLAT: 32*trows pixels per wave)
+static size_t wlds_bytes_t(int cc, int mt, int ks, int stride, int nch, int trows) {
+  const bool flat = ks == 1;
+  const int th = 8 * trows, hw = flat ? 8 * 2 * trows * 16 : 31 * stride + ks, hh = flat ? 1 : (th - 1) * stride + ks;
+  size_t tile = (size_t)hh * hw * (cc * 2 + 16);
+  const size_t red = 8 * 2 * 16 * mt * 4;
+  if (tile < red) tile = red;
+  const size_t wts = (size_t)nch * ((ks * ks * cc + 31) / 32) * 16 * mt * 64;
+  return tile + wts;
+}
+// rows per wave the v3 kernel will use for a geometry (2 preferred, 1 when only that fits), 0 = v3 not applicable
+static int v3_trows(int cc, int mt, int ks, int stride, int nch) {
+  if (ks == 3 && stride == 2) return wlds_bytes_t(cc, mt, ks, stride, nch, 1) <= DY_WLDS_BUDGET ? 1 : 0;
+  if (wlds_bytes_t(cc, mt, ks, stride, nch, 2) <= DY_WLDS_BUDGET) return 2;
+  return wlds_bytes_t(cc, mt, ks, stride, nch, 1) <= DY_WLDS_BUDGET ? 1 : 0;
+}
+
+
+template <int CC, int MT, int KS, int STRIDE, int TR3>
+static int launch_v3(const ConvArgs& a, int grid_y, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = conv_mfma_wlds_kernel<CC, MT, KS, STRIDE, TR3>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DY_WLDS_BUDGET) != hipSuccess)
+      return DY_ERR_LAUNCH;
+    attr_set = true;
+  }
+  ConvArgs b = a;
+  int ntiles;
+  if (KS == 1) {
+    ntiles = cdiv(a.npix, 8 * 2 * TR3 * 16);
+  } else {
+    b.tiles_y = cdiv(a.Ho, 8 * TR3);
+    ntiles = b.tiles_x * b.tiles_y * a.N;
+  }
+  const int gx = ntiles < DY_WLDS_MAX_WGS ? ntiles : DY_WLDS_MAX_WGS;
+  hipLaunchKernelGGL(kern, dim3(gx, grid_y), dim3(512), wlds_bytes_t(CC, MT, KS, STRIDE, a.nch, TR3), s, b, ntiles);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
 template <int CC, int MT, int KS, int STRIDE, int TROWS>
 static int launch_conv(const ConvArgs& a, int grid_x, int grid_y, hipStream_t s) {
+  const int tr = (g_force_v1 || (CC == 64 && STRIDE == 2)) ? 0 : v3_trows(CC, MT, KS, STRIDE, a.nch);
+  if (tr == 2 && !(KS == 3 && STRIDE == 2)) return launch_v3<CC, MT, KS, STRIDE, (KS == 3 && STRIDE == 2) ? 1 : 2>(a, grid_y, s);
+  if (tr == 1) return launch_v3<CC, MT, KS, STRIDE, 1>(a, grid_y, s);
   hipLaunchKernelGGL((conv_mfma_kernel<CC, MT, KS, STRIDE, TROWS>), dim3(grid_x, grid_y), dim3(256), 0, s, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
@@ -323,6 +678,8 @@ static int dispatch_cc_mt(int cc, int mt, const ConvArgs& a, int gx, int gy, hip
 #undef DY_CASE
   return DY_ERR_ARG;
 }
+
+extern "C" int dy_conv_num_partials(int n, int h, int w, int cin, int cout, int ks, int stride, int dil);
 
 extern "C" int dy_conv_forward(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                                float* partials, int n, int h, int w, int cin, int cout, int ks, int stride, int dil,
@@ -355,7 +712,7 @@ extern "C" int dy_conv_forward(const void* x, int ldx, const void* w_packed, con
     a.tiles_y = cdiv(a.Ho, th);
     gx = a.tiles_x * a.tiles_y * n;
   }
-  if (num_partials) *num_partials = gx;
+  if (num_partials) *num_partials = dy_conv_num_partials(n, h, w, cin, cout, ks, stride, dil);
   if ((epi & DY_EPI_STATS) && !partials) return DY_ERR_ARG;
   if (gx <= 0) return DY_ERR_ARG;
   if (ks == 1) return dispatch_cc_mt<1, 1, 2>(cc, mt, a, gx, ng, stream);
@@ -364,9 +721,16 @@ extern "C" int dy_conv_forward(const void* x, int ldx, const void* w_packed, con
 }
 
 // number of partial rows dy_conv_forward will write for a given problem (host-side planning helper)
-extern "C" int dy_conv_num_partials(int n, int h, int w, int ks, int stride, int dil) {
+extern "C" int dy_conv_num_partials(int n, int h, int w, int cin, int cout, int ks, int stride, int dil) {
   const int H = dil == 2 ? 2 * h : h, W = dil == 2 ? 2 * w : w, pad = ks / 2;
   const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
-  if (ks == 1) return cdiv(n * Ho * Wo, 256);
-  return cdiv(Wo, 32) * cdiv(Ho, stride == 1 ? 8 : 4) * n;
+  int tiles;
+  if (ks == 1) tiles = cdiv(n * Ho * Wo, 256);
+  else tiles = cdiv(Wo, 32) * cdiv(Ho, stride == 1 ? 8 : 4) * n;
+  int cp, op, cc, nch, mt, ng, kst, pe;
+  if (dy_conv_geometry(cin, cout, ks, stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return tiles;
+  const int tr = (g_force_v1 || (cc == 64 && stride == 2)) ? 0 : v3_trows(cc, mt, ks, stride, nch);
+  if (!tr) return tiles;
+  const int t3 = ks == 1 ? cdiv(n * Ho * Wo, 8 * 2 * tr * 16) : cdiv(Wo, 32) * cdiv(Ho, 8 * tr) * n;
+  return t3 > DY_WLDS_MAX_WGS ? DY_WLDS_MAX_WGS : t3;
 }

@@ -34,13 +34,20 @@ static __device__ __forceinline__ half8 tr_frag(const char* base0, const char* b
   return u.h;
 }
 
+// output rows per tile: small channel counts get taller tiles so that staging is amortised over more k-steps
+static constexpr __host__ __device__ int wg_th(int ks, int stride, int nci, int mtc) {
+  if (ks == 1) return (nci + mtc <= 4) ? 8 : 4;
+  if (stride == 1) return (nci * mtc <= 1) ? 16 : ((nci + mtc <= 4) ? 8 : 4);
+  return (nci * mtc <= 1) ? 8 : ((nci + mtc <= 4) ? 4 : 2);
+}
+
 template <int KS, int STRIDE, int NCI, int MTC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   constexpr bool FLAT = (KS == 1);
   constexpr int TAPS = KS * KS;
   constexpr int NCOL = NCI * TAPS;          // (ci tile, tap) columns of this workgroup
   constexpr int CPW = (NCOL + 3) / 4;       // columns per wave (round-robin)
-  constexpr int TH = FLAT ? 4 : (STRIDE == 1 ? 4 : 2), TW = 32;
+  constexpr int TH = wg_th(KS, STRIDE, NCI, MTC), TW = 32;
   constexpr int HWX = FLAT ? TH * TW : (TW - 1) * STRIDE + KS;
   constexpr int HHX = FLAT ? 1 : (TH - 1) * STRIDE + KS;
   constexpr int PAD = KS / 2;
@@ -162,19 +169,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   }
 }
 
-// dW[co][ci][tap] (+)= sum_wg slab[wg][tap][co][ci]
+// dW[co][ci][tap] (+)= sum_wg slab[wg][tap][co][ci].  One wave covers 64 consecutive slab elements (coalesced 256-byte
+// reads per slab); the slab axis is split over the block's 4 waves with 4 independent loads in flight per thread, so
+// the reduction is bandwidth- rather than latency-bound.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int nslabs, float* dw, int cout, int cin,
                                                            int taps, int cout_p, int cin_p, int accumulate) {
-  const int total = cout * cin * taps;
-  const size_t slab_elems = (size_t)taps * cout_p * cin_p;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
-    const int tap = idx % taps;
-    const int t = idx / taps;
-    const int ci = t % cin, co = t / cin;
-    const size_t off = ((size_t)tap * cout_p + co) * cin_p + ci;
-    float s = 0.f;
-    for (int k = 0; k < nslabs; ++k) s += slabs[k * slab_elems + off];
-    dw[idx] = accumulate ? dw[idx] + s : s;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long S = (long)taps * cout_p * cin_p;
+  const long o = (long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (o < S) {
+    const float* p = slabs + o;
+    int k = grp;
+    for (; k + 12 < nslabs; k += 16) {
+      s0 += p[(long)k * S];
+      s1 += p[(long)(k + 4) * S];
+      s2 += p[(long)(k + 8) * S];
+      s3 += p[(long)(k + 12) * S];
+    }
+    for (; k < nslabs; k += 4) s0 += p[(long)k * S];
+  }
+  __shared__ float red[4][64];
+  red[grp][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && o < S) {
+    const float tot = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int ci = (int)(o % cin_p);
+    const long t = o / cin_p;
+    const int co = (int)(t % cout_p), tap = (int)(t / cout_p);
+    if (co < cout && ci < cin) {
+      float* d = dw + ((long)co * cin + ci) * taps + tap;
+      *d = accumulate ? *d + tot : tot;
+    }
   }
 }
 
@@ -209,14 +235,18 @@ extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks
   int cp, op, nci, mtc;
   wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc);
   const int pad = ks / 2, Ho = (h + 2 * pad - ks) / stride + 1, Wo = (w + 2 * pad - ks) / stride + 1;
+  const int th = wg_th(ks, stride, nci, mtc);
   int ntiles;
-  if (ks == 1) ntiles = (int)(((long)n * Ho * Wo + 127) / 128);
-  else ntiles = cdiv(Wo, 32) * cdiv(Ho, stride == 1 ? 4 : 2) * n;
-  int gx = ntiles / 8;
-  if (gx > 512) gx = 512;
+  if (ks == 1) ntiles = (int)(((long)n * Ho * Wo + th * 32 - 1) / (th * 32));
+  else ntiles = cdiv(Wo, 32) * cdiv(Ho, th) * n;
+  *slab_elems = (long)ks * ks * cp * op;
+  long cap = (64L << 20) / (*slab_elems * 4);  // keep the slab round trip below ~64 MB per layer
+  if (cap > 768) cap = 768;
+  if (cap < 64) cap = 64;
+  int gx = ntiles / 4;
+  if (gx > cap) gx = (int)cap;
   if (gx < 1) gx = 1;
   *nslabs = gx;
-  *slab_elems = (long)ks * ks * cp * op;
   return DY_OK;
 }
 
@@ -236,12 +266,13 @@ extern "C" int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, f
   a.cin_r8 = (cin + 7) / 8 * 8; a.cout_r8 = (cout + 7) / 8 * 8;
   a.nci_chunks = cp / (16 * nci);
   const int nco_chunks = op / (16 * mtc);
+  const int th = wg_th(ks, stride, nci, mtc);
   if (ks == 1) {
     a.npix = (long)n * a.Ho * a.Wo;
-    a.ntiles = (int)((a.npix + 127) / 128);
+    a.ntiles = (int)((a.npix + th * 32 - 1) / (th * 32));
   } else {
     a.tiles_x = cdiv(a.Wo, 32);
-    a.tiles_y = cdiv(a.Ho, stride == 1 ? 4 : 2);
+    a.tiles_y = cdiv(a.Ho, th);
     a.ntiles = a.tiles_x * a.tiles_y * n;
   }
   int nslabs;
@@ -253,9 +284,9 @@ extern "C" int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, f
   else if (stride == 1) rc = dispatch_wgrad<3, 1>(nci, mtc, a, nslabs, gy, stream);
   else rc = dispatch_wgrad<3, 2>(nci, mtc, a, nslabs, gy, stream);
   if (rc != DY_OK) return rc;
-  const int total = cout * cin * ks * ks;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256) < 512 ? cdiv(total, 256) : 512), dim3(256), 0, stream,
-                     slabs, nslabs, dw, cout, cin, ks * ks, op, cp, accumulate);
+  const int total = ks * ks * op * cp;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, stream, slabs, nslabs, dw, cout, cin,
+                     ks * ks, op, cp, accumulate);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

@@ -37,7 +37,7 @@ SIGNATURES = {
     "dy_conv_geometry": (i32, [i32, i32, i32, i32, ip, ip, ip, ip, ip, ip, ip, ip]),
     "dy_pack_weights": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dy_conv_forward": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, ip, vp]),
-    "dy_conv_num_partials": (i32, [i32, i32, i32, i32, i32, i32]),
+    "dy_conv_num_partials": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "dy_wgrad_workspace": (i32, [i32, i32, i32, i32, i32, i32, i32, ip, lp]),
     "dy_conv_wgrad": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_bn_finalize": (i32, [vp, i32, f32, vp, i32, f32, vp, i32, f32, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp]),

@@ -269,7 +269,7 @@ class Engine:
         npix = x.N * Ho * Wo
         bn = spec.bn
         if self.training:
-            nparts = self.L.dy_conv_num_partials(x.N, x.H, x.W, spec.ks, spec.stride, 1)
+            nparts = self.L.dy_conv_num_partials(x.N, x.H, x.W, x.C, spec.cout, spec.ks, spec.stride, 1)
             part = self.scratch("partials", nparts * 2 * ((spec.cout + 15) // 16 * 16) * 4 + 4096)
             self._conv_raw(spec, x, raw.ptr, raw.ld, DY_EPI_STATS, part.data_ptr())
             cp16 = (spec.cout + 15) // 16 * 16
@@ -438,7 +438,7 @@ class Engine:
         cp16 = (Cc + 15) // 16 * 16
         total = 0
         for l, p in enumerate(ps):
-            n = self.L.dy_conv_num_partials(p.N, p.H, p.W, 1, 1, 1)
+            n = self.L.dy_conv_num_partials(p.N, p.H, p.W, p.C, Cc, 1, 1, 1)
             nps.append(n)
             offs.append(total)
             total += n * 2 * cp16 * 4

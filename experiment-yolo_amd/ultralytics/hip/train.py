@@ -159,3 +159,58 @@ class StepPlan:
         """(loss*B, [box, cls, dfl]) -- synchronises."""
         s = self.crit.scalars.cpu()
         return float(s[8]), s[5:8].clone()
+
+    # ---- measurement helpers (bench.py) -------------------------------------------------------------------------
+    def profile_ops(self, reps=3):
+        """Event-timed, un-captured replay of the forward/backward launch list on the launch stream.
+        Returns [(name, args, avg_ms)] per recorded C-ABI call."""
+        ops = self.rec_fb.ops
+        s = self.eng.stream
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 1)]
+        tot = [0.0] * len(ops)
+        for _ in range(reps):
+            evs[0].record()
+            for i, (fn, args, name) in enumerate(ops):
+                rc = fn(*args, s)
+                if rc != 0:
+                    check(rc, name)
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            for i in range(len(ops)):
+                tot[i] += evs[i].elapsed_time(evs[i + 1])
+        return [(ops[i][2], ops[i][1], tot[i] / reps) for i in range(len(ops))]
+
+    @staticmethod
+    def conv_algorithmic_bytes(args):
+        """Algorithmic HBM bytes of one dy_conv_forward launch: input read once + output written once (+ read when
+        accumulating), at the storage dtype (SURVEY.md 8(d) definition)."""
+        (_x, _ldx, _w, _b, _y, _ldy, _p, n, h, w, cin, cout, ks, stride, dil, oh, ow, epi, _np) = args
+        H, W = (2 * h, 2 * w) if dil == 2 else (h, w)
+        pad = ks // 2
+        Ho, Wo = ((H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1) if not oh else (oh, ow)
+        ob = 4 if epi & 8 else 2
+        out = n * Ho * Wo * cout * ob
+        return n * h * w * cin * 2 + out * (2 if epi & 16 else 1)
+
+    def probe_dominant_kernel(self, batch, reps=10):
+        """Time every launch, pick the slowest dy_conv_forward (= exactly one conv_mfma_kernel launch) and price it."""
+        if self.rec_fb is None:
+            self.forward_backward(batch)
+        prof = self.profile_ops(reps)
+        self.last_profile = prof
+        convs = [(ms, args) for name, args, ms in prof if name == "dy_conv_forward"]
+        if not convs:
+            return None
+        ms, args = max(convs, key=lambda t: t[0])
+        by = self.conv_algorithmic_bytes(args)
+        n, h, w, cin, cout, ks, stride, dil = args[7:15]
+        return {"kernel": f"conv_mfma_kernel {cin}->{cout} k{ks} s{stride} dil{dil} @{h}x{w} n={n}", "us": ms * 1e3, "bytes": by,
+                "gbs": by / (ms * 1e-3) / 1e9}
+
+    def breakdown(self):
+        agg = {}
+        for name, _a, ms in getattr(self, "last_profile", []):
+            k = agg.setdefault(name, [0, 0.0])
+            k[0] += 1
+            k[1] += ms
+        return {k: {"calls": v[0], "ms": round(v[1], 3)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}

@@ -60,7 +60,7 @@ int dy_pack_weights(const float* w, const float* scale, void* out, int cout, int
 int dy_conv_forward(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy, float* partials,
                     int n, int h, int w, int cin, int cout, int ks, int stride, int dil, int out_h, int out_w, int epi,
                     int* num_partials, hipStream_t stream);
-int dy_conv_num_partials(int n, int h, int w, int ks, int stride, int dil);
+int dy_conv_num_partials(int n, int h, int w, int cin, int cout, int ks, int stride, int dil);
 
 /* ---- weight-gradient half of aten::convolution_backward for the same modules. dw: fp32 OIHW (cout,cin,ks,ks). -- */
 int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int stride, int* nslabs, long* slab_elems);

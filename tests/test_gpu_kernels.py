@@ -65,7 +65,7 @@ def test_conv_forward_dgrad_wgrad(cin, cout, ks, s, H, W):
     cp = (cout + 15) // 16 * 16
     if cout % 8 == 0:
         y16 = torch.zeros(N, Ho, Wo, cout, dtype=torch.float16, device="cuda")
-        nparts = eng.L.dy_conv_num_partials(N, H, W, ks, s, 1)
+        nparts = eng.L.dy_conv_num_partials(N, H, W, xa.C, cout, ks, s, 1)
         part = torch.zeros(nparts, 2, cp, device="cuda")
         eng.call("dy_conv_forward", xa.ptr, xa.ld, sp.wpack.data_ptr(), 0, y16.data_ptr(), cout, part.data_ptr(), N, H, W, xa.C, cout,
                  ks, s, 1, 0, 0, 1, None)
