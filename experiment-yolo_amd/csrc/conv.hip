@@ -534,6 +534,7 @@ struct PackArgs {
   const float* scale;  // per-Cout multiplier or null
   f16* out;
   int cout, cin, ks, cc, nch, mt, ngroups, ksteps, transposed;
+  int ld_taps, ld_cphys;  // LDConv column conv: reduction index n*ld_cphys + c maps to w[(o*cin + c)*ld_taps + n]
 };
 
 __global__ void pack_weights_kernel(PackArgs a) {
@@ -554,7 +555,11 @@ __global__ void pack_weights_kernel(PackArgs a) {
     const int tap = flat / a.cc, c = h * a.cc + (flat - tap * a.cc);
     float v = 0.f;
     const int ntap = a.ks * a.ks;
-    if (tap < ntap) {
+    if (a.ld_taps) {  // ks == 1: `c` (forward) or `o` (transposed) runs over n*ld_cphys + channel
+      const int kidx = a.transposed ? o : c, oc = a.transposed ? c : o;
+      const int n = kidx / a.ld_cphys, ch = kidx - n * a.ld_cphys;
+      if (tap == 0 && n < a.ld_taps && ch < a.cin && oc < a.cout) v = a.w[((size_t)oc * a.cin + ch) * a.ld_taps + n];
+    } else if (tap < ntap) {
       if (!a.transposed) {
         if (o < a.cout && c < a.cin) {
           v = a.w[((size_t)o * a.cin + c) * ntap + tap];
@@ -598,6 +603,19 @@ extern "C" int dy_conv_geometry(int cin, int cout, int ks, int stride, int* cin_
   return DY_OK;
 }
 
+extern "C" int dy_pack_weights_ld(const float* w, void* out, int cout, int cin, int ld_taps, int ld_cphys, int transposed,
+                                  hipStream_t stream) {
+  int cp, op, cc, nch, mt, ng, kst, pe;
+  const int keff = ld_taps * ld_cphys, coutp = (cout + 7) / 8 * 8;
+  const int pin = transposed ? coutp : keff, pout = transposed ? keff : cout;
+  if (dy_conv_geometry(pin, pout, 1, 1, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return DY_ERR_ARG;
+  PackArgs a{w, nullptr, (f16*)out, cout, cin, 1, cc, nch, mt, ng, kst, transposed, ld_taps, ld_cphys};
+  const int blocks = cdiv(pe, 256) < 1024 ? cdiv(pe, 256) : 1024;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
 extern "C" int dy_pack_weights(const float* w, const float* scale, void* out, int cout, int cin, int ks, int stride,
                                int transposed, hipStream_t stream) {
   // geometry is that of the pass that will consume the pack: (cin -> cout) forward, or (cout -> cin) stride-1 dgrad
@@ -605,7 +623,7 @@ extern "C" int dy_pack_weights(const float* w, const float* scale, void* out, in
   const int pin = transposed ? cout : cin, pout = transposed ? cin : cout;
   if (dy_conv_geometry(pin, pout, ks, transposed ? 1 : stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK)
     return DY_ERR_ARG;
-  PackArgs a{w, scale, (f16*)out, cout, cin, ks, cc, nch, mt, ng, kst, transposed};
+  PackArgs a{w, scale, (f16*)out, cout, cin, ks, cc, nch, mt, ng, kst, transposed, 0, 0};
   const int blocks = cdiv(pe, 256) < 1024 ? cdiv(pe, 256) : 1024;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, a);
   DY_CHECK_LAUNCH();

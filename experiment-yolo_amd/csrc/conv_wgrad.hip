@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 // reads per slab); the slab axis is split over the block's 4 waves with 4 independent loads in flight per thread, so
 // the reduction is bandwidth- rather than latency-bound.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int nslabs, float* dw, int cout, int cin,
-                                                           int taps, int cout_p, int cin_p, int accumulate) {
+                                                           int taps, int cout_p, int cin_p, int accumulate,
+                                                           int ld_taps, int ld_cphys, int ld_cin) {
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const long S = (long)taps * cout_p * cin_p;
   const long o = (long)blockIdx.x * 64 + lane;
@@ -197,7 +198,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, i
     const int ci = (int)(o % cin_p);
     const long t = o / cin_p;
     const int co = (int)(t % cout_p), tap = (int)(t / cout_p);
-    if (co < cout && ci < cin) {
+    if (ld_taps) {  // LDConv column conv: ci = n*ld_cphys + channel  ->  dw[(co*ld_cin + channel)*ld_taps + n]
+      const int n = ci / ld_cphys, ch = ci - n * ld_cphys;
+      if (co < cout && n < ld_taps && ch < ld_cin) {
+        float* d = dw + ((long)co * ld_cin + ch) * ld_taps + n;
+        *d = accumulate ? *d + tot : tot;
+      }
+    } else if (co < cout && ci < cin) {
       float* d = dw + ((long)co * cin + ci) * taps + tap;
       *d = accumulate ? *d + tot : tot;
     }
@@ -250,8 +257,24 @@ extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks
   return DY_OK;
 }
 
+static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
+                           int cin, int cout, int ks, int stride, int accumulate, int ld_taps, int ld_cphys, int ld_cin,
+                           hipStream_t stream);
+
 extern "C" int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h,
                              int w, int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream) {
+  return conv_wgrad_impl(x, ldx, dy, lddy, slabs, dw, n, h, w, cin, cout, ks, stride, accumulate, 0, 0, 0, stream);
+}
+// LDConv column conv: x = sampled map with ld_taps*ld_cphys channels, dw = (cout, ld_cin, ld_taps, 1) fp32
+extern "C" int dy_conv_wgrad_ld(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h,
+                                int w, int cout, int ld_cin, int ld_taps, int ld_cphys, int accumulate, hipStream_t stream) {
+  return conv_wgrad_impl(x, ldx, dy, lddy, slabs, dw, n, h, w, ld_taps * ld_cphys, cout, 1, 1, accumulate, ld_taps, ld_cphys,
+                         ld_cin, stream);
+}
+
+static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
+                           int cin, int cout, int ks, int stride, int accumulate, int ld_taps, int ld_cphys, int ld_cin,
+                           hipStream_t stream) {
   if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || (ks == 1 && stride != 1)) return DY_ERR_ARG;
   if ((ldx & 7) || (lddy & 7) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return DY_ERR_ALIGN;
   int cp, op, nci, mtc;
@@ -286,7 +309,7 @@ extern "C" int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, f
   if (rc != DY_OK) return rc;
   const int total = ks * ks * op * cp;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, stream, slabs, nslabs, dw, cout, cin,
-                     ks * ks, op, cp, accumulate);
+                     ks * ks, op, cp, accumulate, ld_taps, ld_cphys, ld_cin);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

@@ -1,2 +1,183 @@
-// LDConv sampling kernels (added after the training path)
+// LDConv (linear deformable convolution, reference nn/modules/conv.py:350-503) sampling stage, forward and backward.
+//
+// The reference builds p = p0 + p_n + offset, floors/clamps four corner indices, expands an int64 gather index over
+// all channels four times (:456-489) and blends with bilinear weights g (:390-393).  Here one kernel reads the offsets
+// (fp32, from the p_conv 3x3 MFMA conv), gathers the four corners straight from the NHWC fp16 map (channel-contiguous
+// 16-byte granules) and writes the N samples of every output pixel channel-major as x_off[pix][n*C + c], which turns the
+// reference's (N,1)-kernel column conv (:354, 'b c h w n -> b c (h n) w' :494-503) into a plain 1x1 MFMA conv with
+// K = N*C.  Backward: scatter-add of the sample gradients into an fp32 accumulator (atomics) and the offset gradient
+// through dg/dp with the reference's clamp semantics (no gradient through floor; clamp passes gradient inside [0, H-1]).
 #include "common.h"
+#include "dealyolo_hip.h"
+
+struct LdArgs {
+  const f16* x;
+  const float* off;   // (N,h,w,2*Np): first Np = row offsets, last Np = col offsets
+  f16* xo;            // (N,h,w,Np*C)
+  const f16* dxo;     // backward: gradient of xo
+  float* dx32;        // backward: (N,H,W,C) fp32 accumulator (zeroed by the caller)
+  f16* doff;          // backward: (N,h,w,ldoff) fp16, channels [0,2Np)
+  const int* pn;      // (2*Np) initial sampling shape p_n (rows then cols)
+  int ldx, ldxo, lddxo, ldoff_in, lddoff;
+  int N, H, W, h, w, C, Np, stride;
+};
+
+static __device__ __forceinline__ void ld_coords(const LdArgs& a, long pix, int n, int& r0, int& r1, int& c0, int& c1,
+                                                 float& pr, float& pc, bool& in_r, bool& in_c, long& img) {
+  const int ox = (int)(pix % a.w);
+  const long t = pix / a.w;
+  const int oy = (int)(t % a.h);
+  img = t / a.h;
+  const float* o = a.off + pix * a.ldoff_in;
+  const float ur = (float)(oy * a.stride) + (float)a.pn[n] + o[n];            // :446-454
+  const float uc = (float)(ox * a.stride) + (float)a.pn[a.Np + n] + o[a.Np + n];
+  const float fr = floorf(ur), fc = floorf(uc);
+  const float Hm = (float)(a.H - 1), Wm = (float)(a.W - 1);
+  r0 = (int)fminf(fmaxf(fr, 0.f), Hm);
+  r1 = (int)fminf(fmaxf(fr + 1.f, 0.f), Hm);
+  c0 = (int)fminf(fmaxf(fc, 0.f), Wm);
+  c1 = (int)fminf(fmaxf(fc + 1.f, 0.f), Wm);
+  pr = fminf(fmaxf(ur, 0.f), Hm);
+  pc = fminf(fmaxf(uc, 0.f), Wm);
+  in_r = ur >= 0.f && ur <= Hm;  // torch.clamp backward passes gradient where min <= x <= max
+  in_c = uc >= 0.f && uc <= Wm;
+}
+
+__global__ __launch_bounds__(256) void ldconv_sample_kernel(LdArgs a) {
+  const int cpp = a.C >> 3;
+  const long total = (long)a.N * a.h * a.w * a.Np * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int part = (int)(idx % cpp);
+    long t = idx / cpp;
+    const int n = (int)(t % a.Np);
+    const long pix = t / a.Np;
+    int r0, r1, c0, c1;
+    float pr, pc;
+    bool ir, ic;
+    long img;
+    ld_coords(a, pix, n, r0, r1, c0, c1, pr, pc, ir, ic, img);
+    const float g_lt = (1.f + ((float)r0 - pr)) * (1.f + ((float)c0 - pc));
+    const float g_rb = (1.f - ((float)r1 - pr)) * (1.f - ((float)c1 - pc));
+    const float g_lb = (1.f + ((float)r0 - pr)) * (1.f - ((float)c1 - pc));
+    const float g_rt = (1.f - ((float)r1 - pr)) * (1.f + ((float)c0 - pc));
+    const f16* xb = a.x + img * a.H * a.W * a.ldx + part * 8;
+    const half8 v_lt = *reinterpret_cast<const half8*>(xb + ((long)r0 * a.W + c0) * a.ldx);
+    const half8 v_rb = *reinterpret_cast<const half8*>(xb + ((long)r1 * a.W + c1) * a.ldx);
+    const half8 v_lb = *reinterpret_cast<const half8*>(xb + ((long)r0 * a.W + c1) * a.ldx);
+    const half8 v_rt = *reinterpret_cast<const half8*>(xb + ((long)r1 * a.W + c0) * a.ldx);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      o[j] = (f16)(g_lt * (float)v_lt[j] + g_rb * (float)v_rb[j] + g_lb * (float)v_lb[j] + g_rt * (float)v_rt[j]);
+    *reinterpret_cast<half8*>(a.xo + pix * a.ldxo + n * a.C + part * 8) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void ldconv_sample_bwd_kernel(LdArgs a) {
+  const int cpp = a.C >> 3;  // power of two <= 32 (checked by the host)
+  const long total = (long)a.N * a.h * a.w * a.Np * cpp;
+  const long span = ((total + 255) / 256) * 256;  // keep whole waves in the loop so shuffles see every lane
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < span; idx += (long)gridDim.x * 256) {
+    const bool live = idx < total;
+    const long id2 = live ? idx : total - 1;
+    const int part = (int)(id2 % cpp);
+    long t = id2 / cpp;
+    const int n = (int)(t % a.Np);
+    const long pix = t / a.Np;
+    int r0, r1, c0, c1;
+    float pr, pc;
+    bool ir, ic;
+    long img;
+    ld_coords(a, pix, n, r0, r1, c0, c1, pr, pc, ir, ic, img);
+    const float ar0 = 1.f + ((float)r0 - pr), ar1 = 1.f - ((float)r1 - pr);
+    const float ac0 = 1.f + ((float)c0 - pc), ac1 = 1.f - ((float)c1 - pc);
+    const float g_lt = ar0 * ac0, g_rb = ar1 * ac1, g_lb = ar0 * ac1, g_rt = ar1 * ac0;
+    const f16* xb = a.x + img * a.H * a.W * a.ldx + part * 8;
+    const long o_lt = ((long)r0 * a.W + c0), o_rb = ((long)r1 * a.W + c1), o_lb = ((long)r0 * a.W + c1), o_rt = ((long)r1 * a.W + c0);
+    const half8 v_lt = *reinterpret_cast<const half8*>(xb + o_lt * a.ldx);
+    const half8 v_rb = *reinterpret_cast<const half8*>(xb + o_rb * a.ldx);
+    const half8 v_lb = *reinterpret_cast<const half8*>(xb + o_lb * a.ldx);
+    const half8 v_rt = *reinterpret_cast<const half8*>(xb + o_rt * a.ldx);
+    const half8 g = *reinterpret_cast<const half8*>(a.dxo + pix * a.lddxo + n * a.C + part * 8);
+    float dpr = 0.f, dpc = 0.f;
+    float* db = a.dx32 ? a.dx32 + img * a.H * a.W * a.C + part * 8 : nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gj = live ? (float)g[j] : 0.f;
+      // d/dp_r: d(ar0) = -1, d(ar1) = +1 ; d/dp_c: d(ac0) = -1, d(ac1) = +1
+      dpr += gj * (-ac0 * (float)v_lt[j] + ac1 * (float)v_rb[j] - ac1 * (float)v_lb[j] + ac0 * (float)v_rt[j]);
+      dpc += gj * (-ar0 * (float)v_lt[j] + ar1 * (float)v_rb[j] + ar0 * (float)v_lb[j] - ar1 * (float)v_rt[j]);
+      if (db && live) {
+        atomicAdd(db + o_lt * a.C + j, gj * g_lt);
+        atomicAdd(db + o_rb * a.C + j, gj * g_rb);
+        atomicAdd(db + o_lb * a.C + j, gj * g_lb);
+        atomicAdd(db + o_rt * a.C + j, gj * g_rt);
+      }
+    }
+    for (int o = 1; o < cpp; o <<= 1) {  // the cpp granule-threads of one (pixel, n) are adjacent lanes
+      dpr += __shfl_xor(dpr, o, 64);
+      dpc += __shfl_xor(dpc, o, 64);
+    }
+    if (live && part == 0) {
+      f16* d = a.doff + pix * a.lddoff;
+      d[n] = (f16)(ir ? dpr : 0.f);
+      d[a.Np + n] = (f16)(ic ? dpc : 0.f);
+    }
+  }
+}
+
+extern "C" int dy_ldconv_sample(const void* x, int ldx, const float* off, int ldoff, const int* pn, void* xo, int ldxo,
+                                int n, int H, int W, int h, int w, int C, int Np, int stride, hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (ldxo & 7)) return DY_ERR_ALIGN;
+  LdArgs a{};
+  a.x = (const f16*)x; a.off = off; a.xo = (f16*)xo; a.pn = pn; a.ldx = ldx; a.ldxo = ldxo; a.ldoff_in = ldoff;
+  a.N = n; a.H = H; a.W = W; a.h = h; a.w = w; a.C = C; a.Np = Np; a.stride = stride;
+  long blocks = ((long)n * h * w * Np * (C >> 3) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(ldconv_sample_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+extern "C" int dy_ldconv_sample_backward(const void* x, int ldx, const float* off, int ldoff, const int* pn,
+                                         const void* dxo, int lddxo, float* dx32, void* doff, int lddoff, int n, int H,
+                                         int W, int h, int w, int C, int Np, int stride, hipStream_t stream) {
+  const int cpp = C >> 3;
+  if ((C & 7) || (ldx & 7) || (lddxo & 7) || (cpp & (cpp - 1)) || cpp > 32) return DY_ERR_ALIGN;
+  LdArgs a{};
+  a.x = (const f16*)x; a.off = off; a.dxo = (const f16*)dxo; a.dx32 = dx32; a.doff = (f16*)doff; a.pn = pn;
+  a.ldx = ldx; a.lddxo = lddxo; a.ldoff_in = ldoff; a.lddoff = lddoff;
+  a.N = n; a.H = H; a.W = W; a.h = h; a.w = w; a.C = C; a.Np = Np; a.stride = stride;
+  long blocks = ((long)n * h * w * Np * cpp + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(ldconv_sample_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// dst(fp16, strided) (+)= src(fp32 dense): folds the fp32 scatter accumulator into the activation-gradient buffer
+__global__ __launch_bounds__(256) void f32_to_f16_add_kernel(const float* src, f16* dst, int ld, int C, long npix, int accumulate) {
+  const int cpp = C >> 3;
+  const long total = npix * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int c0 = (int)(idx - pix * cpp) * 8;
+    const float4 a0 = *reinterpret_cast<const float4*>(src + pix * C + c0), a1 = *reinterpret_cast<const float4*>(src + pix * C + c0 + 4);
+    float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    f16* d = dst + pix * ld + c0;
+    half8 o;
+    if (accumulate) o = *reinterpret_cast<const half8*>(d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] + (accumulate ? (float)o[j] : 0.f));
+    *reinterpret_cast<half8*>(d) = o;
+  }
+}
+extern "C" int dy_f32_to_f16_add(const float* src, void* dst, int ld, long npix, int C, int accumulate, hipStream_t stream) {
+  if ((C & 7) || (ld & 7)) return DY_ERR_ALIGN;
+  long blocks = (npix * (C >> 3) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(f32_to_f16_add_kernel, dim3((int)blocks), dim3(256), 0, stream, src, (f16*)dst, ld, C, npix, accumulate);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}

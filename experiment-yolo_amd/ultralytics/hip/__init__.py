@@ -40,6 +40,11 @@ SIGNATURES = {
     "dy_conv_num_partials": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "dy_wgrad_workspace": (i32, [i32, i32, i32, i32, i32, i32, i32, ip, lp]),
     "dy_conv_wgrad": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_ldconv_sample": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_ldconv_sample_backward": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_f32_to_f16_add": (i32, [vp, vp, i32, i64, i32, i32, vp]),
+    "dy_pack_weights_ld": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dy_conv_wgrad_ld": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_bn_finalize": (i32, [vp, i32, f32, vp, i32, f32, vp, i32, f32, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp]),
     "dy_bn_eval_coef": (i32, [vp, vp, vp, vp, vp, i32, f32, vp]),
     "dy_bn_act_apply": (i32, [vp, i32, vp, i32, vp, i32, vp, i64, i32, i32, vp]),
@@ -59,6 +64,9 @@ SIGNATURES = {
     "dy_loss_workspace_bytes": (sz, [i32, i32, i32]),
     "dy_loss_workspace_layout": (i32, [i32, i32, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     "dy_detection_loss": (i32, [C.POINTER(DyLossArgs), vp]),
+    "dy_decode_predictions": (i32, [vp, vp, ip, ip, C.POINTER(f32), i32, i32, i32, i32, vp, vp]),
+    "dy_nms_candidates": (i32, [vp, i32, i32, i32, f32, i32, vp, i32, vp, vp, vp, vp, i32, vp]),
+    "dy_soft_nms": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp]),
     "dy_optimizer_step": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, i64, vp, vp, vp, i32, vp]),
     "dy_axpy_f32": (i32, [vp, vp, f32, i64, vp]),
 }

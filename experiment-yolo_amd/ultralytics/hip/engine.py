@@ -129,6 +129,7 @@ class ConvSpec:
         self.name, self.weight, self.bias, self.bn = name, weight, bias, bn  # bn: dict(weight,bias,running_mean,running_var,nbt)|None
         self.ks, self.stride, self.act = ks, stride, act
         self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.ld = None  # (N, C_phys, real_cin) for LDConv's (N,1) column conv seen as a 1x1 conv over N*C_phys channels
         self.bn_eps, self.bn_mom = bn_eps, bn_mom
         self.wpack = self.wpack_t = self.coef = self.bwdcoef = None
         self.gweight = self.gbias = self.gbn_w = self.gbn_b = None  # fp32 gradient views
@@ -212,6 +213,8 @@ class Engine:
         if spec.wpack is not None:
             return
         g = [C.c_int() for _ in range(8)]
+        if spec.ld is not None:
+            spec.cin = spec.ld[0] * spec.ld[1]
         cin_phys = (spec.cin + 7) // 8 * 8
         check(self.L.dy_conv_geometry(spec.cin, spec.cout, spec.ks, spec.stride, *[C.byref(x) for x in g]), "dy_conv_geometry")
         spec.wpack = torch.zeros(g[7].value, dtype=torch.float16, device=self.device)
@@ -226,6 +229,12 @@ class Engine:
 
     def pack(self, spec: ConvSpec, fold_scale=None, transposed=True):
         self.prepare_conv(spec)
+        if spec.ld is not None:
+            n, cphys, cin = spec.ld
+            self.call("dy_pack_weights_ld", spec.weight.data_ptr(), spec.wpack.data_ptr(), spec.cout, cin, n, cphys, 0)
+            if transposed:
+                self.call("dy_pack_weights_ld", spec.weight.data_ptr(), spec.wpack_t.data_ptr(), spec.cout, cin, n, cphys, 1)
+            return
         self.call("dy_pack_weights", spec.weight.data_ptr(), _ptr(fold_scale), spec.wpack.data_ptr(), spec.cout, spec.cin,
                   spec.ks, spec.stride, 0)
         if transposed:
@@ -312,8 +321,13 @@ class Engine:
         ns, se = C.c_int(), C.c_long()
         self.L.dy_wgrad_workspace(x.N, x.H, x.W, spec.cin, spec.cout, spec.ks, spec.stride, C.byref(ns), C.byref(se))
         slabs = self.scratch("slabs", ns.value * se.value * 4)
-        self.call("dy_conv_wgrad", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), spec.gweight.data_ptr(), x.N, x.H, x.W,
-                  spec.cin, spec.cout, spec.ks, spec.stride, accumulate_w)
+        if spec.ld is not None:
+            n, cphys, cin = spec.ld
+            self.call("dy_conv_wgrad_ld", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), spec.gweight.data_ptr(), x.N, x.H, x.W,
+                      spec.cout, cin, n, cphys, accumulate_w)
+        else:
+            self.call("dy_conv_wgrad", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), spec.gweight.data_ptr(), x.N, x.H, x.W,
+                      spec.cin, spec.cout, spec.ks, spec.stride, accumulate_w)
         if x.needs_grad:
             acc = x.grad_target()
             self.call("dy_conv_forward", dy_ptr, lddy, spec.wpack_t.data_ptr(), 0, x.gptr, x.ld, 0, x.N, Ho, Wo,
@@ -483,6 +497,35 @@ class Engine:
                       None)
             # shared conv3d weights/bias: the three scales accumulate into one gradient
             self._conv_bias_bwd(conv3d, p, lambda dr=dr, Cc=Cc: (dr.data_ptr(), Cc), accumulate=1 if l else 0)
+
+    # ---- LDConv (reference nn/modules/conv.py:366-410) -----------------------------------------------------------
+    def ldconv(self, sp_p: ConvSpec, sp_c: ConvSpec, pn_i32, Np, stride, x: Act, out: Act | None = None):
+        h, w = self.out_hw(sp_p, x)
+        off = torch.empty((x.N, h, w, 2 * Np), dtype=torch.float32, device=self.device)
+        self.keep.append(off)
+        doff = None
+        if self.tape is not None:
+            doff = torch.zeros((x.N, h, w, 8 * ((2 * Np + 7) // 8)), dtype=torch.float16, device=self.device)
+            self.keep.append(doff)
+        self.conv_bias(sp_p, x, off.data_ptr(), 2 * Np, True, lambda: (doff.data_ptr(), doff.shape[-1]))
+        xo = self.new_act(x.N, h, w, Np * x.C)
+        self.call("dy_ldconv_sample", x.ptr, x.ld, off.data_ptr(), 2 * Np, pn_i32.data_ptr(), xo.ptr, xo.ld, x.N, x.H, x.W, h, w,
+                  x.C, Np, stride)
+        if self.tape is not None:
+            def bwd():
+                assert xo.grad_ready()
+                dx32 = None
+                if x.needs_grad:
+                    dx32 = self.scratch("ld_dx32", x.npix * x.C * 4)
+                    self.call("dy_fill_zero", dx32.data_ptr(), x.npix * x.C * 4)
+                self.call("dy_ldconv_sample_backward", x.ptr, x.ld, off.data_ptr(), 2 * Np, pn_i32.data_ptr(), xo.gptr, xo.ld,
+                          0 if dx32 is None else dx32.data_ptr(), doff.data_ptr(), doff.shape[-1], x.N, x.H, x.W, h, w, x.C, Np,
+                          stride)
+                if dx32 is not None:
+                    acc = x.grad_target()
+                    self.call("dy_f32_to_f16_add", dx32.data_ptr(), x.gptr, x.ld, x.npix, x.C, acc)
+            self.tape.append(bwd)
+        return self.conv_bn_act(sp_c, xo, out)
 
     # ---- loss -----------------------------------------------------------------------------------------------------
     def zero_f32(self, t):

@@ -111,14 +111,15 @@ class Runtime:
         return dict(weight=bn.weight.data, bias=bn.bias.data, running_mean=bn.running_mean, running_var=bn.running_var,
                     nbt=bn.num_batches_tracked)
 
-    def make_spec(self, key, conv: nn.Module, bn, act, ks, stride, eps=BN2D_EPS, mom=BN2D_MOM, name=""):
+    def make_spec(self, key, conv: nn.Module, bn, act, ks, stride, eps=BN2D_EPS, mom=BN2D_MOM, name="", ld=None):
         sp = self.specs.get(key)
         if sp is not None and sp.weight.data_ptr() == conv.weight.data.data_ptr() and (sp.bn is None) == (bn is None):
             return sp
         w = conv.weight.data
-        w2 = w.reshape(w.shape[0], w.shape[1], ks, ks) if w.dim() != 4 or w.shape[2] != ks else w
+        w2 = w if ld is not None else (w.reshape(w.shape[0], w.shape[1], ks, ks) if w.dim() != 4 or w.shape[2] != ks else w)
         sp = ConvSpec(name, w2, None if conv.bias is None else conv.bias.data, None if bn is None else self._bn_dict(bn), ks,
                       stride, act, eps, mom)
+        sp.ld = ld
         sp.gweight = self.gviews.get(id(conv.weight))
         sp.gbias = None if conv.bias is None else self.gviews.get(id(conv.bias))
         if bn is not None:
@@ -131,6 +132,10 @@ class Runtime:
     def spec(self, m):
         """ConvSpec of a ``Conv`` module (fused or not)."""
         return self.specs[id(m)]
+
+    def ldconv(self, m, x, out=None):
+        sp_p, sp_c = self.specs[(id(m), "p_conv")], self.specs[(id(m), "conv", x.C)]
+        return self.eng.ldconv(sp_p, sp_c, m._pn_i32, m.num_param, m.stride, x, out)
 
     def pack_all(self, transposed=True):
         """Refresh every MFMA weight pack from the fp32 masters (recorded at the start of each training step)."""

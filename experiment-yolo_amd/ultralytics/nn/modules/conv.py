@@ -100,5 +100,13 @@ class LDConv(HipModule):
         s = self.stride
         return (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
 
+    def _build_specs(self, rt):
+        inc = self.p_conv.in_channels
+        cphys = (inc + 7) // 8 * 8
+        rt.make_spec((id(self), "p_conv"), self.p_conv, None, DY_ACT_NONE, 3, self.stride, name="LDConv.p_conv")
+        rt.make_spec((id(self), "conv", cphys), self.conv[0], self.conv[1], DY_ACT_SILU, 1, 1, name="LDConv.conv",
+                     ld=(self.num_param, cphys, inc))
+        self.__dict__["_pn_i32"] = self.p_n.reshape(-1).to(torch.int32).to(rt.eng.device).contiguous()
+
     def forward_act(self, x, out=None):
         return self.rt.ldconv(self, x, out)

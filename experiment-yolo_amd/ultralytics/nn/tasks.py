@@ -194,6 +194,12 @@ class BaseModel(HipModule):
             ys.append(x if m.i in self.save else None)
         return x
 
+    def _export(self, rt, y):
+        from .modules.head import HeadOut
+        if isinstance(y, HeadOut):
+            return self.model[-1]._export(rt, y)
+        return super()._export(rt, y)
+
     def fuse(self, verbose=True):
         """Fold BatchNorm into every ``Conv`` (reference tasks.py:168-195, utils/torch_utils.py:171-198).  LDConv's inner BN
         and ScalSeq's BatchNorm3d are left alone, as in the reference."""

@@ -1,0 +1,127 @@
+"""Post-processing ops (drop-in for the detection part of reference utils/ops.py) issued as HIP kernels."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ..hip import check, lib
+
+__all__ = ("non_max_suppression", "soft_nms", "decode_predictions", "xywh2xyxy", "xyxy2xywh", "make_divisible")
+
+
+def make_divisible(x, divisor):
+    import math
+    if isinstance(divisor, torch.Tensor):
+        divisor = int(divisor.max())
+    return math.ceil(x / divisor) * divisor
+
+
+def xywh2xyxy(x):
+    """(x, y, w, h) -> (x1, y1, x2, y2) (reference utils/ops.py:527-546); plain tensor plumbing for callers."""
+    y = torch.empty_like(x)
+    dw, dh = x[..., 2] / 2, x[..., 3] / 2
+    y[..., 0], y[..., 1] = x[..., 0] - dw, x[..., 1] - dh
+    y[..., 2], y[..., 3] = x[..., 0] + dw, x[..., 1] + dh
+    return y
+
+
+def xyxy2xywh(x):
+    y = torch.empty_like(x)
+    y[..., 0], y[..., 1] = (x[..., 0] + x[..., 2]) / 2, (x[..., 1] + x[..., 3]) / 2
+    y[..., 2], y[..., 3] = x[..., 2] - x[..., 0], x[..., 3] - x[..., 1]
+    return y
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def decode_predictions(ho):
+    """Detect inference path (reference nn/modules/head.py:50-74): HeadOut -> y (B, 4+nc, A) fp32."""
+    L = lib()
+    nl, dev = len(ho.box), ho.box[0].device
+    B = ho.box[0].shape[0]
+    A = sum(b.shape[1] * b.shape[2] for b in ho.box)
+    y = torch.empty((B, 4 + ho.nc, A), dtype=torch.float32, device=dev)
+    PP = C.c_void_p * nl
+    box, cls = PP(*[b.data_ptr() for b in ho.box]), PP(*[c.data_ptr() for c in ho.cls])
+    H = (C.c_int * nl)(*[b.shape[1] for b in ho.box])
+    W = (C.c_int * nl)(*[b.shape[2] for b in ho.box])
+    st = (C.c_float * nl)(*[float(s) for s in ho.strides])
+    check(L.dy_decode_predictions(box, cls, H, W, st, nl, B, ho.nc, ho.cls[0].shape[-1], y.data_ptr(), _stream(dev)),
+          "dy_decode_predictions")
+    return y
+
+
+def soft_nms(bboxes, scores, iou_thresh=0.5, sigma=0.5, score_threshold=0.25):
+    """Gaussian soft-NMS with the reference's exact sequential semantics (utils/ops.py:260-290).  ``scores`` is decayed
+    IN PLACE; returns the kept indices as a CPU int64 tensor, like the reference's ``torch.LongTensor(keep)``."""
+    if bboxes.device.type != "cuda":
+        raise RuntimeError("soft_nms: HIP path only (no CPU fallback)")
+    n, dev = scores.shape[0], bboxes.device
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64)
+    b = bboxes.reshape(n, 4).float().contiguous()
+    s = scores if (scores.dtype == torch.float32 and scores.is_contiguous()) else scores.float().contiguous()
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    oa, ob, keep = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
+    nk = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().dy_soft_nms(b.data_ptr(), s.data_ptr(), 0, cnt.data_ptr(), oa.data_ptr(), ob.data_ptr(), keep.data_ptr(),
+                            nk.data_ptr(), 1, n, float(iou_thresh), float(sigma), float(score_threshold), 0.0, _stream(dev)),
+          "dy_soft_nms")
+    if s is not scores:
+        scores.copy_(s)
+    return keep[: int(nk.item())].long().cpu()
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        labels=(), max_det=300, nc=0, max_time_img=0.05, max_nms=30000, max_wh=7680, rotated=False):
+    """Reference utils/ops.py:292-427 for detection outputs (no masks / apriori labels / rotated boxes).
+
+    prediction: (B, 4+nc, A) [xywh, class scores] or the (y, feats) tuple of an eval forward.  Returns a list of (k, 6)
+    tensors [x1, y1, x2, y2, conf, cls] on the prediction's device.  Unlike the reference the input is not modified and
+    there is no wall-clock time limit (a nondeterminism source)."""
+    assert 0 <= conf_thres <= 1 and 0 <= iou_thres <= 1
+    if isinstance(prediction, (list, tuple)):
+        prediction = prediction[0]
+    if labels or rotated:
+        raise NotImplementedError("apriori labels / rotated boxes are outside the DEAL-YOLO hot path")
+    if prediction.device.type != "cuda":
+        raise RuntimeError("non_max_suppression: HIP path only (no CPU fallback)")
+    pred = prediction.float().contiguous()
+    B, no, A = pred.shape
+    nc = nc or (no - 4)
+    if no != 4 + nc:
+        raise NotImplementedError("mask coefficients are outside the hot path")
+    dev = pred.device
+    multi_label = bool(multi_label) and nc > 1
+    cap = A * (nc if multi_label else 1)
+    cbox = torch.empty((B, cap, 4), dtype=torch.float32, device=dev)
+    csc = torch.empty((B, cap), dtype=torch.float32, device=dev)
+    ccl = torch.empty((B, cap), dtype=torch.float32, device=dev)
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    cls_t = torch.tensor(list(classes), dtype=torch.int32, device=dev) if classes is not None else None
+    L, st = lib(), _stream(dev)
+    check(L.dy_nms_candidates(pred.data_ptr(), B, nc, A, float(conf_thres), int(multi_label), 0 if cls_t is None else cls_t.data_ptr(),
+                              0 if cls_t is None else cls_t.numel(), cbox.data_ptr(), csc.data_ptr(), ccl.data_ptr(), cnt.data_ptr(), cap, st),
+          "dy_nms_candidates")
+    counts = cnt.cpu()
+    if int(counts.max()) > max_nms:  # utils/ops.py:395-396: keep the max_nms most confident, in descending order
+        for b in range(B):
+            n = int(counts[b])
+            if n > max_nms:
+                idx = csc[b, :n].argsort(descending=True)[:max_nms]
+                cbox[b, :max_nms], csc[b, :max_nms], ccl[b, :max_nms] = cbox[b, idx], csc[b, idx], ccl[b, idx]
+                cnt[b] = max_nms
+        counts = cnt.cpu()
+    oa, ob, keep = (torch.empty((B, cap), dtype=torch.int32, device=dev) for _ in range(3))
+    nk = torch.zeros(B, dtype=torch.int32, device=dev)
+    check(L.dy_soft_nms(cbox.data_ptr(), csc.data_ptr(), ccl.data_ptr(), cnt.data_ptr(), oa.data_ptr(), ob.data_ptr(), keep.data_ptr(),
+                        nk.data_ptr(), B, cap, float(iou_thres), 0.5, 0.25, 0.0 if agnostic else float(max_wh), st), "dy_soft_nms")
+    nks = nk.cpu()
+    out = []
+    for b in range(B):
+        i = keep[b, : min(int(nks[b]), max_det)].long()
+        out.append(torch.cat((cbox[b, i], csc[b, i, None], ccl[b, i, None]), 1))
+    return out

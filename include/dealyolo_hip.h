@@ -67,6 +67,21 @@ int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int strid
 int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
                   int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream);
 
+/* ---- LDConv, nn/modules/conv.py:350-503: sampling (offset -> 4-corner bilinear gather, :366-410, :456-489) writes
+ *      x_off[pix][n*C + c]; the (N,1) column conv (:354) then is a 1x1 conv with K = N*C whose weights are packed /
+ *      whose weight gradient is unpacked by the *_ld variants (master layout (cout, cin, N, 1)). ------------------- */
+int dy_ldconv_sample(const void* x, int ldx, const float* off, int ldoff, const int* pn, void* xo, int ldxo, int n, int H,
+                     int W, int h, int w, int C, int Np, int stride, hipStream_t stream);
+/* dx32: (n,H,W,C) fp32 scatter accumulator, zeroed by the caller (NULL: skip); doff: fp16 (n,h,w,lddoff), ch [0,2Np) */
+int dy_ldconv_sample_backward(const void* x, int ldx, const float* off, int ldoff, const int* pn, const void* dxo,
+                              int lddxo, float* dx32, void* doff, int lddoff, int n, int H, int W, int h, int w, int C,
+                              int Np, int stride, hipStream_t stream);
+int dy_f32_to_f16_add(const float* src, void* dst, int ld, long npix, int C, int accumulate, hipStream_t stream);
+int dy_pack_weights_ld(const float* w, void* out, int cout, int cin, int ld_taps, int ld_cphys, int transposed,
+                       hipStream_t stream);
+int dy_conv_wgrad_ld(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
+                     int cout, int ld_cin, int ld_taps, int ld_cphys, int accumulate, hipStream_t stream);
+
 /* ---- nn.BatchNorm2d / BatchNorm3d (training statistics) + SiLU / LeakyReLU, nn/modules/conv.py:49-55,
  *      nn/extra_modules/block.py:3440-3441, utils/torch_utils.py:347-349, and their autograd backward. ------------- */
 /* coef: [4][C] = scale, shift, mean, invstd.  Up to three weighted partial sets (ScalSeq: three resolutions). */
@@ -138,6 +153,19 @@ size_t dy_loss_workspace_bytes(int B, int A, int nmax);
  * (B,A f32) inside the workspace after a call -- used by the parity tests */
 int dy_loss_workspace_layout(int B, int A, int nmax, size_t* off_pred_box, size_t* off_asg_gt, size_t* off_tscore);
 int dy_detection_loss(const DyLossArgs* args, hipStream_t stream);
+
+/* ---- Detect inference decode nn/modules/head.py:50-74 (+ DFL nn/modules/block.py:52-55, dist2bbox utils/tal.py:310-318)
+ *      -> y (B, 4+nc, A) fp32 [xywh pixels, sigmoid class scores] ------------------------------------------------- */
+int dy_decode_predictions(const float* const* box, const float* const* cls, const int* H, const int* W,
+                          const float* stride, int nl, int B, int nc, int ncp, float* y, hipStream_t stream);
+/* ---- ops.non_max_suppression utils/ops.py:292-427: candidate extraction (:344-392, order-preserving) ... */
+int dy_nms_candidates(const float* pred, int B, int nc, int A, float conf, int multi_label, const int* classes,
+                      int n_classes, float* cbox, float* cscore, float* ccls, int* ccount, int cap, hipStream_t stream);
+/* ---- ... and ops.soft_nms utils/ops.py:260-290 with bbox_iou_for_nms :162-199 (sequential semantics kept; scores are
+ *      decayed in place; keep/nkeep receive the kept candidate indices per image) ---------------------------------- */
+int dy_soft_nms(const float* boxes, float* scores, const float* cls, const int* count, int* order_a, int* order_b,
+                int* keep, int* nkeep, int B, int cap, float iou_thr, float sigma, float score_thr, float class_offset,
+                hipStream_t stream);
 
 /* ---- BaseTrainer.optimizer_step engine/trainer.py:949-957 + build_optimizer groups :1146-1174 + ModelEMA.update
  *      utils/torch_utils.py:447-458 + GradScaler policy, over flat fp32 buffers. ------------------------------------ */

@@ -9,11 +9,11 @@ import torch
 
 from conftest import CFG_DIR
 from golden.cases import MODES
-from gpu_util import relerr
+from gpu_util import l2err, relerr
 from oracle import graph as og
 
 pytestmark = pytest.mark.gpu
-MODELS = ["yolov8n-ASF-P2P2"]
+MODELS = ["yolov8n-ASF-P2P2", "yolov8n-LD-P2"]
 
 
 def _build(name, mi):
@@ -36,16 +36,17 @@ def test_model_step_vs_golden(golden, mi, name, mode):
     plan.forward_backward(batch)
     torch.cuda.synchronize()
     ho = plan.ho
+    ld = "LD" in name  # LDConv floors its sampling coordinates: an fp16 rounding can move a sample to the next pixel
     for l, f in enumerate(ho.as_reference_list()):
-        e = relerr(f.float(), G.t(f"{name}/feat{l}"))
-        print(f"feat{l} relerr {e:.2e}")
-        assert e < 3e-2
+        e, e2 = relerr(f.float(), G.t(f"{name}/feat{l}")), l2err(f.float(), G.t(f"{name}/feat{l}"))
+        print(f"feat{l} relerr {e:.2e} l2err {e2:.2e}")
+        assert (e2 < 5e-2) if ld else (e < 3e-2)
     s = plan.crit.scalars.cpu()
     ref_items = G.t(f"{name}/{mode}/items")
     print("items", s[5:8].tolist(), ref_items.tolist())
     # fp16 activations perturb the head logits by ~1e-3..1e-2 relative; the averaged losses agree to better than 5e-3
-    assert relerr(s[5:8], ref_items) < 5e-3
-    assert abs(float(s[8]) - float(G[f"{name}/{mode}/loss"])) < 5e-3 * float(G[f"{name}/{mode}/loss"])
+    assert relerr(s[5:8], ref_items) < (2e-2 if ld else 5e-3)
+    assert abs(float(s[8]) - float(G[f"{name}/{mode}/loss"])) < (2e-2 if ld else 5e-3) * float(G[f"{name}/{mode}/loss"])
     names = list(G[f"{name}/{mode}/grad_names"])
     params = dict(m.named_parameters())
     scale = float(plan.state[0])
@@ -53,10 +54,10 @@ def test_model_step_vs_golden(golden, mi, name, mode):
     ref = G.t(f"{name}/{mode}/grad_l2")
     rel = ((l2 - ref).abs() / (ref.abs() + 1e-3 * ref.abs().max())).numpy()
     print("grad-l2 rel err: median %.2e max %.2e (%s)" % (np.median(rel), rel.max(), names[int(rel.argmax())]))
-    assert np.median(rel) < 2e-2 and rel.max() < 0.15
+    assert np.median(rel) < (6e-2 if ld else 2e-2) and rel.max() < (0.5 if ld else 0.15)
     if mode == "ciou":
         first = params[names[0]].grad.float().cpu() / scale
-        assert relerr(first, G.t(f"{name}/{mode}/grad_first")) < 5e-2
+        assert (l2err if ld else relerr)(first, G.t(f"{name}/{mode}/grad_first")) < (0.15 if ld else 5e-2)
         sd = m.state_dict()
         rm = list(G[f"{name}/run_mean_names"])
         assert relerr(torch.stack([sd[k].sum() for k in rm]).cpu(), G.t(f"{name}/run_mean_sum")) < 5e-3

@@ -12,8 +12,10 @@ pytestmark = pytest.mark.gpu
 
 def _make(name, layer):
     from ultralytics.nn.extra_modules.block import Add, ScalSeq
-    from ultralytics.nn.modules import SPPF, C2f, Conv
+    from ultralytics.nn.modules import SPPF, C2f, Conv, LDConv
     a = layer.args
+    if layer.kind == "LDConv":
+        return LDConv(layer.cin, layer.cout, a["N"], a["s"])
     if layer.kind == "Conv":
         return Conv(layer.cin, layer.cout, a["k"], a["s"])
     if layer.kind == "C2f":
@@ -27,9 +29,12 @@ def _make(name, layer):
     raise KeyError(name)
 
 
-CASES = {k: v for k, v in module_cases().items() if v[0].kind in ("Conv", "C2f", "SPPF", "ScalSeq", "Add")}
+CASES = {k: v for k, v in module_cases().items() if v[0].kind in ("Conv", "C2f", "SPPF", "ScalSeq", "Add", "LDConv")
+         and k not in ("ldconv_n5s1", "ldconv_n1s1")}
+# excluded: N=5 on 8 channels (K=40) and an 8-channel output -- BatchNorm'd conv outputs must be multiples of 16 channels
+# on the HIP path (every width of the supported YAMLs is); the oracle covers both cases on CPU.
 TOL = {"Conv": (3e-3, 6e-3, 4e-3), "C2f": (1.5e-2, 3e-2, 3e-2), "SPPF": (8e-3, 2e-2, 2e-2), "ScalSeq": (1e-2, 3e-2, 8e-2),
-       "Add": (2e-3, 2e-3, 1)}
+       "Add": (2e-3, 2e-3, 1), "LDConv": (8e-3, 3e-2, 6e-2)}
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -44,7 +49,7 @@ def test_module_vs_golden(golden, name):
     ty, tx, tp = TOL[layer.kind]
     # max-type modules (SPPF pooling, ScalSeq's max over scales): an fp16 rounding can flip an arg-max at isolated
     # positions and re-route that position's gradient, so gradients are compared in the L2 sense there
-    err = l2err if layer.kind in ("SPPF", "ScalSeq") else relerr
+    err = l2err if layer.kind in ("SPPF", "ScalSeq", "LDConv") else relerr  # LDConv: floor() flips at integer crossings
     assert relerr(y, G.t(f"{name}/y")) < ty, "forward"
     for j, gx in enumerate(gxs):
         if gx is not None:

@@ -1,0 +1,60 @@
+"""-m gpu: decode + soft-NMS kernels against the reference-generated fixtures tests/golden/nms.npz.  Kept indices must be
+bit-exact; decayed scores may differ by one fp32 ulp (device exp vs the host's vectorised expf)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_soft_nms_cases(golden):
+    from ultralytics.utils.ops import soft_nms
+    G = golden("nms")
+    names = sorted({k.split("/")[1] for k in G.keys("soft/")})
+    for n in names:
+        boxes = G.t(f"soft/{n}/boxes").view(-1, 4).cuda()
+        scores = G.t(f"soft/{n}/scores_in").clone().cuda()
+        keep = soft_nms(boxes, scores, float(G[f"soft/{n}/thr"]))
+        assert keep.tolist() == G[f"soft/{n}/keep"].tolist(), n
+        ref = G.t(f"soft/{n}/scores_out")
+        assert torch.allclose(scores.cpu(), ref, rtol=3e-7, atol=0), n
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("predict", dict(conf_thres=0.25, iou_thres=0.7, max_det=300)),
+    ("val", dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300)),
+    ("agnostic", dict(conf_thres=0.25, iou_thres=0.45, agnostic=True, max_det=300)),
+    ("classes", dict(conf_thres=0.2, iou_thres=0.6, classes=[1, 4], max_det=20)),
+])
+def test_nms_full(golden, tag, kw):
+    from ultralytics.utils.ops import non_max_suppression
+    G = golden("nms")
+    out = non_max_suppression(G.t("nms/pred").cuda(), **kw)
+    for i, o in enumerate(out):
+        ref = G.t(f"nms/{tag}/img{i}")
+        assert o.shape == ref.shape, (tag, i, o.shape, ref.shape)
+        assert torch.equal(o[:, :4].cpu(), ref[:, :4]) and torch.equal(o[:, 5].cpu(), ref[:, 5]), (tag, i)
+        assert torch.allclose(o[:, 4].cpu(), ref[:, 4], rtol=3e-7, atol=0)
+
+
+def test_decode_and_eval_paths(golden):
+    """Eval forward of DEAL-YOLO-N: unfused BN (running statistics) and fused (BN folded) against the reference."""
+    import os
+    from conftest import CFG_DIR
+    from gpu_util import relerr
+    from oracle import graph as og
+    from ultralytics.nn.tasks import DetectionModel
+    G = golden("models")
+    name = "yolov8n-ASF-P2P2"
+    m = DetectionModel(os.path.join(CFG_DIR, name + ".yaml"), ch=3, verbose=False)
+    g = og.build_graph(og.load_yaml(os.path.join(CFG_DIR, name + ".yaml")))
+    m.load_state_dict(og.fill_state(og.state_layout(g), 7), strict=True)
+    m.cuda().eval()
+    y, feats = m(G.t(f"{name}/img").cuda())
+    ref = G.t(f"{name}/y_eval")
+    assert y.shape == ref.shape
+    assert relerr(y[:, :4].cpu(), ref[:, :4]) < 2e-2 and relerr(y[:, 4:].cpu(), ref[:, 4:]) < 2e-2
+    m.fuse()
+    yf, _ = m(G.t(f"{name}/img").cuda())
+    reff = G.t(f"{name}/y_eval_fused")
+    assert relerr(yf[:, :4].cpu(), reff[:, :4]) < 2e-2 and relerr(yf[:, 4:].cpu(), reff[:, 4:]) < 2e-2
+    assert sum(p.numel() for p in m.parameters()) == int(G[f"{name}/n_params_fused"])
