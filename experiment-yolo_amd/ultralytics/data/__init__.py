@@ -1,0 +1,23 @@
+"""Batch sources in the dataloader's batch-dict format (reference data/dataset.py:207-224).  The real CPU data pipeline
+(YOLO-format reader, mosaic/HSV/affine) is out of scope; this synthetic source follows the
+recipe of SURVEY.md section 8(d)."""
+import numpy as np
+import torch
+
+
+class SyntheticDetection:
+    def __init__(self, n_batches, batch, imgsz=640, nc=6, boxes_per_image=8, seed=1, wh=(0.01, 0.09), device="cpu"):
+        self.n, self.B, self.s, self.nc, self.k, self.seed, self.wh, self.device = n_batches, batch, imgsz, nc, boxes_per_image, seed, wh, device
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for i in range(self.n):
+            rng = np.random.default_rng(self.seed * 100003 + i)
+            n = self.B * self.k
+            yield {k: v.to(self.device) for k, v in dict(
+                img=torch.from_numpy(rng.random((self.B, 3, self.s, self.s), dtype=np.float32)),
+                batch_idx=torch.arange(self.B).repeat_interleave(self.k).float(),
+                cls=torch.from_numpy(rng.integers(0, self.nc, (n, 1)).astype(np.float32)),
+                bboxes=torch.from_numpy(np.concatenate([rng.random((n, 2)) * 0.8 + 0.1, rng.random((n, 2)) * (self.wh[1] - self.wh[0]) + self.wh[0]], 1).astype(np.float32))).items()}

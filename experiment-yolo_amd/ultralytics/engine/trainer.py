@@ -1,0 +1,121 @@
+"""Training loop of the hot path (drop-in for the step semantics of reference engine/trainer.py:595-957, 1115-1180):
+warm-up interpolation of lr / momentum / accumulate, linear | cosine LR, parameter groups, global-norm clip 10, SGD-nesterov
+| Adam(W) ('auto' rule), EMA, one process per GPU with a single RCCL all-reduce per step.  The batch source is any iterable
+of the dataloader's batch dicts (img, batch_idx, cls, bboxes; reference data/dataset.py:207-224): the CPU data pipeline
+itself is out of scope."""
+from __future__ import annotations
+
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..cfg import get_cfg
+from ..hip.train import StepPlan
+from ..utils import LOGGER, RANK
+from ..utils.torch_utils import ModelEMA, init_seeds, select_device
+
+
+class DetectionTrainer:
+    def __init__(self, model, cfg=None, overrides=None):
+        self.args = get_cfg(cfg or {}, overrides) if cfg else get_cfg(overrides=overrides)
+        self.model = model
+        self.world_size = int(os.environ.get("WORLD_SIZE", 1))
+        self.rank = int(os.environ.get("RANK", 0))
+        init_seeds(self.args.seed + 1 + (RANK if RANK >= 0 else -1) + 1, self.args.deterministic)
+        self.device = select_device(self.args.device)
+        self.plan = self.ema = None
+        self.lf = None
+
+    # ---- reference build_optimizer 'auto' rule (engine/trainer.py:1133-1144)
+    def _optimizer_choice(self, iterations, nc):
+        name, lr, mom = self.args.optimizer, self.args.lr0, self.args.momentum
+        if name == "auto":
+            lr_fit = round(0.002 * 5 / (4 + nc), 6)
+            name, lr, mom = ("SGD", 0.01, 0.9) if iterations > 10000 else ("AdamW", lr_fit, 0.9)
+            self.args.warmup_bias_lr = 0.0
+        if name not in ("SGD", "Adam", "AdamW"):
+            raise NotImplementedError(f"optimizer '{name}' is not on the HIP path (SGD, Adam, AdamW, auto)")
+        return name, lr, mom
+
+    def setup(self, batches_per_epoch, batch_size, imgsz):
+        a = self.args
+        if self.world_size > 1 and not dist.is_initialized():
+            torch.cuda.set_device(self.device)
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world_size, device_id=self.device)
+        self.model.to(self.device).train()
+        self.model.args = a
+        for k, v in self.model.named_parameters():  # always freeze .dfl (engine/trainer.py:670)
+            v.requires_grad = ".dfl" not in k
+        global_bs = batch_size * self.world_size
+        self.accumulate = max(round(a.nbs / global_bs), 1)
+        self.wd = a.weight_decay * global_bs * self.accumulate / a.nbs
+        iterations = math.ceil(batches_per_epoch * batch_size / max(global_bs, a.nbs)) * a.epochs
+        name, self.lr0, self.momentum = self._optimizer_choice(iterations, self.model.model[-1].nc)
+        self.plan = StepPlan(self.model, batch_size, imgsz, nmax=getattr(a, "nmax", 16) or 16, optimizer=name, world_size=self.world_size,
+                             use_graph=bool(a.hipgraph), init_scale=float(a.loss_scale) if a.amp else 1.0)
+        bl = self.plan.crit.bbox_loss
+        bl.use_wiseiou, bl.nwd_loss, bl.iou_ratio = bool(a.wiou), bool(a.nwd), float(a.iou_ratio)
+        self.ema = ModelEMA(self.plan)
+        self.nb = batches_per_epoch
+        self.nw = max(round(a.warmup_epochs * self.nb), 100) if a.warmup_epochs > 0 else -1
+        if a.cos_lr:
+            self.lf = lambda x: max((1 - math.cos(x * math.pi / a.epochs)) / 2, 0) * (a.lrf - 1) + 1
+        else:
+            self.lf = lambda x: max(1 - x / a.epochs, 0) * (1.0 - a.lrf) + a.lrf
+        self.last_opt_step = -1
+
+    def train_step(self, batch, ni, epoch):
+        """One iteration of the hot loop (reference engine/trainer.py:780-815)."""
+        a, p = self.args, self.plan
+        lr = [self.lr0 * self.lf(epoch)] * 3
+        mom = self.momentum
+        acc = self.accumulate
+        if ni <= self.nw:
+            xi = [0, self.nw]
+            acc = max(1, int(np.interp(ni, xi, [1, a.nbs / (p.B * self.world_size)]).round()))
+            lr = [float(np.interp(ni, xi, [a.warmup_bias_lr if j == 0 else 0.0, self.lr0 * self.lf(epoch)])) for j in range(3)]
+            mom = float(np.interp(ni, xi, [a.warmup_momentum, self.momentum]))
+        p.set_hyper(lr, mom, [0.0, self.wd, 0.0])
+        p.sync_buffers()
+        p.forward_backward(batch)
+        if self.accumulate > 1 or acc > 1 or p._micro:
+            p.accumulate()
+        if ni - self.last_opt_step >= acc:
+            p.all_reduce()
+            p.optimizer_step()
+            self.last_opt_step = ni
+        return lr, mom
+
+    def train(self, loader, batch_size, imgsz, epochs=None, log_every=0):
+        """loader: re-iterable of batch dicts.  Returns the list of per-epoch mean loss items."""
+        a = self.args
+        if epochs is not None:
+            a.epochs = epochs
+        nb = len(loader)
+        self.setup(nb, batch_size, imgsz)
+        hist = []
+        for epoch in range(a.epochs):
+            t0, tloss = time.time(), None
+            for i, batch in enumerate(loader):
+                ni = i + nb * epoch
+                self.train_step(batch, ni, epoch)
+                if log_every and (i % log_every == 0):
+                    _, items = self.plan.loss_items()
+                    tloss = items if tloss is None else (tloss * i + items) / (i + 1)
+            torch.cuda.synchronize()
+            _, items = self.plan.loss_items()
+            hist.append(items if tloss is None else tloss)
+            if self.rank == 0:
+                LOGGER.info(f"epoch {epoch + 1}/{a.epochs}  box/cls/dfl {[round(float(x), 4) for x in hist[-1]]}  "
+                            f"{nb * batch_size * self.world_size / (time.time() - t0):.1f} img/s")
+        return hist
+
+    def save_model(self, path):
+        """state_dict checkpoint (model + EMA); whole-module pickles of the reference format are a section 8f item."""
+        torch.save({"model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                    "ema": {k: v.detach().cpu() for k, v in self.ema.state_dict().items()},
+                    "updates": self.plan.ema_updates, "train_args": vars(self.args), "yaml": self.model.yaml}, path)

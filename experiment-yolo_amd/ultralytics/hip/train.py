@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 
 from . import check
+from .dist import all_reduce_flat, broadcast_buffers
 from .engine import Recorder
 
 
@@ -106,8 +107,14 @@ class StepPlan:
 
     # ---- optimizer ----------------------------------------------------------------------------------------------
     def all_reduce(self):
+        """ONE RCCL all-reduce(SUM) over the flat fp32 gradient buffer (4 MB for DEAL-YOLO-N)."""
         if self.world_size > 1:
-            dist.all_reduce(self.rt.flat_g, op=dist.ReduceOp.SUM)
+            all_reduce_flat(self.gsum if self._micro else self.rt.flat_g, self.world_size)
+
+    def sync_buffers(self):
+        """DDP(broadcast_buffers=True) equivalent: rank 0's BN running statistics before the forward."""
+        if self.world_size > 1:
+            broadcast_buffers(self.rt.flat_b, 0)
 
     def accumulate(self):
         """Gradient accumulation across micro-batches (reference engine/trainer.py:812: step only every ``accumulate``

@@ -1,0 +1,53 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/dealyolo_hip.h declares (no compute
+calls -- there is no GPU here)."""
+import os
+import re
+import subprocess
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "dealyolo_hip.h")
+LIBDIR = os.path.join(ROOT, "experiment-yolo_amd", "csrc")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dy_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    subprocess.run(["make", "-C", LIBDIR, "-j8"], check=True, capture_output=True)
+    from ultralytics.hip import SIGNATURES, lib
+    L = lib()
+    decl = _declared()
+    assert len(decl) >= 30
+    for name in decl:
+        assert hasattr(L, name), f"{name} declared in dealyolo_hip.h but not exported"
+        assert name in SIGNATURES, f"{name} has no ctypes signature in ultralytics/hip/__init__.py"
+    assert sorted(SIGNATURES) == decl, set(SIGNATURES) ^ set(decl)
+    assert L.dy_abi_version() >= 1
+
+
+def test_geometry_helpers_run_on_host():
+    """Pure host-side planning helpers may be called without a GPU."""
+    import ctypes as C
+    from ultralytics.hip import lib
+    L = lib()
+    g = [C.c_int() for _ in range(8)]
+    assert L.dy_conv_geometry(64, 64, 3, 1, *[C.byref(x) for x in g]) == 0
+    cin_p, cout_p, cc, nch, mt, ng, kst, pe = [x.value for x in g]
+    assert (cin_p, cout_p, cc, nch, mt, ng, kst) == (64, 64, 64, 1, 4, 1, 18) and pe == 18 * 64 * 32
+    assert L.dy_conv_geometry(3, 16, 3, 2, *[C.byref(x) for x in g]) == 0 and g[0].value == 8
+    assert L.dy_conv_geometry(64, 64, 5, 1, *[C.byref(x) for x in g]) == -1  # unsupported kernel size -> DY_ERR_ARG
+    assert L.dy_loss_workspace_bytes(64, 33600, 8) > 64 * 33600 * 4 * 10
+
+
+def test_no_fallback_on_cpu():
+    """The product path fails loudly without a GPU instead of computing on the CPU."""
+    import pytest
+    import torch
+    from ultralytics.nn.modules import Conv
+    m = Conv(16, 16, 3)
+    with pytest.raises(RuntimeError, match="GPU only|no CPU fallback"):
+        m(torch.zeros(1, 16, 8, 8))

@@ -1,0 +1,67 @@
+"""CPU: host-side logic of the drop-in package -- YAML graph building, parameter naming/counts against the reference's
+(golden), optimizer grouping, Concat in-place planning, cfg loading.  No kernels are launched."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import CFG_DIR
+
+MODELS = ["yolov8n-ASF-P2P2", "yolov8n-LD-P2", "yolov8n-p2"]
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_state_dict_matches_reference(golden, name):
+    from ultralytics.nn.tasks import DetectionModel
+    G = golden("models")
+    m = DetectionModel(os.path.join(CFG_DIR, name + ".yaml"), verbose=False)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(G[f"{name}/keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(G[f"{name}/shapes"])
+    assert sum(p.numel() for p in m.parameters()) == int(G[f"{name}/n_params"])
+    assert m.stride.tolist() == G[f"{name}/stride"].tolist()
+    det = f"model.{len(m.model) - 1}"
+    got = torch.stack([sd[f"{det}.cv3.{l}.2.bias"] for l in range(len(m.stride))])
+    np.testing.assert_allclose(got.numpy(), G[f"{name}/init_cls_bias"], rtol=1e-6)
+    bn = [x for x in m.modules() if type(x) is torch.nn.BatchNorm2d]
+    assert all(b.eps == 1e-3 and b.momentum == 0.03 for b in bn)
+    bn3 = [x for x in m.modules() if type(x) is torch.nn.BatchNorm3d]
+    assert all(b.eps == 1e-5 and b.momentum == 0.1 for b in bn3)
+
+
+def test_scale_letter_and_missing_module():
+    from ultralytics.nn.tasks import DetectionModel, guess_model_scale, yaml_model_load
+    assert guess_model_scale("yolov8s-ASF-P2P2.yaml") == "s"
+    d = yaml_model_load(os.path.join(CFG_DIR, "yolov8s-ASF-P2P2.yaml"))
+    assert d["scale"] == "s"
+    ms = DetectionModel(d, verbose=False)
+    assert ms.model[0].conv.out_channels == 32  # width 0.5 * 64
+    d["backbone"][0][2] = "GhostConv"
+    with pytest.raises(NotImplementedError, match="outside the DEAL-YOLO hot path"):
+        DetectionModel(d, verbose=False)
+
+
+def test_concat_plan_is_in_place_for_deal_yolo():
+    from ultralytics.nn.tasks import DetectionModel
+    m = DetectionModel(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"), verbose=False)
+    plan = m._concat_plan()
+    # every Concat input of DEAL-YOLO-N is produced straight into the concat buffer: no copy kernels
+    assert plan == {10: (11, 0), 9: (11, 1), 15: (16, 0), 14: (16, 1), 18: (19, 0), 12: (19, 1), 21: (22, 0), 8: (22, 1)}
+
+
+def test_optimizer_groups_match_reference(golden):
+    """Flat layout = [bias | decayed weights | norm weights] with the reference's group sizes (trainer.npz)."""
+    from oracle.trainer import param_groups
+    from ultralytics.nn.tasks import DetectionModel
+    G = golden("trainer")
+    m = DetectionModel(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"), verbose=False)
+    norm = tuple(v for k, v in torch.nn.__dict__.items() if "Norm" in k and isinstance(v, type))
+    groups = ([], [], [])
+    for mn, mod in m.named_modules():
+        for pn, p in mod.named_parameters(recurse=False):
+            full = f"{mn}.{pn}"
+            groups[0 if "bias" in full else (2 if isinstance(mod, norm) else 1)].append(full)
+    assert [len(g) for g in groups] == G["SGD/group_sizes"].tolist()
+    ref = param_groups(m.state_dict().keys())
+    assert [sorted(g) for g in groups] == [sorted(g) for g in ref]

@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Entry script with the reference's shape (reference train.py:6-25): build from a model YAML, train.  The dataset is the
+synthetic COCO-format source because the CPU data pipeline is out of scope."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiment-yolo_amd"))
+from ultralytics import YOLO  # noqa: E402
+from ultralytics.data import SyntheticDetection  # noqa: E402
+
+if __name__ == "__main__":
+    model = YOLO("yolov8n-ASF-P2P2.yaml")
+    model.train(data=SyntheticDetection(n_batches=20, batch=64, imgsz=640), imgsz=640, epochs=2, batch=64, close_mosaic=10,
+                workers=8, device="0", optimizer="SGD", project="runs/train", name="exp")
