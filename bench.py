@@ -40,20 +40,38 @@ def synth_batch(seed, B, imgsz, nc, n_per=8):
                 bboxes=torch.from_numpy(np.concatenate([rng.random((n, 2)) * 0.8 + 0.1, rng.random((n, 2)) * 0.08 + 0.01], 1).astype(np.float32)))
 
 
+def host_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (the GPU box gives 16 per GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max") and txt[0] != "max":
+                n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            elif path.endswith("quota_us") and int(txt[0]) > 0:
+                n = min(n, max(1, int(int(txt[0]) / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))))
+        except Exception:
+            pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(imgsz, steps=6, warm=2, bs=2):
     """CPU oracle (port of the reference PyTorch CPU trainer step: forward + loss + autograd backward + SGD + EMA)."""
     from oracle import graph as og, trainer as otr
     g = og.build_graph(og.load_yaml(CFG))
     sd = og.default_init_state(g, 0)
     ts = otr.TrainState(g, sd, otr.Hyp(), batch_size=bs, nb=8)
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     t = []
     for i in range(warm + steps):
         batch = synth_batch(100 + i, bs, imgsz, g.nc)
         t0 = time.perf_counter()
         otr.train_step(ts, batch)
         t.append(time.perf_counter() - t0)
-    dt = float(np.median(t[warm:]))
+        print(f"[bench] cpu_baseline step {i + 1}/{warm + steps}: {t[-1]:.2f} s ({torch.get_num_threads()} threads)", file=sys.stderr, flush=True)
+        if sum(t) > 90:  # bounded sample: never let the reported baseline stall the run
+            break
+    dt = float(np.median(t[warm:] if len(t) > warm else t))
     return {"value": bs / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} steps of bs={bs} {imgsz}x{imgsz} after {warm} warm-up (median), fp32, oracle/trainer.py"}
 

@@ -537,42 +537,65 @@ struct PackArgs {
   int ld_taps, ld_cphys;  // LDConv column conv: reduction index n*ld_cphys + c maps to w[(o*cin + c)*ld_taps + n]
 };
 
-__global__ void pack_weights_kernel(PackArgs a) {
-  const int total = a.ngroups * a.nch * a.ksteps * 16 * a.mt * 32;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    int r = idx;
-    const int kk = r & 31;
-    r >>= 5;
-    const int m = r % (16 * a.mt);
-    r /= (16 * a.mt);
-    const int ks = r % a.ksteps;
-    r /= a.ksteps;
-    const int h = r % a.nch;
-    const int g = r / a.nch;
-    const int mt = m >> 4, i = m & 15, qq = i >> 2, rr = i & 3;
-    const int o = g * 16 * a.mt + qq * 4 * a.mt + mt * 4 + rr;  // GEMM row = conv output channel of this pass
-    const int flat = ks * 32 + kk;
-    const int tap = flat / a.cc, c = h * a.cc + (flat - tap * a.cc);
-    float v = 0.f;
-    const int ntap = a.ks * a.ks;
-    if (a.ld_taps) {  // ks == 1: `c` (forward) or `o` (transposed) runs over n*ld_cphys + channel
-      const int kidx = a.transposed ? o : c, oc = a.transposed ? c : o;
-      const int n = kidx / a.ld_cphys, ch = kidx - n * a.ld_cphys;
-      if (tap == 0 && n < a.ld_taps && ch < a.cin && oc < a.cout) v = a.w[((size_t)oc * a.cin + ch) * a.ld_taps + n];
-    } else if (tap < ntap) {
-      if (!a.transposed) {
-        if (o < a.cout && c < a.cin) {
-          v = a.w[((size_t)o * a.cin + c) * ntap + tap];
-          if (a.scale) v *= a.scale[o];
-        }
-      } else {  // pass output channel o = original Cin index, reduction channel c = original Cout index
-        if (o < a.cin && c < a.cout) {
-          v = a.w[((size_t)c * a.cin + o) * ntap + (ntap - 1 - tap)];
-          if (a.scale) v *= a.scale[c];
-        }
+static __device__ __forceinline__ void pack_one(const PackArgs& a, int idx) {
+  int r = idx;
+  const int kk = r & 31;
+  r >>= 5;
+  const int m = r % (16 * a.mt);
+  r /= (16 * a.mt);
+  const int ks = r % a.ksteps;
+  r /= a.ksteps;
+  const int h = r % a.nch;
+  const int g = r / a.nch;
+  const int mt = m >> 4, i = m & 15, qq = i >> 2, rr = i & 3;
+  const int o = g * 16 * a.mt + qq * 4 * a.mt + mt * 4 + rr;  // GEMM row = conv output channel of this pass
+  const int flat = ks * 32 + kk;
+  const int tap = flat / a.cc, c = h * a.cc + (flat - tap * a.cc);
+  float v = 0.f;
+  const int ntap = a.ks * a.ks;
+  if (a.ld_taps) {  // ks == 1: `c` (forward) or `o` (transposed) runs over n*ld_cphys + channel
+    const int kidx = a.transposed ? o : c, oc = a.transposed ? c : o;
+    const int n = kidx / a.ld_cphys, ch = kidx - n * a.ld_cphys;
+    if (tap == 0 && n < a.ld_taps && ch < a.cin && oc < a.cout) v = a.w[((size_t)oc * a.cin + ch) * a.ld_taps + n];
+  } else if (tap < ntap) {
+    if (!a.transposed) {
+      if (o < a.cout && c < a.cin) {
+        v = a.w[((size_t)o * a.cin + c) * ntap + tap];
+        if (a.scale) v *= a.scale[o];
+      }
+    } else {  // pass output channel o = original Cin index, reduction channel c = original Cout index
+      if (o < a.cin && c < a.cout) {
+        v = a.w[((size_t)c * a.cin + o) * ntap + (ntap - 1 - tap)];
+        if (a.scale) v *= a.scale[c];
       }
     }
-    a.out[idx] = (f16)v;
+  }
+  a.out[idx] = (f16)v;
+}
+
+__global__ void pack_weights_kernel(PackArgs a) {
+  const int total = a.ngroups * a.nch * a.ksteps * 16 * a.mt * 32;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) pack_one(a, idx);
+}
+
+// all packs of a model in ONE launch: descs[i].first_block is the exclusive prefix of per-descriptor block counts
+struct PackDesc {
+  PackArgs a;
+  int total, first_block;
+};
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDesc* descs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {  // last descriptor whose first_block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const PackDesc& d = descs[lo];
+  const int base = (blockIdx.x - d.first_block) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = base + k * 256 + threadIdx.x;
+    if (idx < d.total) pack_one(d.a, idx);
   }
 }
 
@@ -612,6 +635,36 @@ extern "C" int dy_pack_weights_ld(const float* w, void* out, int cout, int cin, 
   PackArgs a{w, nullptr, (f16*)out, cout, cin, 1, cc, nch, mt, ng, kst, transposed, ld_taps, ld_cphys};
   const int blocks = cdiv(pe, 256) < 1024 ? cdiv(pe, 256) : 1024;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// Fill one host-side descriptor (sizeof = dy_pack_desc_bytes()) for dy_pack_weights_batched; returns its block count.
+extern "C" int dy_pack_desc_bytes(void) { return (int)sizeof(PackDesc); }
+extern "C" int dy_pack_desc_fill(void* desc, const float* w, const float* scale, void* out, int cout, int cin, int ks,
+                                 int stride, int transposed, int ld_taps, int ld_cphys, int first_block) {
+  int cp, op, cc, nch, mt, ng, kst, pe;
+  int pin, pout;
+  if (ld_taps) {
+    const int keff = ld_taps * ld_cphys, coutp = (cout + 7) / 8 * 8;
+    pin = transposed ? coutp : keff;
+    pout = transposed ? keff : cout;
+    ks = 1;
+    stride = 1;
+  } else {
+    pin = transposed ? cout : cin;
+    pout = transposed ? cin : cout;
+  }
+  if (dy_conv_geometry(pin, pout, ks, transposed ? 1 : stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return DY_ERR_ARG;
+  PackDesc* d = reinterpret_cast<PackDesc*>(desc);
+  d->a = PackArgs{w, scale, (f16*)out, cout, cin, ks, cc, nch, mt, ng, kst, transposed, ld_taps, ld_cphys};
+  d->total = pe;
+  d->first_block = first_block;
+  return cdiv(pe, 1024);
+}
+extern "C" int dy_pack_weights_batched(const void* descs_device, int n, int total_blocks, hipStream_t stream) {
+  if (n <= 0 || total_blocks <= 0) return DY_ERR_ARG;
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, stream, (const PackDesc*)descs_device, n);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

@@ -69,7 +69,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int c = 0; c < CPW; ++c) acc[m][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  // ---- software pipeline: the next tile's X halo and dY tile are fetched into registers while the current tile is
+  // multiplied (one workgroup keeps ~30-60 KB of loads in flight under its MFMAs instead of idling on them)
+  constexpr int NGX = HHX * HWX * (CIN_C / 8), NGY = TH * TW * (COUT_C / 8);
+  constexpr int NPX = (NGX + 255) / 256, NPY = (NGY + 255) / 256;
+  uint4 pfx[NPX], pfy[NPY];
+  auto prefetch = [&](int tile) {
     int n = 0, oy0 = 0, ox0 = 0;
     long pix0 = 0;
     if (FLAT) {
@@ -77,47 +82,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     } else {
       const int bx = tile % a.tiles_x;
       const int t2 = tile / a.tiles_x;
-      const int by = t2 % a.tiles_y;
       n = t2 / a.tiles_y;
-      oy0 = by * TH;
+      oy0 = (t2 % a.tiles_y) * TH;
       ox0 = bx * TW;
     }
-    // ---- stage X halo (this ci chunk) and dY tile (this co chunk); zero outside the image
-    for (int id = tid; id < HHX * HWX * (CIN_C / 8); id += 256) {
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int id = tid + i * 256;
       const int pixel = id / (CIN_C / 8), part = id - pixel * (CIN_C / 8);
       const f16* src = nullptr;
-      const bool cok = ci0 + part * 8 < a.cin_r8;
-      if (!cok) {
-      } else if (FLAT) {
-        const long gp = pix0 + pixel;
-        if (gp < a.npix) src = a.x + gp * a.ldx + ci0 + part * 8;
-      } else {
-        const int hy = pixel / HWX, hx = pixel - hy * HWX;
-        const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) src = a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.ldx + ci0 + part * 8;
+      if (id < NGX && ci0 + part * 8 < a.cin_r8) {
+        if (FLAT) {
+          const long gp = pix0 + pixel;
+          if (gp < a.npix) src = a.x + gp * a.ldx + ci0 + part * 8;
+        } else {
+          const int hy = pixel / HWX, hx = pixel - hy * HWX;
+          const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
+          if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) src = a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.ldx + ci0 + part * 8;
+        }
       }
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (src) v = *reinterpret_cast<const uint4*>(src);
-      *reinterpret_cast<uint4*>(sx + pixel * PSX + part * 16) = v;
+      pfx[i] = src ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
     }
-    for (int id = tid; id < TH * TW * (COUT_C / 8); id += 256) {
+#pragma unroll
+    for (int i = 0; i < NPY; ++i) {
+      const int id = tid + i * 256;
       const int pixel = id / (COUT_C / 8), part = id - pixel * (COUT_C / 8);
       const f16* src = nullptr;
-      const bool cok = co0 + part * 8 < a.cout_r8;
-      if (!cok) {
-      } else if (FLAT) {
-        const long gp = pix0 + pixel;
-        if (gp < a.npix) src = a.dy + gp * a.lddy + co0 + part * 8;
-      } else {
-        const int ty = pixel / TW, tx = pixel - ty * TW;
-        const int oy = oy0 + ty, ox = ox0 + tx;
-        if (oy < a.Ho && ox < a.Wo) src = a.dy + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.lddy + co0 + part * 8;
+      if (id < NGY && co0 + part * 8 < a.cout_r8) {
+        if (FLAT) {
+          const long gp = pix0 + pixel;
+          if (gp < a.npix) src = a.dy + gp * a.lddy + co0 + part * 8;
+        } else {
+          const int ty = pixel / TW, tx = pixel - ty * TW;
+          const int oy = oy0 + ty, ox = ox0 + tx;
+          if (oy < a.Ho && ox < a.Wo) src = a.dy + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.lddy + co0 + part * 8;
+        }
       }
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (src) v = *reinterpret_cast<const uint4*>(src);
-      *reinterpret_cast<uint4*>(sy + pixel * PSY + part * 16) = v;
+      pfy[i] = src ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) prefetch(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();  // previous tile's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int id = tid + i * 256;
+      if (id < NGX) *reinterpret_cast<uint4*>(sx + (id / (CIN_C / 8)) * PSX + (id % (CIN_C / 8)) * 16) = pfx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NPY; ++i) {
+      const int id = tid + i * 256;
+      if (id < NGY) *reinterpret_cast<uint4*>(sy + (id / (COUT_C / 8)) * PSY + (id % (COUT_C / 8)) * 16) = pfy[i];
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
 #pragma unroll
     for (int r = 0; r < TH; ++r) {  // one k-step = 32 consecutive output pixels of tile row r
       const int kpix = 8 * q + qq;  // first-read row of this lane inside the k-step
@@ -148,7 +168,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
         }
       }
     }
-    __syncthreads();
   }
 
   // ---- one slab per workgroup: [tap][cout_p][cin_p] fp32 (16 lanes -> 64 contiguous bytes)

@@ -200,17 +200,27 @@ __global__ __launch_bounds__(256) void decode_kernel(LossCtx c) {
   const int lane = threadIdx.x & 63, side = lane >> 4, bin = lane & 15;
   const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((long)gridDim.x * 256) >> 6;
   const long total = (long)c.B * c.A;
-  for (long ba = wave; ba < total; ba += nw) {
-    const int b = (int)(ba / c.A), a = (int)(ba - (long)b * c.A);
-    int l, iy, ix;
-    anchor_of(c, a, l, iy, ix);
-    const Level& L = c.lv[l];
-    const float logit = L.box[(((size_t)b * L.H + iy) * L.W + ix) * 64 + lane];
-    float pr;
-    const float e = softmax16_expect(logit, bin, pr);
-    const float anc = (side & 1) ? (iy + 0.5f) : (ix + 0.5f);
-    const float coord = side < 2 ? anc - e : anc + e;
-    if (bin == 0) c.pred_box[ba * 4 + side] = coord;
+  constexpr int U = 4;  // anchors per iteration: U independent 256-byte loads in flight per wave
+  for (long ba0 = wave * U; ba0 < total; ba0 += nw * U) {
+    float logit[U];
+    int iyv[U], ixv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long ba = ba0 + u < total ? ba0 + u : total - 1;
+      const int b = (int)(ba / c.A), a = (int)(ba - (long)b * c.A);
+      int l;
+      anchor_of(c, a, l, iyv[u], ixv[u]);
+      const Level& L = c.lv[l];
+      logit[u] = L.box[(((size_t)b * L.H + iyv[u]) * L.W + ixv[u]) * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float pr;
+      const float e = softmax16_expect(logit[u], bin, pr);
+      const float anc = (side & 1) ? (iyv[u] + 0.5f) : (ixv[u] + 0.5f);
+      const float coord = side < 2 ? anc - e : anc + e;
+      if (bin == 0 && ba0 + u < total) c.pred_box[(ba0 + u) * 4 + side] = coord;
+    }
   }
 }
 
@@ -509,17 +519,20 @@ __global__ __launch_bounds__(256) void box_loss_kernel(LossCtx c) {
   const long total = (long)c.B * c.A;
   const float tss = c.scal[1], gs = c.gscale[0], Bf = (float)c.B;
   float l_box = 0.f, l_dfl = 0.f;
-  for (long ba = wave; ba < total; ba += nw) {
+  for (long base = wave * 64; base < total; base += nw * 64) {
+   // one coalesced load tells the wave which of its 64 anchors are foreground (~1 %); only those are visited
+   const int jl = (base + lane < total) ? c.asg_gt[base + lane] : -1;
+   unsigned long long fgm = __ballot(jl >= 0);
+   while (fgm) {
+    const int bit = __ffsll((long long)fgm) - 1;
+    fgm &= fgm - 1;
+    const long ba = base + bit;
+    const int j = __shfl(jl, bit, 64);
     const int b = (int)(ba / c.A), a = (int)(ba - (long)b * c.A);
     int l, iy, ix;
     anchor_of(c, a, l, iy, ix);
     const Level& L = c.lv[l];
     const size_t off = (((size_t)b * L.H + iy) * L.W + ix) * 64 + lane;
-    const int j = c.asg_gt[ba];
-    if (j < 0) {
-      if (L.dbox) L.dbox[off] = (f16)0.f;
-      continue;
-    }
     const float logit = L.box[off];
     float pr;
     const float e = softmax16_expect(logit, bin, pr);
@@ -580,6 +593,7 @@ __global__ __launch_bounds__(256) void box_loss_kernel(LossCtx c) {
     if (L.dbox) L.dbox[off] = (f16)(glogit * gs);
     if (lane == 0) l_box += lb.v * kb;
     if (bin == 0) l_dfl += dfl_side * 0.25f * kb;
+   }
   }
   // lanes with bin==0 hold the four side terms of dfl; lane 0 holds box
   l_dfl = wave_sum(l_dfl);
@@ -712,6 +726,9 @@ extern "C" int dy_detection_loss(const DyLossArgs* d, hipStream_t stream) {
     n_cls += g;
   }
   c.partials = partB;
+  for (int l = 0; l < c.nl; ++l)  // background anchors get zero box-gradient: one memset instead of 2 M scattered stores
+    if (c.lv[l].dbox && hipMemsetAsync(c.lv[l].dbox, 0, (size_t)c.B * c.lv[l].H * c.lv[l].W * 64 * 2, stream) != hipSuccess)
+      return DY_ERR_LAUNCH;
   hipLaunchKernelGGL(box_loss_kernel, dim3(gridA), dim3(256), 0, stream, c);
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, stream, c, partB, gridA, partC, n_cls);
   DY_CHECK_LAUNCH();

@@ -36,6 +36,9 @@ SIGNATURES = {
     "dy_abi_version": (i32, []),
     "dy_conv_geometry": (i32, [i32, i32, i32, i32, ip, ip, ip, ip, ip, ip, ip, ip]),
     "dy_pack_weights": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dy_pack_desc_bytes": (i32, []),
+    "dy_pack_desc_fill": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32]),
+    "dy_pack_weights_batched": (i32, [vp, i32, i32, vp]),
     "dy_conv_forward": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, ip, vp]),
     "dy_conv_num_partials": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "dy_wgrad_workspace": (i32, [i32, i32, i32, i32, i32, i32, i32, ip, lp]),

@@ -138,9 +138,31 @@ class Runtime:
         return self.eng.ldconv(sp_p, sp_c, m._pn_i32, m.num_param, m.stride, x, out)
 
     def pack_all(self, transposed=True):
-        """Refresh every MFMA weight pack from the fp32 masters (recorded at the start of each training step)."""
-        for sp in self.specs.values():
-            self.eng.pack(sp, fold_scale=None, transposed=transposed)
+        """Refresh every MFMA weight pack from the fp32 masters in ONE launch (recorded at the start of each step)."""
+        import ctypes as C
+        if not self.specs:
+            return
+        key = (transposed, tuple(sp.weight.data_ptr() for sp in self.specs.values()))
+        cached = getattr(self, "_pack_tbl", None)
+        if cached is None or cached[0] != key:
+            L = self.eng.L
+            sz = L.dy_pack_desc_bytes()
+            n = len(self.specs) * (2 if transposed else 1)
+            host = (C.c_char * (sz * n))()
+            blocks, i = 0, 0
+            for sp in self.specs.values():
+                for tr in ((0, 1) if transposed else (0,)):
+                    ld = sp.ld or (0, 0, sp.weight.shape[1])
+                    nb = L.dy_pack_desc_fill(C.byref(host, i * sz), sp.weight.data_ptr(), 0, (sp.wpack_t if tr else sp.wpack).data_ptr(),
+                                             sp.cout, ld[2] if sp.ld else sp.weight.shape[1], sp.ks, sp.stride, tr, ld[0], ld[1], blocks)
+                    if nb < 0:
+                        raise RuntimeError(f"dy_pack_desc_fill failed for {sp.name}")
+                    blocks += nb
+                    i += 1
+            dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(self.eng.device)
+            self.eng.keep.append(dev)
+            self._pack_tbl = cached = (key, dev, n, blocks)
+        self.eng.call("dy_pack_weights_batched", cached[1].data_ptr(), cached[2], cached[3])
 
     def ensure_packed(self):
         """Eager (inference) path: re-pack when any master weight changed (torch version counters + explicit marks)."""

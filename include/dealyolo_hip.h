@@ -53,6 +53,12 @@ int dy_conv_geometry(int cin, int cout, int ks, int stride, int* cin_p, int* cou
  * transposed=1 builds the (Cout->Cin, flipped taps) pack consumed by the stride-1 input-gradient pass. */
 int dy_pack_weights(const float* w, const float* scale, void* out, int cout, int cin, int ks, int stride,
                     int transposed, hipStream_t stream);
+/* every pack of a model in ONE launch: fill host descriptors (dy_pack_desc_bytes() each, first_block = running sum of the
+ * returned block counts), copy them to the device once, then call dy_pack_weights_batched every step. */
+int dy_pack_desc_bytes(void);
+int dy_pack_desc_fill(void* desc, const float* w, const float* scale, void* out, int cout, int cin, int ks, int stride,
+                      int transposed, int ld_taps, int ld_cphys, int first_block);
+int dy_pack_weights_batched(const void* descs_device, int n, int total_blocks, hipStream_t stream);
 /* y[n,ho,wo,:cout] = conv(x)[...]; x: (n,h,w,cin) with cin a multiple of 8 (zero-padded channels).
  * dil=2: x is read as a zero-dilated map of size (2h,2w) -- the input gradient of a stride-2 conv; out_h/out_w (>0)
  * then give the extent of the forward input (2h or 2h-1), otherwise pass 0 to derive the output extent.
