@@ -93,10 +93,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    rehearsal = os.environ.get("DY_REHEARSE_ON_ONE_GPU") == "1"  # N ranks on one GPU over gloo: exercises the N>1 code path only
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ultralytics.hip.train import StepPlan
     from ultralytics.nn.tasks import DetectionModel
@@ -132,7 +138,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     ms = dt / a.steps * 1e3
@@ -142,8 +148,15 @@ def main():
     if rank == 0 and a.probe:
         roof = plan.probe_dominant_kernel(batch, reps=max(5, min(a.steps, 20)))
         if roof:
+            traffic = None
+            try:  # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/
+                tj = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")))
+                if tj.get("kernel") == roof["kernel"]:
+                    traffic = tj["traffic_bytes"]
+            except Exception:
+                pass
             roof = {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS,
-                    "traffic": None, "kernel": roof["kernel"], "avg_us": roof["us"], "bytes_per_launch": roof["bytes"]}
+                    "traffic": traffic, "kernel": roof["kernel"], "avg_us": roof["us"], "bytes_per_launch": roof["bytes"]}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cpu = cpu_baseline(a.imgsz)

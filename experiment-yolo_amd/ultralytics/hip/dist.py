@@ -11,17 +11,32 @@ import torch
 import torch.distributed as dist
 
 
+def _via_host(t):
+    """gloo rehearsal of the GPU path (several ranks sharing one GPU): gloo moves host memory."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def all_reduce_flat(flat_grad: torch.Tensor, world_size: int | None = None):
     """In-place SUM of the flat gradient buffer over all ranks (no-op for a single process)."""
     if dist.is_available() and dist.is_initialized() and (world_size or dist.get_world_size()) > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        if _via_host(flat_grad):
+            h = flat_grad.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            flat_grad.copy_(h)
+        else:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
 
 
 def broadcast_buffers(flat_buffers: torch.Tensor, src: int = 0):
     """DDP's per-forward buffer broadcast: rank ``src``'s BN running statistics win."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(flat_buffers, src=src)
+        if _via_host(flat_buffers):
+            h = flat_buffers.cpu()
+            dist.broadcast(h, src=src)
+            flat_buffers.copy_(h)
+        else:
+            dist.broadcast(flat_buffers, src=src)
     return flat_buffers
 
 
