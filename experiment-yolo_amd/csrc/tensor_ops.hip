@@ -451,3 +451,101 @@ extern "C" int dy_copy_slice(const void* x, int ldx, void* y, int ldy, long npix
 extern "C" int dy_fill_zero(void* p, size_t bytes, hipStream_t stream) {
   return hipMemsetAsync(p, 0, bytes, stream) == hipSuccess ? DY_OK : DY_ERR_LAUNCH;
 }
+
+// ---- Zoom_cat's fine-level branch (reference nn/extra_modules/block.py:3406-3412): adaptive_max_pool2d + adaptive_avg_pool2d
+// to exactly half resolution == 2x2 max + 2x2 mean.  Backward: the max routes to its first arg-max (row-major, as ATen),
+// the mean spreads 1/4.
+struct ZpArgs {
+  const f16* x;
+  f16* y;
+  const f16* dy;
+  f16* dx;
+  int ldx, ldy, lddy, lddx, C, N, H, W, accumulate;  // H, W: output (half) extent
+};
+__global__ __launch_bounds__(256) void zoom_pool_fwd_kernel(ZpArgs a) {
+  const int cpp = a.C >> 3;
+  const long total = (long)a.N * a.H * a.W * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int c0 = (int)(idx - pix * cpp) * 8;
+    const int ox = (int)(pix % a.W);
+    const long t = pix / a.W;
+    const int oy = (int)(t % a.H);
+    const long n = t / a.H;
+    float mx[8], sm[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long src = (n * 2 * a.H + 2 * oy + (i >> 1)) * 2 * a.W + 2 * ox + (i & 1);
+      const half8 v = *reinterpret_cast<const half8*>(a.x + src * a.ldx + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[j];
+        mx[j] = i == 0 ? f : fmaxf(mx[j], f);
+        sm[j] = i == 0 ? f : sm[j] + f;
+      }
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)((float)(f16)mx[j] + (float)(f16)(sm[j] * 0.25f));
+    *reinterpret_cast<half8*>(a.y + pix * a.ldy + c0) = o;
+  }
+}
+__global__ __launch_bounds__(256) void zoom_pool_bwd_kernel(ZpArgs a) {
+  const int cpp = a.C >> 3;
+  const long total = (long)a.N * a.H * a.W * cpp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long pix = idx / cpp;
+    const int c0 = (int)(idx - pix * cpp) * 8;
+    const int ox = (int)(pix % a.W);
+    const long t = pix / a.W;
+    const int oy = (int)(t % a.H);
+    const long n = t / a.H;
+    const half8 g = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0);
+    half8 v[4];
+    long src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      src[i] = (n * 2 * a.H + 2 * oy + (i >> 1)) * 2 * a.W + 2 * ox + (i & 1);
+      v[i] = *reinterpret_cast<const half8*>(a.x + src[i] * a.ldx + c0);
+    }
+    int am[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      am[j] = 0;
+      float best = (float)v[0][j];
+#pragma unroll
+      for (int i = 1; i < 4; ++i)
+        if ((float)v[i][j] > best) {
+          best = (float)v[i][j];
+          am[j] = i;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f16* d = a.dx + src[i] * a.lddx + c0;
+      half8 o;
+      if (a.accumulate) o = *reinterpret_cast<const half8*>(d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gi = (float)g[j] * (0.25f + (am[j] == i ? 1.f : 0.f));
+        o[j] = (f16)(gi + (a.accumulate ? (float)o[j] : 0.f));
+      }
+      *reinterpret_cast<half8*>(d) = o;
+    }
+  }
+}
+extern "C" int dy_zoom_pool(const void* x, int ldx, void* y, int ldy, int n, int h, int w, int C, hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (ldy & 7)) return DY_ERR_ALIGN;
+  ZpArgs a{(const f16*)x, (f16*)y, nullptr, nullptr, ldx, ldy, 0, 0, C, n, h, w, 0};
+  hipLaunchKernelGGL(zoom_pool_fwd_kernel, dim3(grid_for((long)n * h * w * (C >> 3))), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+extern "C" int dy_zoom_pool_backward(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int n, int h,
+                                     int w, int C, int accumulate, hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7)) return DY_ERR_ALIGN;
+  ZpArgs a{(const f16*)x, nullptr, (const f16*)dy, (f16*)dx, ldx, 0, lddy, lddx, C, n, h, w, accumulate};
+  hipLaunchKernelGGL(zoom_pool_bwd_kernel, dim3(grid_for((long)n * h * w * (C >> 3))), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}

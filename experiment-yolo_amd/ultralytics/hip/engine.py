@@ -440,6 +440,33 @@ class Engine:
             self.tape.append(bwd)
         return y
 
+    def zoom_cat(self, xs, out: Act | None = None):
+        """Zoom_cat (reference nn/extra_modules/block.py:3402-3412): [maxpool+avgpool of the fine map | middle map | 2x
+        nearest of the coarse map] written into one buffer (exact 2x pyramids only)."""
+        l, m, s = xs
+        assert l.H == 2 * m.H and l.W == 2 * m.W and m.H == 2 * s.H and m.W == 2 * s.W, "Zoom_cat needs exact 2x pyramids"
+        y = out if out is not None else self.new_act(m.N, m.H, m.W, l.C + m.C + s.C)
+        yl, ym, ys = y.sub(0, l.C), y.sub(l.C, m.C), y.sub(l.C + m.C, s.C)
+        self.call("dy_zoom_pool", l.ptr, l.ld, yl.ptr, yl.ld, l.N, m.H, m.W, l.C)
+        self.call("dy_copy_slice", m.ptr, m.ld, ym.ptr, ym.ld, m.npix, m.C)
+        self.call("dy_upsample2x", s.ptr, s.ld, ys.ptr, ys.ld, s.N, s.H, s.W, s.C, 0, 0)
+        if self.tape is not None:
+            def bwd():
+                if l.needs_grad:
+                    acc = l.grad_target()
+                    self.call("dy_zoom_pool_backward", l.ptr, l.ld, yl.gptr, yl.ld, l.gptr, l.ld, l.N, m.H, m.W, l.C, acc)
+                if m.needs_grad:
+                    acc = m.grad_target()
+                    if acc:
+                        self.call("dy_add", m.gptr, m.ld, ym.gptr, ym.ld, 0, 0, m.gptr, m.ld, m.npix, m.C)
+                    else:
+                        self.call("dy_copy_slice", ym.gptr, ym.ld, m.gptr, m.ld, m.npix, m.C)
+                if s.needs_grad:
+                    acc = s.grad_target()
+                    self.call("dy_upsample2x", ys.gptr, ys.ld, s.gptr, s.ld, s.N, s.H, s.W, s.C, 1, acc)
+            self.tape.append(bwd)
+        return y
+
     # ---- ScalSeq (reference nn/extra_modules/block.py:3426-3443) --------------------------------------------------
     def scalseq(self, conv3d: ConvSpec, bn3d, coef, bwdcoef, gbn, ps, out: Act | None = None):
         """ps = [p3 (full res), p4 (1/2), p5 (1/4)] already channel-matched.  conv3d: 1x1x1 conv with bias applied to

@@ -17,7 +17,7 @@ class Zoom_cat(HipModule):
     """cat(maxpool+avgpool of the fine map, middle map, nearest-upsampled coarse map) (reference :3402-3412)."""
 
     def forward_act(self, xs, out=None):
-        return self.rt.zoom_cat(xs, out)
+        return self.rt.eng.zoom_cat(list(xs), out)
 
 
 class ScalSeq(HipModule):

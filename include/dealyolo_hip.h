@@ -125,6 +125,10 @@ int dy_scalseq_tail_backward(const void* r0, int ld0, const void* r1, int ld1, c
                              int lddy, void* dr, int lddr, const float* coef, const float* bwdcoef, float* partials,
                              int max_partials, int n, int h, int w, int C, int level, int mode, int* nparts,
                              hipStream_t stream);
+/* Zoom_cat fine branch nn/extra_modules/block.py:3406-3412: 2x2 max + 2x2 mean to half resolution (h, w = output extent) */
+int dy_zoom_pool(const void* x, int ldx, void* y, int ldy, int n, int h, int w, int C, hipStream_t stream);
+int dy_zoom_pool_backward(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int n, int h, int w, int C,
+                          int accumulate, hipStream_t stream);
 int dy_copy_slice(const void* x, int ldx, void* y, int ldy, long npix, int C, hipStream_t stream);
 int dy_fill_zero(void* p, size_t bytes, hipStream_t stream);
 

