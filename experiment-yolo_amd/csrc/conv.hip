@@ -259,10 +259,11 @@ static __device__ __forceinline__ int swz(int pixel, int part) {
   return pixel * (CC * 2 + 16) + (part << 4);
 }
 
-template <int CC, int MT, int KS, int STRIDE, int TROWS>
-__global__ __launch_bounds__(512) void conv_mfma_wlds_kernel(ConvArgs a, int ntiles) {
+template <int CC, int MT, int KS, int STRIDE, int TROWS, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_mfma_wlds_kernel(ConvArgs a, int ntiles) {
   constexpr bool FLAT = (KS == 1);
-  constexpr int NW = 8;                                 // waves per workgroup
+  constexpr int NTHR = NW * 64;                         // NW waves per workgroup (8: two per SIMD; 4: one per SIMD, half the
+                                                        // A-fragment LDS traffic per MFMA because each wave owns 64 pixels)
   constexpr int NT = 2 * TROWS;                         // 16-pixel N-tiles per wave
   constexpr int TH = NW * TROWS, TW = 32;
   constexpr int HW_ = FLAT ? NW * NT * 16 : (TW - 1) * STRIDE + KS;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(512) void conv_mfma_wlds_kernel(ConvArgs a, int nti
   constexpr int CPP = CC / 8;
   constexpr int PAD = KS / 2;
   constexpr int NCHUNK16 = HH_ * HW_ * CPP;
-  constexpr int NPF = (NCHUNK16 + 511) / 512;
+  constexpr int NPF = (NCHUNK16 + NTHR - 1) / NTHR;
   constexpr int NC = 4 * MT;
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int wrows = a.nch * KSTEPS * 16 * MT;
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(512) void conv_mfma_wlds_kernel(ConvArgs a, int nti
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
   {
     const uint4* src = reinterpret_cast<const uint4*>(a.w + (size_t)blockIdx.y * wrows * 32);
-    for (int c = tid; c < wrows * 4; c += 512) {
+    for (int c = tid; c < wrows * 4; c += NTHR) {
       const int row = c >> 2, qq = c & 3;
       *reinterpret_cast<uint4*>(sw + row * 64 + ((qq ^ ((row >> 2) & 3)) << 4)) = src[c];
     }
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(512) void conv_mfma_wlds_kernel(ConvArgs a, int nti
   int gyx[NPF];    // packed (ry << 16) | (rx & 0xffff), relative real coordinates; -1 row marks "never valid"
 #pragma unroll
   for (int i = 0; i < NPF; ++i) {
-    const int id = tid + i * 512;
+    const int id = tid + i * NTHR;
     const int pixel = id / CPP, part = id - pixel * CPP;
     if (FLAT) {
       goff[i] = pixel * a.ldx + part * 8;
@@ -371,30 +372,39 @@ __global__ __launch_bounds__(512) void conv_mfma_wlds_kernel(ConvArgs a, int nti
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < NPF; ++i)
-        if (tid + i * 512 < NCHUNK16) {
-          const int id = tid + i * 512;
+        if (tid + i * NTHR < NCHUNK16) {
+          const int id = tid + i * NTHR;
           *reinterpret_cast<uint4*>(st + swz<CC>(id / CPP, id % CPP)) = pf[i];
         }
       __syncthreads();
       if (h + 1 < a.nch) prefetch(tile, h + 1);
       else if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x, 0);
       const char* wh = sw + (size_t)(h * KSTEPS) * (16 * MT) * 64;
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
+      // software-pipelined k-loop: the fragments of k-step ks+1 are requested from LDS BEFORE the MFMAs of k-step ks issue
+      // (hipcc otherwise emits read -> wait -> 2 MFMAs, exposing the ~100-cycle LDS latency once per pair)
+      half8 af[2][MT], bf[2][NT];
+      auto load_frags = [&](int buf, int ks) {
         const int kk = ks * 32 + q * 8;
         int tap = kk / CC;
         const int c = kk - tap * CC;
         if (tap > KS * KS - 1) tap = KS * KS - 1;
         const int toff = ((tap / KS) * HW_ + (tap % KS)) * PS + c * 2;
-        half8 af[MT], bf[NT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const half8*>(wh + (ks * (16 * MT) + m * 16) * 64 + aoff);
+        for (int m = 0; m < MT; ++m) af[buf][m] = *reinterpret_cast<const half8*>(wh + (ks * (16 * MT) + m * 16) * 64 + aoff);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const half8*>(st + boff[t] + toff);
+        for (int t = 0; t < NT; ++t) bf[buf][t] = *reinterpret_cast<const half8*>(st + boff[t] + toff);
+      };
+      load_frags(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        if (ks + 1 < KSTEPS) load_frags((ks + 1) & 1, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf[t], acc[m][t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks & 1][m], bf[ks & 1][t], acc[m][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- epilogue of this tile
@@ -687,28 +697,33 @@ extern "C" int dy_pack_weights(const float* w, const float* scale, void* out, in
 #define DY_WLDS_MAX_WGS 512
 static bool g_force_v1 = getenv("DY_CONV_V1") != nullptr;
 
-// LDS bytes of the v3 kernel with `trows` output rows per wave (FLAT: 32*trows pixels per wave)
-static size_t wlds_bytes_t(int cc, int mt, int ks, int stride, int nch, int trows) {
+// LDS bytes of the v3 kernel with `nw` waves and `trows` output rows per wave (FLAT: 32*trows pixels per wave)
+static size_t wlds_bytes_t(int cc, int mt, int ks, int stride, int nch, int trows, int nw = 8) {
   const bool flat = ks == 1;
-  const int th = 8 * trows, hw = flat ? 8 * 2 * trows * 16 : 31 * stride + ks, hh = flat ? 1 : (th - 1) * stride + ks;
+  const int th = nw * trows, hw = flat ? nw * 2 * trows * 16 : 31 * stride + ks, hh = flat ? 1 : (th - 1) * stride + ks;
   size_t tile = (size_t)hh * hw * (cc * 2 + 16);
-  const size_t red = 8 * 2 * 16 * mt * 4;
+  const size_t red = nw * 2 * 16 * mt * 4;
   if (tile < red) tile = red;
   const size_t wts = (size_t)nch * ((ks * ks * cc + 31) / 32) * 16 * mt * 64;
   return tile + wts;
 }
-// rows per wave the v3 kernel will use for a geometry (2 preferred, 1 when only that fits), 0 = v3 not applicable
+// v3 configuration for a geometry: 2 = 8 waves x 2 rows (preferred), 4 = 4 waves x 2 rows (same per-wave tile, fits when the
+// 16-row halo does not: 64-channel 3x3), 1 = 8 waves x 1 row, 0 = v3 not applicable
+static bool g_no_nw4 = getenv("DY_CONV_NW4") == nullptr;  // measured slower (224 vs 202 us on 64->64 3x3 @160^2): opt-in only
 static int v3_trows(int cc, int mt, int ks, int stride, int nch) {
   if (ks == 3 && stride == 2) return wlds_bytes_t(cc, mt, ks, stride, nch, 1) <= DY_WLDS_BUDGET ? 1 : 0;
   if (wlds_bytes_t(cc, mt, ks, stride, nch, 2) <= DY_WLDS_BUDGET) return 2;
+  if (!g_no_nw4 && ks == 3 && wlds_bytes_t(cc, mt, ks, stride, nch, 2, 4) <= DY_WLDS_BUDGET) return 4;
   return wlds_bytes_t(cc, mt, ks, stride, nch, 1) <= DY_WLDS_BUDGET ? 1 : 0;
 }
+static int v3_tile_rows(int cfg) { return cfg == 2 ? 16 : 8; }
+static int v3_flat_pix(int cfg) { return cfg == 2 ? 512 : (cfg == 4 ? 256 : 256); }
 
 
-template <int CC, int MT, int KS, int STRIDE, int TR3>
+template <int CC, int MT, int KS, int STRIDE, int TR3, int NW>
 static int launch_v3(const ConvArgs& a, int grid_y, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = conv_mfma_wlds_kernel<CC, MT, KS, STRIDE, TR3>;
+  auto kern = conv_mfma_wlds_kernel<CC, MT, KS, STRIDE, TR3, NW>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DY_WLDS_BUDGET) != hipSuccess)
       return DY_ERR_LAUNCH;
@@ -717,22 +732,23 @@ static int launch_v3(const ConvArgs& a, int grid_y, hipStream_t s) {
   ConvArgs b = a;
   int ntiles;
   if (KS == 1) {
-    ntiles = cdiv(a.npix, 8 * 2 * TR3 * 16);
+    ntiles = cdiv(a.npix, NW * 2 * TR3 * 16);
   } else {
-    b.tiles_y = cdiv(a.Ho, 8 * TR3);
+    b.tiles_y = cdiv(a.Ho, NW * TR3);
     ntiles = b.tiles_x * b.tiles_y * a.N;
   }
   const int gx = ntiles < DY_WLDS_MAX_WGS ? ntiles : DY_WLDS_MAX_WGS;
-  hipLaunchKernelGGL(kern, dim3(gx, grid_y), dim3(512), wlds_bytes_t(CC, MT, KS, STRIDE, a.nch, TR3), s, b, ntiles);
+  hipLaunchKernelGGL(kern, dim3(gx, grid_y), dim3(NW * 64), wlds_bytes_t(CC, MT, KS, STRIDE, a.nch, TR3, NW), s, b, ntiles);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
 
 template <int CC, int MT, int KS, int STRIDE, int TROWS>
 static int launch_conv(const ConvArgs& a, int grid_x, int grid_y, hipStream_t s) {
-  const int tr = (g_force_v1 || (CC == 64 && STRIDE == 2)) ? 0 : v3_trows(CC, MT, KS, STRIDE, a.nch);
-  if (tr == 2 && !(KS == 3 && STRIDE == 2)) return launch_v3<CC, MT, KS, STRIDE, (KS == 3 && STRIDE == 2) ? 1 : 2>(a, grid_y, s);
-  if (tr == 1) return launch_v3<CC, MT, KS, STRIDE, 1>(a, grid_y, s);
+  const int cfg = (g_force_v1 || (CC == 64 && STRIDE == 2)) ? 0 : v3_trows(CC, MT, KS, STRIDE, a.nch);
+  if (cfg == 2 && !(KS == 3 && STRIDE == 2)) return launch_v3<CC, MT, KS, STRIDE, (KS == 3 && STRIDE == 2) ? 1 : 2, 8>(a, grid_y, s);
+  if (cfg == 4 && KS == 3 && STRIDE == 1) return launch_v3<CC, MT, KS, STRIDE, (KS == 3 && STRIDE == 1) ? 2 : 1, (KS == 3 && STRIDE == 1) ? 4 : 8>(a, grid_y, s);
+  if (cfg == 1) return launch_v3<CC, MT, KS, STRIDE, 1, 8>(a, grid_y, s);
   hipLaunchKernelGGL((conv_mfma_kernel<CC, MT, KS, STRIDE, TROWS>), dim3(grid_x, grid_y), dim3(256), 0, s, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
@@ -800,8 +816,8 @@ extern "C" int dy_conv_num_partials(int n, int h, int w, int cin, int cout, int 
   else tiles = cdiv(Wo, 32) * cdiv(Ho, stride == 1 ? 8 : 4) * n;
   int cp, op, cc, nch, mt, ng, kst, pe;
   if (dy_conv_geometry(cin, cout, ks, stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return tiles;
-  const int tr = (g_force_v1 || (cc == 64 && stride == 2)) ? 0 : v3_trows(cc, mt, ks, stride, nch);
-  if (!tr) return tiles;
-  const int t3 = ks == 1 ? cdiv(n * Ho * Wo, 8 * 2 * tr * 16) : cdiv(Wo, 32) * cdiv(Ho, 8 * tr) * n;
+  const int cfg = (g_force_v1 || (cc == 64 && stride == 2)) ? 0 : v3_trows(cc, mt, ks, stride, nch);
+  if (!cfg) return tiles;
+  const int t3 = ks == 1 ? cdiv(n * Ho * Wo, v3_flat_pix(cfg)) : cdiv(Wo, 32) * cdiv(Ho, v3_tile_rows(cfg)) * n;
   return t3 > DY_WLDS_MAX_WGS ? DY_WLDS_MAX_WGS : t3;
 }

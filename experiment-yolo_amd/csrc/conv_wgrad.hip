@@ -138,34 +138,51 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     }
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
-#pragma unroll
-    for (int r = 0; r < TH; ++r) {  // one k-step = 32 consecutive output pixels of tile row r
-      const int kpix = 8 * q + qq;  // first-read row of this lane inside the k-step
-      half8 af[MTC];
+    // software-pipelined: A fragments of k-step r+1 and the B fragment of column c+1 are requested before the MFMAs
+    // of (r, c) issue, so the transposed LDS reads run under the matrix pipe instead of in front of it
+    const int kpix = 8 * q + qq;  // first-read row of this lane inside a k-step
+    half8 af[2][MTC], bf[2];
+    auto load_a = [&](int buf, int r) {
 #pragma unroll
       for (int m = 0; m < MTC; ++m) {
         const char* b0 = sy + (r * TW + kpix) * PSY + (m * 16 + 4 * pp) * 2;
-        af[m] = tr_frag(b0, b0 + 4 * PSY);
+        af[buf][m] = tr_frag(b0, b0 + 4 * PSY);
       }
+    };
+    auto load_b = [&](int buf, int r, int c) {
+      const int col = wave + 4 * c;
+      if (col < NCOL) {
+        const int cit = col / TAPS, tap = col - cit * TAPS;
+        const int dy = tap / KS, dx = tap - dy * KS;
+        const char* b0;
+        int step;
+        if (FLAT) {
+          b0 = sx + (r * TW + kpix) * PSX + (cit * 16 + 4 * pp) * 2;
+          step = 4 * PSX;
+        } else {
+          b0 = sx + ((r * STRIDE + dy) * HWX + kpix * STRIDE + dx) * PSX + (cit * 16 + 4 * pp) * 2;
+          step = 4 * STRIDE * PSX;
+        }
+        bf[buf] = tr_frag(b0, b0 + step);
+      }
+    };
+    load_a(0, 0);
+    load_b(0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {  // one k-step = 32 consecutive output pixels of tile row r
+      if (r + 1 < TH) load_a((r + 1) & 1, r + 1);
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
-        const int col = wave + 4 * c;  // wave-uniform
-        if (col < NCOL) {
-          const int cit = col / TAPS, tap = col - cit * TAPS;
-          const int dy = tap / KS, dx = tap - dy * KS;
-          const char* b0;
-          int step;
-          if (FLAT) {
-            b0 = sx + (r * TW + kpix) * PSX + (cit * 16 + 4 * pp) * 2;
-            step = 4 * PSX;
-          } else {
-            b0 = sx + ((r * STRIDE + dy) * HWX + kpix * STRIDE + dx) * PSX + (cit * 16 + 4 * pp) * 2;
-            step = 4 * STRIDE * PSX;
-          }
-          const half8 bf = tr_frag(b0, b0 + step);
+        const int lin = r * CPW + c;
+        if (c + 1 < CPW) load_b((lin + 1) & 1, r, c + 1);
+        else if (r + 1 < TH) load_b((lin + 1) & 1, r + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave + 4 * c < NCOL) {
 #pragma unroll
-          for (int m = 0; m < MTC; ++m) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf, acc[m][c], 0, 0, 0);
+          for (int m = 0; m < MTC; ++m)
+            acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[r & 1][m], bf[lin & 1], acc[m][c], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

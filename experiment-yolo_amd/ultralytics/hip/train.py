@@ -97,7 +97,7 @@ class StepPlan:
             if self.use_graph:
                 torch.cuda.synchronize()
                 self.graph_fb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_fb):
+                with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
                     self.eng.replay(self.rec_fb)
         elif self.graph_fb is not None:
             self.graph_fb.replay()
@@ -144,7 +144,7 @@ class StepPlan:
             if self.use_graph:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     eng.replay(self.rec_opt[key])
                 self.graph_opt[key] = g
         elif key in self.graph_opt:
