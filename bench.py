@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="capture the step into hipGraphs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--probe", type=int, default=1, help="time the dominant kernel with HIP events")
+    ap.add_argument("--model", default="yolov8n-ASF-P2P2", help="model YAML stem (yolov8n-LD-P2 = BASELINE.json configs[3])")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,7 +109,13 @@ def main():
     from ultralytics.nn.tasks import DetectionModel
 
     torch.manual_seed(0)
-    model = DetectionModel(CFG, verbose=False).to(dev).train()
+    cfg_path = CFG if a.model == "yolov8n-ASF-P2P2" else os.path.join(os.path.dirname(CFG), a.model + ".yaml")
+    model = DetectionModel(cfg_path, verbose=False).to(dev).train()
+    if "LD" in a.model:  # zero-initialised p_conv weights (reference conv.py:357) would make every offset identical
+        with torch.no_grad():
+            for n_, p_ in model.named_parameters():
+                if n_.endswith("p_conv.weight"):
+                    p_.normal_(0, 0.02)
     for k, v in model.named_parameters():
         v.requires_grad = ".dfl" not in k
     plan = StepPlan(model, a.batch, a.imgsz, nmax=8, optimizer="SGD", world_size=world, use_graph=bool(a.graph))
@@ -165,7 +172,7 @@ def main():
         out = {"metric": "images/sec (train) DEAL-YOLO-N 640x640 bs=64/GPU", "value": value, "unit": "images/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-               "config": {"workload": f"DEAL-YOLO-N (yolov8n-ASF-P2P2.yaml) train step {a.imgsz}x{a.imgsz}, per-GPU batch {a.batch}, "
+               "config": {"workload": f"{'DEAL-YOLO-N' if a.model == 'yolov8n-ASF-P2P2' else a.model} ({a.model}.yaml) train step {a.imgsz}x{a.imgsz}, per-GPU batch {a.batch}, "
                                       f"fwd+TAL/CIoU/DFL/BCE loss+bwd+SGD+EMA, BASELINE.json configs[1]",
                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
                           "loss_items_last": [float(x) for x in s[5:8]], "loss_scale": float(plan.state[0]),

@@ -624,7 +624,11 @@ extern "C" int dy_conv_geometry(int cin, int cout, int ks, int stride, int* cin_
                                 int* mt, int* ngroups, int* ksteps, int* packed_elems) {
   if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || (ks == 1 && stride != 1)) return DY_ERR_ARG;
   const int cp = (cin + 7) / 8 * 8, op = (cout + 15) / 16 * 16;
-  const int c = pick_cc(cp, ks, stride), m = pick_mt(op);
+  int c = pick_cc(cp, ks, stride);
+  const int m = pick_mt(op);
+  // 64-channel 3x3 with a 64-wide cout group: two 32-channel chunks let the 16-row halo tile share LDS with the 72 KiB
+  // of weights, so each wave owns 64 pixels (4 N-tiles) and re-reads half as many A fragments per MFMA
+  if (ks == 3 && stride == 1 && c == 64 && m == 4 && getenv("DY_CONV_CC64") == nullptr) c = 32;
   *cin_p = cp;
   *cout_p = op;
   *cc = c;

@@ -73,55 +73,62 @@ __global__ __launch_bounds__(256) void ldconv_sample_kernel(LdArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void ldconv_sample_bwd_kernel(LdArgs a) {
-  const int cpp = a.C >> 3;  // power of two <= 32 (checked by the host)
-  const long total = (long)a.N * a.h * a.w * a.Np * cpp;
-  const long span = ((total + 255) / 256) * 256;  // keep whole waves in the loop so shuffles see every lane
+// One thread per (output pixel, sample n, channel): the C lanes of a sample are adjacent, so every atomic wave-instruction
+// adds runs of C contiguous floats (the shape float atomics run at full rate in; one-lane-per-row scatter is ~17x slower,
+// MI355X_MICROARCH.md "Global float atomics"), the sample's geometry is computed by the group's first lane and broadcast,
+// and the offset gradient is a log2(C)-step shuffle reduction over the group.
+__global__ __launch_bounds__(256) void ldconv_sample_bwd_kernel(LdArgs a, int G) {
+  // G = lanes per sample: the largest power of two <= 64 dividing C; each lane walks C/G channels G apart.
+  const int C = a.C;
+  const long total = (long)a.N * a.h * a.w * a.Np * G;
+  const long span = ((total + 255) / 256) * 256;
+  const int lane = threadIdx.x & 63, gl = lane & (G - 1), leader = lane & ~(G - 1);
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < span; idx += (long)gridDim.x * 256) {
     const bool live = idx < total;
-    const long id2 = live ? idx : total - 1;
-    const int part = (int)(id2 % cpp);
-    long t = id2 / cpp;
+    const long t = (live ? idx : total - 1) / G;
     const int n = (int)(t % a.Np);
     const long pix = t / a.Np;
-    int r0, r1, c0, c1;
-    float pr, pc;
-    bool ir, ic;
-    long img;
-    ld_coords(a, pix, n, r0, r1, c0, c1, pr, pc, ir, ic, img);
+    int r0 = 0, r1 = 0, c0 = 0, c1 = 0, flags = 0;
+    float pr = 0.f, pc = 0.f;
+    long img = 0;
+    if (gl == 0) {
+      bool ir, ic;
+      ld_coords(a, pix, n, r0, r1, c0, c1, pr, pc, ir, ic, img);
+      flags = (ir ? 1 : 0) | (ic ? 2 : 0);
+    }
+    r0 = __shfl(r0, leader, 64); r1 = __shfl(r1, leader, 64);
+    c0 = __shfl(c0, leader, 64); c1 = __shfl(c1, leader, 64);
+    pr = __shfl(pr, leader, 64); pc = __shfl(pc, leader, 64);
+    flags = __shfl(flags, leader, 64);
+    img = pix / ((long)a.h * a.w);
     const float ar0 = 1.f + ((float)r0 - pr), ar1 = 1.f - ((float)r1 - pr);
     const float ac0 = 1.f + ((float)c0 - pc), ac1 = 1.f - ((float)c1 - pc);
-    const float g_lt = ar0 * ac0, g_rb = ar1 * ac1, g_lb = ar0 * ac1, g_rt = ar1 * ac0;
-    const f16* xb = a.x + img * a.H * a.W * a.ldx + part * 8;
     const long o_lt = ((long)r0 * a.W + c0), o_rb = ((long)r1 * a.W + c1), o_lb = ((long)r0 * a.W + c1), o_rt = ((long)r1 * a.W + c0);
-    const half8 v_lt = *reinterpret_cast<const half8*>(xb + o_lt * a.ldx);
-    const half8 v_rb = *reinterpret_cast<const half8*>(xb + o_rb * a.ldx);
-    const half8 v_lb = *reinterpret_cast<const half8*>(xb + o_lb * a.ldx);
-    const half8 v_rt = *reinterpret_cast<const half8*>(xb + o_rt * a.ldx);
-    const half8 g = *reinterpret_cast<const half8*>(a.dxo + pix * a.lddxo + n * a.C + part * 8);
+    const f16* xb = a.x + img * a.H * a.W * a.ldx;
+    float* db = a.dx32 ? a.dx32 + img * a.H * a.W * C : nullptr;
+    const f16* gb = a.dxo + pix * a.lddxo + n * C;
     float dpr = 0.f, dpc = 0.f;
-    float* db = a.dx32 ? a.dx32 + img * a.H * a.W * a.C + part * 8 : nullptr;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float gj = live ? (float)g[j] : 0.f;
-      // d/dp_r: d(ar0) = -1, d(ar1) = +1 ; d/dp_c: d(ac0) = -1, d(ac1) = +1
-      dpr += gj * (-ac0 * (float)v_lt[j] + ac1 * (float)v_rb[j] - ac1 * (float)v_lb[j] + ac0 * (float)v_rt[j]);
-      dpc += gj * (-ar0 * (float)v_lt[j] + ar1 * (float)v_rb[j] + ar0 * (float)v_lb[j] - ar1 * (float)v_rt[j]);
+    for (int c = gl; c < C; c += G) {
+      const float v_lt = (float)xb[o_lt * a.ldx + c], v_rb = (float)xb[o_rb * a.ldx + c];
+      const float v_lb = (float)xb[o_lb * a.ldx + c], v_rt = (float)xb[o_rt * a.ldx + c];
+      const float g = live ? (float)gb[c] : 0.f;
+      dpr += g * (-ac0 * v_lt + ac1 * v_rb - ac1 * v_lb + ac0 * v_rt);
+      dpc += g * (-ar0 * v_lt + ar1 * v_rb + ar0 * v_lb - ar1 * v_rt);
       if (db && live) {
-        atomicAdd(db + o_lt * a.C + j, gj * g_lt);
-        atomicAdd(db + o_rb * a.C + j, gj * g_rb);
-        atomicAdd(db + o_lb * a.C + j, gj * g_lb);
-        atomicAdd(db + o_rt * a.C + j, gj * g_rt);
+        atomicAdd(db + o_lt * C + c, g * (ar0 * ac0));
+        atomicAdd(db + o_rb * C + c, g * (ar1 * ac1));
+        atomicAdd(db + o_lb * C + c, g * (ar0 * ac1));
+        atomicAdd(db + o_rt * C + c, g * (ar1 * ac0));
       }
     }
-    for (int o = 1; o < cpp; o <<= 1) {  // the cpp granule-threads of one (pixel, n) are adjacent lanes
+    for (int o = 1; o < G; o <<= 1) {
       dpr += __shfl_xor(dpr, o, 64);
       dpc += __shfl_xor(dpc, o, 64);
     }
-    if (live && part == 0) {
+    if (live && gl == 0) {
       f16* d = a.doff + pix * a.lddoff;
-      d[n] = (f16)(ir ? dpr : 0.f);
-      d[a.Np + n] = (f16)(ic ? dpc : 0.f);
+      d[n] = (f16)((flags & 1) ? dpr : 0.f);
+      d[a.Np + n] = (f16)((flags & 2) ? dpc : 0.f);
     }
   }
 }
@@ -142,15 +149,16 @@ extern "C" int dy_ldconv_sample(const void* x, int ldx, const float* off, int ld
 extern "C" int dy_ldconv_sample_backward(const void* x, int ldx, const float* off, int ldoff, const int* pn,
                                          const void* dxo, int lddxo, float* dx32, void* doff, int lddoff, int n, int H,
                                          int W, int h, int w, int C, int Np, int stride, hipStream_t stream) {
-  const int cpp = C >> 3;
-  if ((C & 7) || (ldx & 7) || (lddxo & 7) || (cpp & (cpp - 1)) || cpp > 32) return DY_ERR_ALIGN;
+  if ((C & 7) || (ldx & 7) || (lddxo & 7)) return DY_ERR_ALIGN;
+  int G = 64;
+  while (C % G) G >>= 1;
   LdArgs a{};
   a.x = (const f16*)x; a.off = off; a.dxo = (const f16*)dxo; a.dx32 = dx32; a.doff = (f16*)doff; a.pn = pn;
   a.ldx = ldx; a.lddxo = lddxo; a.ldoff_in = ldoff; a.lddoff = lddoff;
   a.N = n; a.H = H; a.W = W; a.h = h; a.w = w; a.C = C; a.Np = Np; a.stride = stride;
-  long blocks = ((long)n * h * w * Np * cpp + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(ldconv_sample_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  long blocks = ((long)n * h * w * Np * G + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(ldconv_sample_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, a, G);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

@@ -196,31 +196,31 @@ static __device__ __forceinline__ float softmax16_expect(float logit, int bin, f
   return quad16_sum(prob * (float)bin);
 }
 
+// 16 lanes per anchor (lane = side*4 + quarter, 4 consecutive bins each): one 16-byte load per lane, a wave covers four
+// anchors per instruction and the 16-bin softmax needs two shuffles instead of four.
 __global__ __launch_bounds__(256) void decode_kernel(LossCtx c) {
-  const int lane = threadIdx.x & 63, side = lane >> 4, bin = lane & 15;
-  const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((long)gridDim.x * 256) >> 6;
   const long total = (long)c.B * c.A;
-  constexpr int U = 4;  // anchors per iteration: U independent 256-byte loads in flight per wave
-  for (long ba0 = wave * U; ba0 < total; ba0 += nw * U) {
-    float logit[U];
-    int iyv[U], ixv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long ba = ba0 + u < total ? ba0 + u : total - 1;
-      const int b = (int)(ba / c.A), a = (int)(ba - (long)b * c.A);
-      int l;
-      anchor_of(c, a, l, iyv[u], ixv[u]);
-      const Level& L = c.lv[l];
-      logit[u] = L.box[(((size_t)b * L.H + iyv[u]) * L.W + ixv[u]) * 64 + lane];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float pr;
-      const float e = softmax16_expect(logit[u], bin, pr);
-      const float anc = (side & 1) ? (iyv[u] + 0.5f) : (ixv[u] + 0.5f);
-      const float coord = side < 2 ? anc - e : anc + e;
-      if (bin == 0 && ba0 + u < total) c.pred_box[(ba0 + u) * 4 + side] = coord;
-    }
+  const int sub = threadIdx.x & 15, side = sub >> 2, quarter = sub & 3;
+  for (long ba = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; ba < total; ba += ((long)gridDim.x * 256) >> 4) {
+    const int b = (int)(ba / c.A), a = (int)(ba - (long)b * c.A);
+    int l, iy, ix;
+    anchor_of(c, a, l, iy, ix);
+    const Level& L = c.lv[l];
+    const float4 v = *reinterpret_cast<const float4*>(L.box + (((size_t)b * L.H + iy) * L.W + ix) * 64 + sub * 4);
+    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    const float e0 = expf(v.x - m), e1 = expf(v.y - m), e2 = expf(v.z - m), e3 = expf(v.w - m);
+    float den = (e0 + e1) + (e2 + e3);
+    const float k0 = (float)(quarter * 4);
+    float num = e0 * k0 + e1 * (k0 + 1.f) + e2 * (k0 + 2.f) + e3 * (k0 + 3.f);
+    den += __shfl_xor(den, 1, 64);
+    num += __shfl_xor(num, 1, 64);
+    den += __shfl_xor(den, 2, 64);
+    num += __shfl_xor(num, 2, 64);
+    const float e = num / den;
+    const float anc = (side & 1) ? (iy + 0.5f) : (ix + 0.5f);
+    if (quarter == 0) c.pred_box[ba * 4 + side] = side < 2 ? anc - e : anc + e;
   }
 }
 
@@ -709,7 +709,10 @@ extern "C" int dy_detection_loss(const DyLossArgs* d, hipStream_t stream) {
                      d->n_targets, d->n_targets_dev, d->img_w, d->img_h);
   if (hipMemsetAsync(c.cnt, 0, BA * 4, stream) != hipSuccess) return DY_ERR_LAUNCH;
   const int gridA = (int)((BA * 64 + 255) / 256 < 2048 ? (BA * 64 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(decode_kernel, dim3(gridA), dim3(256), 0, stream, c);
+  {
+    const long nb = ((long)BA * 16 + 255) / 256;
+    hipLaunchKernelGGL(decode_kernel, dim3((int)(nb < 4096 ? nb : 4096)), dim3(256), 0, stream, c);
+  }
   hipLaunchKernelGGL(tal_topk_kernel, dim3((int)BN), dim3(256), 0, stream, c);
   hipLaunchKernelGGL(tal_scatter_kernel, dim3(cdiv((int)BN * TOPK, 256)), dim3(256), 0, stream, c);
   const int gridE = (int)((BA + 255) / 256 < 2048 ? (BA + 255) / 256 : 2048);

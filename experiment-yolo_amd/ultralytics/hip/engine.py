@@ -67,7 +67,7 @@ class Act:
         st = self.st
         if st.gbuf is None:
             st.gbuf = torch.empty_like(st.buf)
-            st.eng.keep.append(st.gbuf)
+            st.eng.hold(st.gbuf)
         return st.gbuf
 
     @property
@@ -172,6 +172,12 @@ class Engine:
             if rc != 0:
                 check(rc, name)
 
+    def hold(self, *ts):
+        """Keep per-call buffers alive for recorded launches.  Eager (un-recorded) calls must NOT retain them: the caching
+        allocator is stream-ordered, so a buffer freed by Python is only reused by launches enqueued later on this stream."""
+        if self.rec is not None:
+            self.keep.extend(ts)
+
     def scratch(self, key, nbytes):
         """Stream-ordered scratch reused across layers (partials, slabs, raw-gradient staging)."""
         t = self._scratch.get(key)
@@ -185,7 +191,7 @@ class Engine:
 
     def new_storage(self, N, H, W, C, dtype=torch.float16):
         st = Storage(self, N, H, W, C, dtype)
-        self.keep.append(st.buf)
+        self.hold(st.buf)
         return st
 
     def new_act(self, N, H, W, C):
@@ -376,7 +382,7 @@ class Engine:
 
     def maxpool5(self, x: Act, out: Act):
         arg = torch.empty(x.npix * x.C, dtype=torch.uint8, device=self.device)
-        self.keep.append(arg)
+        self.hold(arg)
         self.call("dy_maxpool5", x.ptr, x.ld, out.ptr, out.ld, arg.data_ptr(), x.N, x.H, x.W, x.C)
         if self.tape is not None:
             def bwd():
@@ -529,11 +535,11 @@ class Engine:
     def ldconv(self, sp_p: ConvSpec, sp_c: ConvSpec, pn_i32, Np, stride, x: Act, out: Act | None = None):
         h, w = self.out_hw(sp_p, x)
         off = torch.empty((x.N, h, w, 2 * Np), dtype=torch.float32, device=self.device)
-        self.keep.append(off)
+        self.hold(off)
         doff = None
         if self.tape is not None:
             doff = torch.zeros((x.N, h, w, 8 * ((2 * Np + 7) // 8)), dtype=torch.float16, device=self.device)
-            self.keep.append(doff)
+            self.hold(doff)
         self.conv_bias(sp_p, x, off.data_ptr(), 2 * Np, True, lambda: (doff.data_ptr(), doff.shape[-1]))
         xo = self.new_act(x.N, h, w, Np * x.C)
         self.call("dy_ldconv_sample", x.ptr, x.ld, off.data_ptr(), 2 * Np, pn_i32.data_ptr(), xo.ptr, xo.ld, x.N, x.H, x.W, h, w,

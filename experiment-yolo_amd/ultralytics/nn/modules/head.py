@@ -70,11 +70,11 @@ class Detect(HipModule):
         nb = 4 * self.reg_max
         boxes = [torch.empty((x.N, x.H, x.W, nb), dtype=torch.float32, device=eng.device) for x in xs]
         clss = [torch.zeros((x.N, x.H, x.W, ncp), dtype=torch.float32, device=eng.device) for x in xs]
-        eng.keep += boxes + clss
+        eng.hold(*boxes, *clss)
         ho = HeadOut(boxes, clss, self.nc, [float(s) for s in self.stride])
         if eng.tape is not None:
             ho.alloc_grads()
-            eng.keep += ho.dbox + ho.dcls
+            eng.hold(*ho.dbox, *ho.dcls)
         for l, x in enumerate(xs):
             a = self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(x))
             c = self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(x))
