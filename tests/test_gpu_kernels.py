@@ -73,8 +73,12 @@ def test_conv_forward_dgrad_wgrad(cin, cout, ks, s, H, W):
         ref0 = F.conv2d(x, w, None, s, ks // 2)
         assert relerr(y16.float().permute(0, 3, 1, 2), ref0) < 2e-3
         yq = y16.float()
-        assert relerr(part[:, 0, :cout].sum(0), yq.sum((0, 1, 2))) < 1e-4 + 1e-5
-        assert relerr(part[:, 1, :cout].sum(0), (yq * yq).sum((0, 1, 2))) < 1e-4
+        # BN partial sums: the ping-pong kernel sums its fp32 accumulators (== the fp32 conv up to summation order), the
+        # older kernels sum the fp16-rounded stored values; both must sit within fp16 rounding noise of the fp32 sums
+        r0 = ref0.permute(0, 2, 3, 1)
+        assert relerr(part[:, 0, :cout].sum(0), r0.sum((0, 1, 2))) < 5e-4
+        assert relerr(part[:, 1, :cout].sum(0), (r0 * r0).sum((0, 1, 2))) < 5e-4
+        assert min(relerr(part[:, 0, :cout].sum(0), r0.sum((0, 1, 2))), relerr(part[:, 0, :cout].sum(0), yq.sum((0, 1, 2)))) < 1.1e-4
     # gradients: dY random (fp16), dX via transposed pack (+ zero-dilation for stride 2), dW via the tr-read kernel
     coutp = (cout + 7) // 8 * 8
     dy = h16(torch.randn(N, cout, Ho, Wo))

@@ -31,7 +31,7 @@ ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
 def run():
     if mode == "fwd":
-        eng._conv_raw(sp, xa, y.buf.data_ptr(), y.C, 0)
+        eng._conv_raw(sp, xa, y.buf.data_ptr(), y.C, int(os.environ.get("DY_EPI", "0")))
     else:
         eng._conv_bwd(sp, Storage.act(x) if False else xa, y.buf.data_ptr(), y.C, Ho, Wo)
 
@@ -49,3 +49,17 @@ ms = ev[0].elapsed_time(ev[1]) / reps
 by = N * H * W * cp * 2 + N * Ho * Wo * cout * 2
 fl = 2 * N * Ho * Wo * cout * cin * ks * ks
 print(f"{mode} {cin}->{cout} k{ks} s{s} @{H}x{W} n={N}: {ms*1e3:.1f} us  {by/ms/1e6:.0f} GB/s  {fl/ms/1e9:.1f} TFLOP/s  (v1={'DY_CONV_V1' in os.environ})")
+if os.environ.get("DY_TIMING"):
+    import ctypes as C
+    from ultralytics.hip import lib
+    L = lib()
+    out = (C.c_ulonglong * 8)()
+    L.dy_conv_timing_fetch(out, 1)
+    run(); torch.cuda.synchronize()
+    L.dy_conv_timing_fetch(out, 1)
+    n = max(out[7], 1)
+    names = ["loop-top", "k_loop", "epilogue(+idle slot)", "stage_write(+vmcnt)", "prefetch_issue", "barrier", "-"]
+    tot = sum(out[i] for i in range(7))
+    for i, nm in enumerate(names):
+        print(f"  {nm:22s} {out[i]/n:10.0f} cycles/wave  {100*out[i]/tot:5.1f}%")
+    print(f"  total {tot/n:.0f} cycles per wave0, {n} workgroups")
