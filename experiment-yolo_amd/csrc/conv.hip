@@ -238,8 +238,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * (16 * MT) + ch];
-      const int ctot = gridDim.y * 16 * MT;
-      a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + ch] = s;
+      const int ctot = (a.cout + 15) & ~15;  // partial rows are round16(cout) wide whatever the cout-group padding
+      if (blockIdx.y * 16 * MT + ch < ctot) a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + ch] = s;
     }
   }
 }
@@ -567,8 +567,8 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_wlds_kernel(ConvArgs a, int
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) s += red[(w * 2 + which) * (16 * MT) + ch];
-      const int ctot = gridDim.y * 16 * MT;
-      a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + ch] = s;
+      const int ctot = (a.cout + 15) & ~15;  // partial rows are round16(cout) wide whatever the cout-group padding
+      if (blockIdx.y * 16 * MT + ch < ctot) a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + ch] = s;
     }
   }
 }
@@ -616,6 +616,11 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
   const int wgs = __builtin_amdgcn_readfirstlane(wg);
   char* const st = dsm + wrows * 64 + g * TILE_BYTES;
   char* const xs = dsm + wrows * 64 + 2 * TILE_BYTES + wave * (16 * XROW);
+  float* const bsh = reinterpret_cast<float*>(dsm + wrows * 64 + 2 * TILE_BYTES + 8 * (16 * XROW));  // this cout group's bias
+  if (tid < 16 * MT) {
+    const int c = blockIdx.y * (16 * MT) + tid;
+    bsh[tid] = ((a.epi & DY_EPI_BIAS) && c < a.cout) ? a.bias[c] : 0.f;
+  }
   {
     const uint4* src = reinterpret_cast<const uint4*>(a.w + (size_t)blockIdx.y * wrows * 32);
     for (int c = tid; c < wrows * 4; c += 512) {
@@ -737,10 +742,12 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
   };
   advance_pf();  // chunk 0 in flight while the weights land
 
-  const bool fast_epi = !(a.epi & (DY_EPI_BIAS | DY_EPI_SILU | DY_EPI_F32OUT)) && a.cout % (16 * MT) == 0 && !(a.ldy & 7) &&
-                        (a.epi & (DY_EPI_ACCUM | DY_EPI_STATS)) != (DY_EPI_ACCUM | DY_EPI_STATS);
-  const bool f32_epi = (a.epi & DY_EPI_F32OUT) && !(a.epi & (DY_EPI_SILU | DY_EPI_ACCUM | DY_EPI_STATS)) && a.cout % (16 * MT) == 0 &&
-                       !(a.ldy & 3) && !((uintptr_t)a.y & 15) && (!(a.epi & DY_EPI_BIAS) || !((uintptr_t)a.bias & 15));
+  const int e4 = a.epi & (DY_EPI_ACCUM | DY_EPI_STATS | DY_EPI_BIAS | DY_EPI_SILU);
+  const bool fast_epi = !(a.epi & DY_EPI_F32OUT) && a.cout % 8 == 0 && !(a.ldy & 7) &&
+                        (e4 == 0 || e4 == DY_EPI_ACCUM || e4 == DY_EPI_STATS || e4 == (DY_EPI_STATS | DY_EPI_BIAS) ||
+                         e4 == (DY_EPI_BIAS | DY_EPI_SILU));
+  const bool f32_epi = (a.epi & DY_EPI_F32OUT) && !(a.epi & (DY_EPI_SILU | DY_EPI_ACCUM | DY_EPI_STATS)) && a.cout % 4 == 0 &&
+                       !(a.ldy & 3) && !((uintptr_t)a.y & 15);
   f32x4 acc[MT][NT];
   for (int s = -1; s <= 2 * Jmax; ++s) {
     const int r = s - g;
@@ -798,8 +805,6 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
         for (int i = 0; i < NPF; ++i)
           if (gtid + i * GTHR < NCHUNK16) *reinterpret_cast<uint4*>(wb + i * (GTHR / CPP) * PS) = pf[i];
         TSTAMP(3)
-        advance_pf();  // chunk j+2 flies during that k-loop
-        TSTAMP(4)
       }
       if (j >= 0 && j < J && eh == a.nch - 1) {
         const int n = ecur.n, oy0 = ecur.by * TH, ox0 = ecur.bx * TW, pix0 = ecur.bx * HW_;
@@ -814,8 +819,9 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
           //    store is 64 separate 16-byte writes per instruction (measured: 21 % of the kernel).  Each N-tile is
           //    therefore turned through a per-wave LDS scratch so that PPR consecutive lanes write one pixel's whole
           //    channel block: full-line stores, 8x fewer write requests.
-          auto fast = [&](auto acc_tag, auto stats_tag) {
+          auto fast = [&](auto acc_tag, auto stats_tag, auto bias_tag, auto silu_tag) {
             constexpr bool ACCUM = decltype(acc_tag)::value, STATS = decltype(stats_tag)::value;
+            constexpr bool BIAS = decltype(bias_tag)::value, SILU = decltype(silu_tag)::value;
             constexpr int PPR = RB / 16;                       // 16-byte pieces per pixel row
             constexpr int PIXPASS = 64 / PPR;                  // pixels one store instruction covers
             constexpr int NPASS = PIXPASS >= 16 ? 1 : 16 / PIXPASS;
@@ -823,6 +829,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             // costs one compare; row validity, tile origin and the N-tile / pass displacement are scalar arithmetic
             const int dpix = lane / PPR, piece = lane % PPR;
             const unsigned loff = (unsigned)((dpix * a.ldy + blockIdx.y * (16 * MT) + piece * 8) * 2);
+            const bool chok = (int)(blockIdx.y * (16 * MT) + piece * 8) < a.cout;  // padded cout groups: whole 8-channel pieces drop
             const int row0 = FLAT ? 0 : oy0 + wgs * TROWS;
             const long tbase = FLAT ? (long)(pix0 + wgs * (NT * 16)) * a.ldy : ((long)(n * a.Ho + row0) * a.Wo + ox0) * a.ldy;
             char* const ybase = reinterpret_cast<char*>(a.y) + tbase * 2;
@@ -839,7 +846,16 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
               const f32x2 k2 = {keep, keep};
 #pragma unroll
               for (int m = 0; m < MT; ++m) {
-                const f32x2 lo = {acc[m][t][0], acc[m][t][1]}, hi = {acc[m][t][2], acc[m][t][3]};
+                f32x2 lo = {acc[m][t][0], acc[m][t][1]}, hi = {acc[m][t][2], acc[m][t][3]};
+                if (BIAS) {
+                  const f32x4 b = *reinterpret_cast<const f32x4*>(bsh + q * NC + m * 4);
+                  lo += (f32x2){b[0], b[1]};
+                  hi += (f32x2){b[2], b[3]};
+                }
+                if (SILU) {
+                  lo = (f32x2){silu_f(lo[0]), silu_f(lo[1])};
+                  hi = (f32x2){silu_f(hi[0]), silu_f(hi[1])};
+                }
                 hv.h[m * 2] = __builtin_convertvector(lo, half2_);
                 hv.h[m * 2 + 1] = __builtin_convertvector(hi, half2_);
                 if (STATS) {  // BN partial sums from the fp32 accumulators (before the fp16 rounding of the stored tensor);
@@ -868,7 +884,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
               for (int ps = 0; ps < NPASS; ++ps) {
                 const int c0 = tcol + ps * PIXPASS;                 // compile-time column of lane group 0
                 const long soff = FLAT ? (long)c0 * a.ldy : ((long)(t >> 1) * a.Wo + c0) * a.ldy;  // scalar
-                const bool valid = rowok && dpix < 16 && c0 + dpix < collim;
+                const bool valid = rowok && chok && dpix < 16 && c0 + dpix < collim;
                 union { uint4 u; half2_ h[4]; } d, o;
                 d.u = *reinterpret_cast<const uint4_a*>(xr + ps * PIXPASS * XROW);
                 uint4* const yp = reinterpret_cast<uint4*>(ybase + soff * 2 + (valid ? loff : 0u));
@@ -891,7 +907,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             f32x4 b4[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-              b4[m] = (a.epi & DY_EPI_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + co0 + m * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+              b4[m] = *reinterpret_cast<const f32x4*>(bsh + q * NC + m * 4);
             const int row0 = FLAT ? 0 : oy0 + wgs * TROWS;
             const long tbase = FLAT ? (long)(pix0 + wgs * (NT * 16)) * a.ldy : ((long)(n * a.Ho + row0) * a.Wo + ox0) * a.ldy;
             char* const ybase = reinterpret_cast<char*>(a.y) + tbase * 4;
@@ -906,12 +922,20 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
               f32x4* const yp = reinterpret_cast<f32x4*>(ybase + soff * 4 + (valid ? loff : 0u));
               if (valid) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) yp[m] = acc[m][t] + b4[m];
+                for (int m = 0; m < MT; ++m)
+                  if (co0 + m * 4 < a.cout) yp[m] = acc[m][t] + b4[m];
               }
             }
-          } else if (a.epi & DY_EPI_ACCUM) fast(std::true_type{}, std::false_type{});
-          else if (a.epi & DY_EPI_STATS) fast(std::false_type{}, std::true_type{});
-          else fast(std::false_type{}, std::false_type{});
+          } else {
+            constexpr std::true_type Y{};
+            constexpr std::false_type N_{};
+            const int e = a.epi & (DY_EPI_ACCUM | DY_EPI_STATS | DY_EPI_BIAS | DY_EPI_SILU);
+            if (e == DY_EPI_ACCUM) fast(Y, N_, N_, N_);
+            else if (e == DY_EPI_STATS) fast(N_, Y, N_, N_);
+            else if (e == (DY_EPI_STATS | DY_EPI_BIAS)) fast(N_, Y, Y, N_);
+            else if (e == (DY_EPI_BIAS | DY_EPI_SILU)) fast(N_, N_, Y, Y);
+            else fast(N_, N_, N_, N_);
+          }
         } else {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
@@ -977,6 +1001,10 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
       }
     }
     TSTAMP(2)
+    // last in the memory slot: chunk j+2 flies during the coming k-loop, and neither the epilogue's own loads (accumulate)
+    // nor its registers had to share the slot with the staging registers
+    if (r >= -1 && (r & 1) && ((r - 1) >> 1) + 1 < J) advance_pf();
+    TSTAMP(4)
     __syncthreads();
     TSTAMP(5)
   }
@@ -1005,8 +1033,8 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
       float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) sum += red[(w * 2 + which) * (16 * MT) + chn];
-      const int ctot = gridDim.y * 16 * MT;
-      a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + chn] = sum;
+      const int ctot = (a.cout + 15) & ~15;  // partial rows are round16(cout) wide whatever the cout-group padding
+      if (blockIdx.y * 16 * MT + chn < ctot) a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + chn] = sum;
     }
   }
 }
@@ -1094,7 +1122,9 @@ static int pick_cc(int cin_p, int ks, int stride) {
   if (cin_p % 16 == 0) return 16;
   return 8;
 }
-static int pick_mt(int cout_p) { return cout_p % 64 == 0 ? 4 : (cout_p % 32 == 0 ? 2 : 1); }
+// cout rows per workgroup = 16*MT.  48 / 80 / 96-channel outputs take MT = 4 with a padded last group (zero weight rows, masked
+// stores): these layers are memory-bound, and MT = 1 would stream the whole input once per 16 output channels
+static int pick_mt(int cout16) { return cout16 >= 48 ? 4 : (cout16 == 32 ? 2 : 1); }
 
 extern "C" int dy_conv_geometry(int cin, int cout, int ks, int stride, int* cin_p, int* cout_p, int* cc, int* nch,
                                 int* mt, int* ngroups, int* ksteps, int* packed_elems) {
@@ -1106,11 +1136,11 @@ extern "C" int dy_conv_geometry(int cin, int cout, int ks, int stride, int* cin_
   // of weights, so each wave owns 64 pixels (4 N-tiles) and re-reads half as many A fragments per MFMA
   if (ks == 3 && stride == 1 && c == 64 && m == 4 && getenv("DY_CONV_CC64") == nullptr) c = 32;
   *cin_p = cp;
-  *cout_p = op;
+  *ngroups = (op + 16 * m - 1) / (16 * m);
+  *cout_p = *ngroups * 16 * m;
   *cc = c;
   *nch = cp / c;
   *mt = m;
-  *ngroups = op / (16 * m);
   *ksteps = (ks * ks * c + 31) / 32;
   *packed_elems = (*ngroups) * (*nch) * (*ksteps) * 16 * m * 32;
   return DY_OK;
@@ -1234,7 +1264,7 @@ static size_t pp_lds_bytes(int cc, int mt, int ks, int stride, int nch, int trow
   if (tile < red) tile = red;
   const size_t wts = (size_t)nch * ((ks * ks * cc + 31) / 32) * 16 * mt * 64;
   const size_t xpose = 8 * 16 * (size_t)(32 * mt + 16);  // per-wave store-transpose scratch
-  return 2 * tile + wts + xpose;
+  return 2 * tile + wts + xpose + 16 * mt * 4;          // + this cout group's bias
 }
 // rows per wave of the ping-pong kernel for a geometry (0 = does not fit: v3/v1 take it)
 static int pp_trows(int cc, int mt, int ks, int stride, int nch) {
