@@ -42,7 +42,12 @@ static constexpr __host__ __device__ int wg_th(int ks, int stride, int nci, int 
 }
 
 template <int KS, int STRIDE, int NCI, int MTC>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
+// (256, 2): two workgroups per CU.  Without the second argument hipcc budgets 512 registers per lane (it put the 36 accumulator
+// tiles of the 64x64 3x3 case into AGPRs: 234 + 188), which leaves ONE workgroup per CU whose four waves stage, wait and
+// multiply in lock-step -- 29 % MFMA utilisation.  With two resident workgroups one stages while the other multiplies.
+// (The 64x64-channel 3x3 case needs 144 accumulator registers and cannot: it keeps one workgroup per CU; splitting its input
+// channels over two workgroups to fit was measured slower, 258 vs 224 us.)
+__global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void conv_wgrad_kernel(WgArgs a) {
   constexpr bool FLAT = (KS == 1);
   constexpr int TAPS = KS * KS;
   constexpr int NCOL = NCI * TAPS;          // (ci tile, tap) columns of this workgroup
