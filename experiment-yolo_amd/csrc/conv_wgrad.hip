@@ -57,7 +57,12 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
   constexpr int HHX = FLAT ? 1 : (TH - 1) * STRIDE + KS;
   constexpr int PAD = KS / 2;
   constexpr int CIN_C = 16 * NCI, COUT_C = 16 * MTC;
-  constexpr int PSX = CIN_C * 2 + 16, PSY = COUT_C * 2 + 16;
+  // LDS pitch per staged pixel.  A transposed read touches 8 consecutive pixel rows x 32 bytes per 32-lane group (see load_a),
+  // which tile the 64 banks exactly when (row distance in dwords) mod 64 is an odd multiple of 8: pitch = data + 32 B for
+  // unit-stride rows, data + 16 B where consecutive k are two pixels apart (stride-2 X tile).  The previous layout (rows
+  // q*8+qq, pitch data + 16) measured SQ_LDS_BANK_CONFLICT = 42 % of SQ_LDS_IDX_ACTIVE.
+  constexpr int PSX = CIN_C * 2 + ((STRIDE == 2) ? 16 : (CIN_C >= 32 ? 32 : 0));
+  constexpr int PSY = COUT_C * 2 + (COUT_C >= 32 ? 32 : 0);
   constexpr int XBYTES = HHX * HWX * PSX, YBYTES = TH * TW * PSY;
   __shared__ __attribute__((aligned(16))) char smem[XBYTES + YBYTES];
   char* const sx = smem;
@@ -79,51 +84,69 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
   constexpr int NGX = HHX * HWX * (CIN_C / 8), NGY = TH * TW * (COUT_C / 8);
   constexpr int NPX = (NGX + 255) / 256, NPY = (NGY + 255) / 256;
   uint4 pfx[NPX], pfy[NPY];
+  // tile-invariant byte offset of each of this thread's granules from the tile origin (NEVER = granule does not exist:
+  // the buffer range check answers it with zeros, as it does for rows above/below the image and pixels past the end)
+  constexpr unsigned NEVER = 0x80000000u;
+  constexpr int CPGX = CIN_C / 8, CPGY = COUT_C / 8;
+  unsigned xoff[NPX], yoff[NPY];
+#pragma unroll
+  for (int i = 0; i < NPX; ++i) {
+    const int id = tid + i * 256;
+    const int pixel = id / CPGX, part = id - pixel * CPGX;
+    const bool ok = id < NGX && ci0 + part * 8 < a.cin_r8;
+    const int hy = FLAT ? 0 : pixel / HWX, hx = FLAT ? pixel : pixel - hy * HWX;
+    xoff[i] = ok ? (unsigned)(((hy * a.W + hx) * a.ldx + ci0 + part * 8) * 2) : NEVER;
+  }
+#pragma unroll
+  for (int i = 0; i < NPY; ++i) {
+    const int id = tid + i * 256;
+    const int pixel = id / CPGY, part = id - pixel * CPGY;
+    const bool ok = id < NGY && co0 + part * 8 < a.cout_r8;
+    const int ty = FLAT ? 0 : pixel / TW, tx = FLAT ? pixel : pixel - ty * TW;
+    yoff[i] = ok ? (unsigned)(((ty * a.Wo + tx) * a.lddy + co0 + part * 8) * 2) : NEVER;
+  }
+  auto ld16 = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return *reinterpret_cast<const uint4*>(&v);
+  };
   auto prefetch = [&](int tile) {
-    int n = 0, oy0 = 0, ox0 = 0;
-    long pix0 = 0;
     if (FLAT) {
-      pix0 = (long)tile * (TH * TW);
+      const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x), 0, (int)((unsigned)a.npix * (unsigned)a.ldx * 2u), 0x00020000);
+      const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.dy), 0, (int)((unsigned)a.npix * (unsigned)a.lddy * 2u), 0x00020000);
+      const unsigned ox = (unsigned)tile * (TH * TW) * a.ldx * 2u, oy = (unsigned)tile * (TH * TW) * a.lddy * 2u;
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) pfx[i] = ld16(rx, xoff[i] + ox);
+#pragma unroll
+      for (int i = 0; i < NPY; ++i) pfy[i] = ld16(ry, yoff[i] + oy);
     } else {
       const int bx = tile % a.tiles_x;
       const int t2 = tile / a.tiles_x;
-      n = t2 / a.tiles_y;
-      oy0 = (t2 % a.tiles_y) * TH;
-      ox0 = bx * TW;
-    }
+      const int n = t2 / a.tiles_y;
+      const int oy0 = (t2 % a.tiles_y) * TH, ox0 = bx * TW;
+      const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+      const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x) + (size_t)n * a.H * a.W * a.ldx, 0, a.H * a.W * a.ldx * 2, 0x00020000);
+      const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.dy) + (size_t)n * a.Ho * a.Wo * a.lddy, 0, a.Ho * a.Wo * a.lddy * 2, 0x00020000);
+      const unsigned ox = (unsigned)((iy0 * a.W + ix0) * a.ldx * 2), oy = (unsigned)((oy0 * a.Wo + ox0) * a.lddy * 2);
+      if (ix0 >= 0 && ix0 + HWX <= a.W) {  // wave-uniform: interior in x, no column masks
 #pragma unroll
-    for (int i = 0; i < NPX; ++i) {
-      const int id = tid + i * 256;
-      const int pixel = id / (CIN_C / 8), part = id - pixel * (CIN_C / 8);
-      const f16* src = nullptr;
-      if (id < NGX && ci0 + part * 8 < a.cin_r8) {
-        if (FLAT) {
-          const long gp = pix0 + pixel;
-          if (gp < a.npix) src = a.x + gp * a.ldx + ci0 + part * 8;
-        } else {
-          const int hy = pixel / HWX, hx = pixel - hy * HWX;
-          const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
-          if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) src = a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.ldx + ci0 + part * 8;
+        for (int i = 0; i < NPX; ++i) pfx[i] = ld16(rx, xoff[i] + ox);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+          const int hx = ((tid + i * 256) / CPGX) % HWX;  // recomputed on border tiles only
+          pfx[i] = ld16(rx, (unsigned)(ix0 + hx) < (unsigned)a.W ? xoff[i] + ox : NEVER);
         }
       }
-      pfx[i] = src ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
-    }
+      if (ox0 + TW <= a.Wo) {
 #pragma unroll
-    for (int i = 0; i < NPY; ++i) {
-      const int id = tid + i * 256;
-      const int pixel = id / (COUT_C / 8), part = id - pixel * (COUT_C / 8);
-      const f16* src = nullptr;
-      if (id < NGY && co0 + part * 8 < a.cout_r8) {
-        if (FLAT) {
-          const long gp = pix0 + pixel;
-          if (gp < a.npix) src = a.dy + gp * a.lddy + co0 + part * 8;
-        } else {
-          const int ty = pixel / TW, tx = pixel - ty * TW;
-          const int oy = oy0 + ty, ox = ox0 + tx;
-          if (oy < a.Ho && ox < a.Wo) src = a.dy + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.lddy + co0 + part * 8;
+        for (int i = 0; i < NPY; ++i) pfy[i] = ld16(ry, yoff[i] + oy);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NPY; ++i) {
+          const int tx = ((tid + i * 256) / CPGY) % TW;
+          pfy[i] = ld16(ry, ox0 + tx < a.Wo ? yoff[i] + oy : NEVER);
         }
       }
-      pfy[i] = src ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
     }
   };
 
@@ -145,13 +168,15 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
     if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
     // software-pipelined: A fragments of k-step r+1 and the B fragment of column c+1 are requested before the MFMAs
     // of (r, c) issue, so the transposed LDS reads run under the matrix pipe instead of in front of it
-    const int kpix = 8 * q + qq;  // first-read row of this lane inside a k-step
+    const int kpix = 4 * q + qq;  // first-read row of this lane inside a k-step; the second read is 16 rows further.  (Which of
+                                  // the 32 pixels of a k-step a lane's k index means is free as long as A and B agree: with
+                                  // rows 4q+qq one 32-lane group reads 8 CONSECUTIVE rows, which the pitch above makes conflict-free.)
     half8 af[2][MTC], bf[2];
     auto load_a = [&](int buf, int r) {
 #pragma unroll
       for (int m = 0; m < MTC; ++m) {
         const char* b0 = sy + (r * TW + kpix) * PSY + (m * 16 + 4 * pp) * 2;
-        af[buf][m] = tr_frag(b0, b0 + 4 * PSY);
+        af[buf][m] = tr_frag(b0, b0 + 16 * PSY);
       }
     };
     auto load_b = [&](int buf, int r, int c) {
@@ -163,10 +188,10 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
         int step;
         if (FLAT) {
           b0 = sx + (r * TW + kpix) * PSX + (cit * 16 + 4 * pp) * 2;
-          step = 4 * PSX;
+          step = 16 * PSX;
         } else {
           b0 = sx + ((r * STRIDE + dy) * HWX + kpix * STRIDE + dx) * PSX + (cit * 16 + 4 * pp) * 2;
-          step = 4 * STRIDE * PSX;
+          step = 16 * STRIDE * PSX;
         }
         bf[buf] = tr_frag(b0, b0 + step);
       }
@@ -288,11 +313,14 @@ extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks
   if (ks == 1) ntiles = (int)(((long)n * Ho * Wo + th * 32 - 1) / (th * 32));
   else ntiles = cdiv(Wo, 32) * cdiv(Ho, th) * n;
   *slab_elems = (long)ks * ks * cp * op;
-  long cap = (64L << 20) / (*slab_elems * 4);  // keep the slab round trip below ~64 MB per layer
-  if (cap > 768) cap = 768;
-  if (cap < 64) cap = 64;
-  int gx = ntiles / 4;
-  if (gx > cap) gx = (int)cap;
+  // one slab per workgroup and exactly one resident round of workgroups: 256 CUs x (1 or 2 per CU, see the kernel's launch
+  // bounds) over the (ci chunk, co chunk) grid rows.  More workgroups than that only add slab traffic (147 KB each for
+  // 64x64 3x3) and a ragged second round; fewer leave CUs idle.
+  const int gy = (cp / (16 * nci)) * (op / (16 * mtc));
+  const int per_cu = (ks == 3 && nci * mtc >= 16) ? 1 : 2;
+  int gx = (256 * per_cu) / gy;
+  if (gx < 32) gx = 32;
+  if (gx > ntiles) gx = ntiles;
   if (gx < 1) gx = 1;
   *nslabs = gx;
   return DY_OK;
@@ -318,6 +346,8 @@ static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, flo
                            hipStream_t stream) {
   if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || (ks == 1 && stride != 1)) return DY_ERR_ARG;
   if ((ldx & 7) || (lddy & 7) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return DY_ERR_ALIGN;
+  // staging uses 32-bit buffer offsets: one image (3x3) or the whole tensor (1x1) must stay below 2 GiB
+  if ((ks == 1 ? (double)n : 1.0) * h * w * (ldx > lddy ? ldx : lddy) * 2.0 >= 2147483648.0) return DY_ERR_ARG;
   int cp, op, nci, mtc;
   wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc);
   WgArgs a{};
