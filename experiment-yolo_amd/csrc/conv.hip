@@ -1114,6 +1114,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+static int pp_trows(int cc, int mt, int ks, int stride, int nch);
 static int pick_cc(int cin_p, int ks, int stride) {
   const int cap = (ks == 3 && stride == 2) ? 32 : 64;
   if (cin_p <= cap && (cin_p == 8 || cin_p == 16 || cin_p == 32 || cin_p == 64)) return cin_p;
@@ -1131,10 +1132,28 @@ extern "C" int dy_conv_geometry(int cin, int cout, int ks, int stride, int* cin_
   if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || (ks == 1 && stride != 1)) return DY_ERR_ARG;
   const int cp = (cin + 7) / 8 * 8, op = (cout + 15) / 16 * 16;
   int c = pick_cc(cp, ks, stride);
-  const int m = pick_mt(op);
+  int m = pick_mt(op);
   // 64-channel 3x3 with a 64-wide cout group: two 32-channel chunks let the 16-row halo tile share LDS with the 72 KiB
   // of weights, so each wave owns 64 pixels (4 N-tiles) and re-reads half as many A fragments per MFMA
   if (ks == 3 && stride == 1 && c == 64 && m == 4 && getenv("DY_CONV_CC64") == nullptr) c = 32;
+  // Prefer a shape the weights-in-LDS ping-pong kernel can take: wide layers (128+ channels: 3x3 weights of a 64-wide cout
+  // group are 147+ KB) narrow the cout group to 32 or 16 rows and, for 3x3, the Cin chunk to 32.  The input is then
+  // streamed once per cout group, but these layers sit at 40x40 / 20x20 where the whole activation tensor is L2/MALL
+  // resident; the alternative (v1 kernel, A fragments from L2) measured 150-300 TFLOP/s on them.
+  // (Only up to 128x128 channels: beyond, the cout groups multiply while the 20x20 maps leave each workgroup a handful of
+  // tiles per 74 KB weight load -- 256->256 @20x20 and 128->256 s2 measured 15-55 % slower this way.)
+  if (pp_trows(c, m, ks, stride, cp / c) == 0 && cp <= 128 && op <= 128) {
+    bool found = false;
+    for (int mm = m; mm >= 1 && !found; mm >>= 1)
+      for (int cc2 = c; cc2 >= 32 && !found; cc2 >>= 1) {
+        if (cp % cc2) continue;
+        if (pp_trows(cc2, mm, ks, stride, cp / cc2)) {
+          m = mm;
+          c = cc2;
+          found = true;
+        }
+      }
+  }
   *cin_p = cp;
   *ngroups = (op + 16 * m - 1) / (16 * m);
   *cout_p = *ngroups * 16 * m;
