@@ -431,6 +431,157 @@ extern "C" int dy_scalseq_tail_backward(const void* r0, int ld0, const void* r1,
   return DY_OK;
 }
 
+// All three levels in one pass: a thread owns one level-2 pixel (a 4x4 block of full-resolution positions, four level-1
+// pixels) of one 8-channel granule, so dY and r0/r1/r2 are read once per mode instead of once per (level, mode) --
+// six launches and ~2.9 GB of reads become two launches and ~1.0 GB for the P2 ScalSeq of DEAL-YOLO-N.
+struct SsBwdAllArgs {
+  const f16* r[3];
+  int ld[3];
+  const f16* dy;
+  int lddy;
+  f16* dr[3];
+  int lddr[3];
+  const float* coef;
+  const float* bwdcoef;
+  float* partials;
+  int C, N, H, W, mode;
+};
+__global__ __launch_bounds__(256) void scalseq_bwd_all_kernel(SsBwdAllArgs a) {
+  const int cpp = a.C >> 3;
+  const int h1 = a.H >> 1, w1 = a.W >> 1, h2 = a.H >> 2, w2 = a.W >> 2;
+  const int part = threadIdx.x % cpp, c0 = part * 8;
+  const int rows = 256 / cpp, row = threadIdx.x / cpp;
+  const long npix2 = (long)a.N * h2 * w2;
+  float sc[8], sh[8], mean[8], inv[8], mg[8], mgx[8], ps[8], px[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = a.coef[c0 + j];
+    sh[j] = a.coef[a.C + c0 + j];
+    mean[j] = a.coef[2 * a.C + c0 + j];
+    inv[j] = a.coef[3 * a.C + c0 + j];
+    mg[j] = a.mode ? a.bwdcoef[c0 + j] : 0.f;
+    mgx[j] = a.mode ? a.bwdcoef[a.C + c0 + j] : 0.f;
+    ps[j] = px[j] = 0.f;
+  }
+  if (row < rows) {
+    for (long lp2 = (long)blockIdx.x * rows + row; lp2 < npix2; lp2 += (long)gridDim.x * rows) {
+      const int lx2 = (int)(lp2 % w2);
+      const long t = lp2 / w2;
+      const int ly2 = (int)(t % h2);
+      const long n = t / h2;
+      const half8 own2 = *reinterpret_cast<const half8*>(a.r[2] + lp2 * a.ld[2] + c0);
+      float z2[8], gs2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float zz = (float)own2[j] * sc[j] + sh[j];
+        z2[j] = zz > 0.f ? zz : 0.1f * zz;
+        gs2[j] = 0.f;
+      }
+      for (int q1 = 0; q1 < 4; ++q1) {
+        const int ly1 = ly2 * 2 + (q1 >> 1), lx1 = lx2 * 2 + (q1 & 1);
+        const long lp1 = (n * h1 + ly1) * w1 + lx1;
+        const half8 own1 = *reinterpret_cast<const half8*>(a.r[1] + lp1 * a.ld[1] + c0);
+        float z1[8], gs1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float zz = (float)own1[j] * sc[j] + sh[j];
+          z1[j] = zz > 0.f ? zz : 0.1f * zz;
+          gs1[j] = 0.f;
+        }
+#pragma unroll
+        for (int q0 = 0; q0 < 4; ++q0) {
+          const int y0 = ly1 * 2 + (q0 >> 1), x0 = lx1 * 2 + (q0 & 1);
+          const long pos = (n * a.H + y0) * a.W + x0;
+          const half8 own0 = *reinterpret_cast<const half8*>(a.r[0] + pos * a.ld[0] + c0);
+          const half8 g = *reinterpret_cast<const half8*>(a.dy + pos * a.lddy + c0);
+          half8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float zz0 = (float)own0[j] * sc[j] + sh[j];
+            const float z0 = zz0 > 0.f ? zz0 : 0.1f * zz0;
+            // first maximum wins (max_pool3d over the depth axis); leaky(z) > 0 <=> z > 0, so the slope follows the winner's sign
+            int am = 0;
+            float zb = z0;
+            if (z1[j] > zb) { am = 1; zb = z1[j]; }
+            if (z2[j] > zb) { am = 2; zb = z2[j]; }
+            const float gg = (float)g[j] * (zb > 0.f ? 1.f : 0.1f);
+            const float g0 = am == 0 ? gg : 0.f;
+            gs1[j] += am == 1 ? gg : 0.f;
+            gs2[j] += am == 2 ? gg : 0.f;
+            const float xh0 = ((float)own0[j] - mean[j]) * inv[j];
+            if (a.mode == 0) {
+              ps[j] += g0;
+              px[j] += g0 * xh0;
+            } else {
+              o[j] = (f16)(sc[j] * (g0 - mg[j] - xh0 * mgx[j]));
+            }
+          }
+          if (a.mode) *reinterpret_cast<half8*>(a.dr[0] + pos * a.lddr[0] + c0) = o;
+        }
+        half8 o1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = ((float)own1[j] - mean[j]) * inv[j];
+          if (a.mode == 0) {
+            ps[j] += gs1[j];
+            px[j] += gs1[j] * xh;
+          } else {
+            o1[j] = (f16)(sc[j] * (gs1[j] - 4.f * mg[j] - 4.f * xh * mgx[j]));
+          }
+        }
+        if (a.mode) *reinterpret_cast<half8*>(a.dr[1] + lp1 * a.lddr[1] + c0) = o1;
+      }
+      half8 o2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = ((float)own2[j] - mean[j]) * inv[j];
+        if (a.mode == 0) {
+          ps[j] += gs2[j];
+          px[j] += gs2[j] * xh;
+        } else {
+          o2[j] = (f16)(sc[j] * (gs2[j] - 16.f * mg[j] - 16.f * xh * mgx[j]));
+        }
+      }
+      if (a.mode) *reinterpret_cast<half8*>(a.dr[2] + lp2 * a.lddr[2] + c0) = o2;
+    }
+  }
+  if (a.mode == 0) {
+    __shared__ float red[2][256][9];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[0][threadIdx.x][j] = ps[j];
+      red[1][threadIdx.x][j] = px[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
+      const int which = i / a.C, c = i - which * a.C, pp = c >> 3, j = c & 7;
+      float sum = 0.f;
+      for (int r = 0; r < rows; ++r) sum += red[which][r * cpp + pp][j];
+      a.partials[((size_t)blockIdx.x * 2 + which) * a.C + c] = sum;
+    }
+  }
+}
+extern "C" int dy_scalseq_tail_backward_all(const void* r0, int ld0, const void* r1, int ld1, const void* r2, int ld2,
+                                            const void* dy, int lddy, void* dr0, int lddr0, void* dr1, int lddr1,
+                                            void* dr2, int lddr2, const float* coef, const float* bwdcoef,
+                                            float* partials, int max_partials, int n, int h, int w, int C, int mode,
+                                            int* nparts, hipStream_t stream) {
+  if ((C & 7) || (C >> 3) > 256 || (h & 3) || (w & 3) || (ld0 & 7) || (ld1 & 7) || (ld2 & 7) || (lddy & 7)) return DY_ERR_ARG;
+  if (mode && ((lddr0 & 7) || (lddr1 & 7) || (lddr2 & 7) || !dr0 || !dr1 || !dr2 || !bwdcoef)) return DY_ERR_ARG;
+  if (!mode && !partials) return DY_ERR_ARG;
+  SsBwdAllArgs a{{(const f16*)r0, (const f16*)r1, (const f16*)r2}, {ld0, ld1, ld2}, (const f16*)dy, lddy,
+                 {(f16*)dr0, (f16*)dr1, (f16*)dr2}, {lddr0, lddr1, lddr2}, coef, bwdcoef, partials, C, n, h, w, mode};
+  const int rows = 256 / (C >> 3);
+  long blocks = ((long)n * (h >> 2) * (w >> 2) + rows - 1) / rows;
+  if (blocks > 2048) blocks = 2048;
+  if (mode == 0 && blocks > max_partials) blocks = max_partials;
+  if (blocks < 1) blocks = 1;
+  if (nparts) *nparts = (int)blocks;
+  hipLaunchKernelGGL(scalseq_bwd_all_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
 // ---- strided channel-slice copy (Concat fallback) and zero fill
 __global__ __launch_bounds__(256) void copy_slice_kernel(EwArgs e) {
   const int cpp = e.C >> 3;

@@ -62,6 +62,8 @@ SIGNATURES = {
     "dy_scalseq_tail": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "dy_scalseq_tail_backward": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32,
                                        i32, i32, ip, vp]),
+    "dy_scalseq_tail_backward_all": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32,
+                                           i32, i32, i32, i32, ip, vp]),
     "dy_zoom_pool": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "dy_zoom_pool_backward": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dy_copy_slice": (i32, [vp, i32, vp, i32, i64, i32, vp]),

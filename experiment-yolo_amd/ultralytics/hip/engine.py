@@ -513,23 +513,20 @@ class Engine:
     def _scalseq_bwd(self, conv3d, coef, bwdcoef, gbn, ps, raws, y):
         assert y.grad_ready()
         N, H, W, Cc = y.N, y.H, y.W, y.C
-        part = self.scratch("partials_ss", 3 * 1024 * 2 * Cc * 4 + 4096)
-        base = part.data_ptr()
+        part = self.scratch("partials_ss", 2048 * 2 * Cc * 4 + 4096)
         rargs = (raws[0].ptr, raws[0].ld, raws[1].ptr, raws[1].ld, raws[2].ptr, raws[2].ld, y.gptr, y.ld)
-        tot = 0
+        # one pass over dY / r0 / r1 / r2 per mode (all three levels at once)
+        n = C.c_int(0)
+        self.call("dy_scalseq_tail_backward_all", *rargs, 0, 0, 0, 0, 0, 0, coef.data_ptr(), 0, part.data_ptr(), 2048, N, H, W, Cc, 0,
+                  C.byref(n))
+        self.call("dy_bn_bwd_finalize", part.data_ptr(), n.value, gbn[0].data_ptr(), gbn[1].data_ptr(), bwdcoef.data_ptr(), Cc,
+                  float(3 * N * H * W), 0)
+        drs = [self.scratch(f"draw_ss{l}", ps[l].npix * Cc * 2) for l in range(3)]
+        self.call("dy_scalseq_tail_backward_all", *rargs, drs[0].data_ptr(), Cc, drs[1].data_ptr(), Cc, drs[2].data_ptr(), Cc,
+                  coef.data_ptr(), bwdcoef.data_ptr(), 0, 0, N, H, W, Cc, 1, None)
         for l in range(3):
-            n = C.c_int(0)
-            self.call("dy_scalseq_tail_backward", *rargs, 0, 0, coef.data_ptr(), 0, base + tot * 2 * Cc * 4, 1024, N, H, W, Cc, l, 0,
-                      C.byref(n))
-            tot += n.value
-        self.call("dy_bn_bwd_finalize", base, tot, gbn[0].data_ptr(), gbn[1].data_ptr(), bwdcoef.data_ptr(), Cc, float(3 * N * H * W), 0)
-        for l in range(3):
-            p = ps[l]
-            dr = self.scratch("draw", p.npix * Cc * 2)
-            self.call("dy_scalseq_tail_backward", *rargs, dr.data_ptr(), Cc, coef.data_ptr(), bwdcoef.data_ptr(), 0, 0, N, H, W, Cc, l, 1,
-                      None)
             # shared conv3d weights/bias: the three scales accumulate into one gradient
-            self._conv_bias_bwd(conv3d, p, lambda dr=dr, Cc=Cc: (dr.data_ptr(), Cc), accumulate=1 if l else 0)
+            self._conv_bias_bwd(conv3d, ps[l], lambda dr=drs[l], Cc=Cc: (dr.data_ptr(), Cc), accumulate=1 if l else 0)
 
     # ---- LDConv (reference nn/modules/conv.py:366-410) -----------------------------------------------------------
     def ldconv(self, sp_p: ConvSpec, sp_c: ConvSpec, pn_i32, Np, stride, x: Act, out: Act | None = None):

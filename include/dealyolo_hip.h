@@ -125,6 +125,11 @@ int dy_scalseq_tail_backward(const void* r0, int ld0, const void* r1, int ld1, c
                              int lddy, void* dr, int lddr, const float* coef, const float* bwdcoef, float* partials,
                              int max_partials, int n, int h, int w, int C, int level, int mode, int* nparts,
                              hipStream_t stream);
+/* all three levels in one pass (mode 0: BN partial sums [nparts][2][C]; mode 1: dr0/dr1/dr2 at full, 1/2, 1/4 resolution) */
+int dy_scalseq_tail_backward_all(const void* r0, int ld0, const void* r1, int ld1, const void* r2, int ld2,
+                                 const void* dy, int lddy, void* dr0, int lddr0, void* dr1, int lddr1, void* dr2,
+                                 int lddr2, const float* coef, const float* bwdcoef, float* partials, int max_partials,
+                                 int n, int h, int w, int C, int mode, int* nparts, hipStream_t stream);
 /* Zoom_cat fine branch nn/extra_modules/block.py:3406-3412: 2x2 max + 2x2 mean to half resolution (h, w = output extent) */
 int dy_zoom_pool(const void* x, int ldx, void* y, int ldy, int n, int h, int w, int C, hipStream_t stream);
 int dy_zoom_pool_backward(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int n, int h, int w, int C,

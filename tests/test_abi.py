@@ -37,7 +37,8 @@ def test_geometry_helpers_run_on_host():
     g = [C.c_int() for _ in range(8)]
     assert L.dy_conv_geometry(64, 64, 3, 1, *[C.byref(x) for x in g]) == 0
     cin_p, cout_p, cc, nch, mt, ng, kst, pe = [x.value for x in g]
-    assert (cin_p, cout_p, cc, nch, mt, ng, kst) == (64, 64, 64, 1, 4, 1, 18) and pe == 18 * 64 * 32
+    # 64-channel 3x3: two 32-channel Cin chunks (so the halo tiles share LDS with the 72 KiB of weights)
+    assert (cin_p, cout_p, cc, nch, mt, ng, kst) == (64, 64, 32, 2, 4, 1, 9) and pe == 18 * 64 * 32
     assert L.dy_conv_geometry(3, 16, 3, 2, *[C.byref(x) for x in g]) == 0 and g[0].value == 8
     assert L.dy_conv_geometry(64, 64, 5, 1, *[C.byref(x) for x in g]) == -1  # unsupported kernel size -> DY_ERR_ARG
     assert L.dy_loss_workspace_bytes(64, 33600, 8) > 64 * 33600 * 4 * 10
