@@ -163,7 +163,8 @@ def main():
             except Exception:
                 pass
             roof = {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": roof["kernel"], "avg_us": roof["us"], "bytes_per_launch": roof["bytes"]}
+                    "traffic": traffic, "kernel": roof["kernel"], "avg_us": roof["us"], "bytes_per_launch": roof["bytes"],
+                    "launches_per_step": roof["launches_per_step"]}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cpu = cpu_baseline(a.imgsz)

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "dealyolo_hip.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <type_traits>
 
 struct ConvArgs {
@@ -1388,6 +1389,24 @@ extern "C" int dy_conv_forward(const void* x, int ldx, const void* w_packed, con
   if (ks == 1) return dispatch_cc_mt<1, 1, 2>(cc, mt, a, gx, ng, stream);
   if (stride == 1) return dispatch_cc_mt<3, 1, 2>(cc, mt, a, gx, ng, stream);
   return dispatch_cc_mt<3, 2, 1>(cc, mt, a, gx, ng, stream);
+}
+
+// name of the kernel instantiation dy_conv_forward launches for a geometry, spelled as rocprofv3 prints it (host-side
+// helper: lets bench.py group its live per-launch timings by the same kernel names as the committed profiles)
+extern "C" int dy_conv_kernel_name(int cin, int cout, int ks, int stride, char* out, int cap) {
+  int cp, op, cc, nch, mt, ng, kst, pe;
+  if (!out || cap < 8 || dy_conv_geometry(cin, cout, ks, stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return DY_ERR_ARG;
+  const int pp = pp_trows(cc, mt, ks, stride, nch);
+  if (pp) {
+    snprintf(out, cap, "conv_mfma_pp_kernel<%d, %d, %d, %d, %d>", cc, mt, ks, stride, pp);
+    return DY_OK;
+  }
+  const int cfg = (g_force_v1 || (cc == 64 && stride == 2)) ? 0 : v3_trows(cc, mt, ks, stride, nch);
+  if (cfg == 2 && !(ks == 3 && stride == 2)) snprintf(out, cap, "conv_mfma_wlds_kernel<%d, %d, %d, %d, 2, 8>", cc, mt, ks, stride);
+  else if (cfg == 4 && ks == 3 && stride == 1) snprintf(out, cap, "conv_mfma_wlds_kernel<%d, %d, %d, %d, 2, 4>", cc, mt, ks, stride);
+  else if (cfg == 1) snprintf(out, cap, "conv_mfma_wlds_kernel<%d, %d, %d, %d, 1, 8>", cc, mt, ks, stride);
+  else snprintf(out, cap, "conv_mfma_kernel<%d, %d, %d, %d, %d>", cc, mt, ks, stride, (ks == 3 && stride == 2) ? 1 : 2);
+  return DY_OK;
 }
 
 // number of partial rows dy_conv_forward will write for a given problem (host-side planning helper)

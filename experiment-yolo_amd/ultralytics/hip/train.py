@@ -176,6 +176,9 @@ class StepPlan:
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 1)]
         tot = [0.0] * len(ops)
         for _ in range(reps):
+            # park the GPU for a few tens of ms so that the whole launch list is queued before the first kernel starts: the
+            # event intervals then hold kernel time + the back-to-back dispatch gap, not the host's ctypes launch latency
+            torch.cuda._sleep(60_000_000)
             evs[0].record()
             for i, (fn, args, name) in enumerate(ops):
                 rc = fn(*args, s)
@@ -185,7 +188,16 @@ class StepPlan:
             torch.cuda.synchronize()
             for i in range(len(ops)):
                 tot[i] += evs[i].elapsed_time(evs[i + 1])
-        return [(ops[i][2], ops[i][1], tot[i] / reps) for i in range(len(ops))]
+        # an event record is itself a queue packet: the interval between two records with nothing between them is not zero.
+        # Measure that empty interval in the same queued state and take it off every launch's interval.
+        cal = [torch.cuda.Event(enable_timing=True) for _ in range(33)]
+        torch.cuda._sleep(20_000_000)
+        for e in cal:
+            e.record()
+        torch.cuda.synchronize()
+        gaps = sorted(cal[i].elapsed_time(cal[i + 1]) for i in range(32))
+        self.event_gap_ms = gaps[len(gaps) // 2]
+        return [(ops[i][2], ops[i][1], max(tot[i] / reps - self.event_gap_ms, 0.0)) for i in range(len(ops))]
 
     @staticmethod
     def conv_algorithmic_bytes(args):
@@ -200,19 +212,29 @@ class StepPlan:
         return n * h * w * cin * 2 + out * (2 if epi & 16 else 1)
 
     def probe_dominant_kernel(self, batch, reps=10):
-        """Time every launch, pick the slowest dy_conv_forward (= exactly one conv_mfma_kernel launch) and price it."""
+        """Time every launch of the step (HIP events on the launch stream) and price the dominant conv kernel: the
+        dy_conv_forward kernel instantiation (named as rocprofv3 names it) with the largest total time per step.  Reports its
+        average launch duration and average algorithmic bytes per launch over ALL its launches of one step, which is what
+        `rocprofv3 --kernel-trace --stats` averages for the same kernel name."""
+        import ctypes as C
         if self.rec_fb is None:
             self.forward_backward(batch)
         prof = self.profile_ops(reps)
         self.last_profile = prof
-        convs = [(ms, args) for name, args, ms in prof if name == "dy_conv_forward"]
-        if not convs:
+        groups = {}
+        buf = C.create_string_buffer(128)
+        for name, args, ms in prof:
+            if name == "dy_conv_forward":
+                n, h, w, cin, cout, ks, stride, dil = args[7:15]
+                if self.eng.L.dy_conv_kernel_name(cin, cout, ks, stride, buf, 128) != 0:
+                    continue
+                groups.setdefault(buf.value.decode(), []).append((ms, self.conv_algorithmic_bytes(args)))
+        if not groups:
             return None
-        ms, args = max(convs, key=lambda t: t[0])
-        by = self.conv_algorithmic_bytes(args)
-        n, h, w, cin, cout, ks, stride, dil = args[7:15]
-        return {"kernel": f"conv_mfma_kernel {cin}->{cout} k{ks} s{stride} dil{dil} @{h}x{w} n={n}", "us": ms * 1e3, "bytes": by,
-                "gbs": by / (ms * 1e-3) / 1e9}
+        key, items = max(groups.items(), key=lambda kv: sum(t[0] for t in kv[1]))
+        ms = sum(t[0] for t in items) / len(items)
+        by = sum(t[1] for t in items) / len(items)
+        return {"kernel": key, "us": ms * 1e3, "bytes": by, "gbs": by / (ms * 1e-3) / 1e9, "launches_per_step": len(items)}
 
     def breakdown(self):
         agg = {}

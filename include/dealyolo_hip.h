@@ -67,6 +67,8 @@ int dy_conv_forward(const void* x, int ldx, const void* w_packed, const float* b
                     int n, int h, int w, int cin, int cout, int ks, int stride, int dil, int out_h, int out_w, int epi,
                     int* num_partials, hipStream_t stream);
 int dy_conv_num_partials(int n, int h, int w, int cin, int cout, int ks, int stride, int dil);
+/* host-side: the kernel instantiation dy_conv_forward launches for this geometry, spelled as rocprofv3 prints it */
+int dy_conv_kernel_name(int cin, int cout, int ks, int stride, char* out, int cap);
 
 /* ---- weight-gradient half of aten::convolution_backward for the same modules. dw: fp32 OIHW (cout,cin,ks,ks). -- */
 int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int stride, int* nslabs, long* slab_elems);
