@@ -238,12 +238,12 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
 // dW[co][ci][tap] (+)= sum_wg slab[wg][tap][co][ci].  One wave covers 64 consecutive slab elements (coalesced 256-byte
 // reads per slab); the slab axis is split over the block's 4 waves with 4 independent loads in flight per thread, so
 // the reduction is bandwidth- rather than latency-bound.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int nslabs, float* dw, int cout, int cin,
-                                                           int taps, int cout_p, int cin_p, int accumulate,
-                                                           int ld_taps, int ld_cphys, int ld_cin) {
+static __device__ __forceinline__ void wgrad_reduce_block(int block, const float* slabs, int nslabs, float* dw, int cout, int cin,
+                                                          int taps, int cout_p, int cin_p, int accumulate,
+                                                          int ld_taps, int ld_cphys, int ld_cin) {
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const long S = (long)taps * cout_p * cin_p;
-  const long o = (long)blockIdx.x * 64 + lane;
+  const long o = (long)block * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (o < S) {
     const float* p = slabs + o;
@@ -275,6 +275,53 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, i
       *d = accumulate ? *d + tot : tot;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int nslabs, float* dw, int cout, int cin,
+                                                           int taps, int cout_p, int cin_p, int accumulate,
+                                                           int ld_taps, int ld_cphys, int ld_cin) {
+  wgrad_reduce_block(blockIdx.x, slabs, nslabs, dw, cout, cin, taps, cout_p, cin_p, accumulate, ld_taps, ld_cphys, ld_cin);
+}
+
+// Every layer's slab reduction of one backward pass in ONE launch (67 launches of ~10 us, each latency-bound on a few
+// hundred KB, become one bandwidth-bound pass).  descs[i].first_block is the exclusive prefix of per-layer block counts.
+struct WgReduceDesc {
+  const float* slabs;
+  float* dw;
+  int nslabs, cout, cin, taps, cout_p, cin_p, accumulate, ld_taps, ld_cphys, ld_cin;
+  int first_block, pad_;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgReduceDesc* descs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {  // last descriptor whose first_block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const WgReduceDesc d = descs[lo];
+  wgrad_reduce_block(blockIdx.x - d.first_block, d.slabs, d.nslabs, d.dw, d.cout, d.cin, d.taps, d.cout_p, d.cin_p, d.accumulate,
+                     d.ld_taps, d.ld_cphys, d.ld_cin);
+}
+extern "C" int dy_wgrad_reduce_desc_bytes(void) { return (int)sizeof(WgReduceDesc); }
+static void wgrad_geometry(int cin, int cout, int ks, int stride, int* cin_p, int* cout_p, int* nci, int* mtc);
+// Fills one host-side descriptor for a layer whose dy_conv_wgrad / dy_conv_wgrad_ld call was made with dw == NULL; returns its
+// block count (to be prefix-summed into first_block by the caller) or a negative error.
+extern "C" int dy_wgrad_reduce_desc_fill(void* desc, const float* slabs, int nslabs, float* dw, int cin, int cout, int ks, int stride,
+                                         int accumulate, int ld_taps, int ld_cphys, int ld_cin, int first_block) {
+  if (!desc || !slabs || !dw || nslabs < 1) return DY_ERR_ARG;
+  int cp, op, nci, mtc;
+  const int cin_eff = ld_taps ? ld_taps * ld_cphys : cin;
+  wgrad_geometry(cin_eff, cout, ld_taps ? 1 : ks, ld_taps ? 1 : stride, &cp, &op, &nci, &mtc);
+  const int taps = ld_taps ? 1 : ks * ks;
+  WgReduceDesc* d = reinterpret_cast<WgReduceDesc*>(desc);
+  *d = WgReduceDesc{slabs, dw, nslabs, cout, cin_eff, taps, op, cp, accumulate, ld_taps, ld_cphys, ld_cin, first_block, 0};
+  return cdiv(taps * op * cp, 64);
+}
+extern "C" int dy_wgrad_reduce_batched(const void* descs_device, int n, int total_blocks, hipStream_t stream) {
+  if (n <= 0 || total_blocks <= 0 || !descs_device) return DY_ERR_ARG;
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, stream, (const WgReduceDesc*)descs_device, n);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
 }
 
 template <int KS, int STRIDE, int NCI, int MTC>
@@ -378,6 +425,7 @@ static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, flo
   else if (stride == 1) rc = dispatch_wgrad<3, 1>(nci, mtc, a, nslabs, gy, stream);
   else rc = dispatch_wgrad<3, 2>(nci, mtc, a, nslabs, gy, stream);
   if (rc != DY_OK) return rc;
+  if (!dw) return DY_OK;  // deferred: the caller reduces this layer's slabs later through dy_wgrad_reduce_batched
   const int total = ks * ks * op * cp;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, stream, slabs, nslabs, dw, cout, cin,
                      ks * ks, op, cp, accumulate, ld_taps, ld_cphys, ld_cin);

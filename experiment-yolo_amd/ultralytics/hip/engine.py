@@ -322,22 +322,54 @@ class Engine:
                   spec.bwdcoef.data_ptr(), npix, spec.cout, spec.act, 0)
         self._conv_bwd(spec, x, draw.data_ptr(), spec.cout, y.H, y.W)
 
-    def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0):
-        """weight gradient + input gradient of one convolution given d(raw output) (fp16, (N,Ho,Wo,lddy))."""
+    def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0, defer=True):
+        """weight gradient + input gradient of one convolution given d(raw output) (fp16, (N,Ho,Wo,lddy)).
+        When the engine is collecting (``self.deferred_wgrad`` is a list: StepPlan's backward trace) the per-workgroup slabs of
+        this layer are kept and reduced together with every other layer's by ONE ``dy_wgrad_reduce_batched`` launch at the end
+        of the backward pass; weights shared by several calls (ScalSeq's conv3d: ``defer=False``) reduce immediately."""
         ns, se = C.c_int(), C.c_long()
         self.L.dy_wgrad_workspace(x.N, x.H, x.W, spec.cin, spec.cout, spec.ks, spec.stride, C.byref(ns), C.byref(se))
-        slabs = self.scratch("slabs", ns.value * se.value * 4)
+        deferred = defer and not accumulate_w and self.deferred_wgrad is not None
+        if deferred:
+            slabs = torch.empty(ns.value * se.value, dtype=torch.float32, device=self.device)
+            self.hold(slabs)
+            self.deferred_wgrad.append((spec, slabs, ns.value))
+            dw = 0
+        else:
+            slabs = self.scratch("slabs", ns.value * se.value * 4)
+            dw = spec.gweight.data_ptr()
         if spec.ld is not None:
             n, cphys, cin = spec.ld
-            self.call("dy_conv_wgrad_ld", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), spec.gweight.data_ptr(), x.N, x.H, x.W,
+            self.call("dy_conv_wgrad_ld", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), dw, x.N, x.H, x.W,
                       spec.cout, cin, n, cphys, accumulate_w)
         else:
-            self.call("dy_conv_wgrad", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), spec.gweight.data_ptr(), x.N, x.H, x.W,
+            self.call("dy_conv_wgrad", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), dw, x.N, x.H, x.W,
                       spec.cin, spec.cout, spec.ks, spec.stride, accumulate_w)
         if x.needs_grad:
             acc = x.grad_target()
             self.call("dy_conv_forward", dy_ptr, lddy, spec.wpack_t.data_ptr(), 0, x.gptr, x.ld, 0, x.N, Ho, Wo,
                       spec.cout_phys, spec.cin, spec.ks, 1, spec.stride, x.H, x.W, DY_EPI_ACCUM if acc else 0, None)
+
+    deferred_wgrad = None
+
+    def flush_wgrad(self):
+        """Reduce the slabs of every deferred layer into its fp32 weight gradient: one launch, one descriptor per layer."""
+        items, self.deferred_wgrad = self.deferred_wgrad, None
+        if not items:
+            return
+        sz = self.L.dy_wgrad_reduce_desc_bytes()
+        host = (C.c_char * (sz * len(items)))()
+        blocks = 0
+        for i, (spec, slabs, ns) in enumerate(items):
+            ld = spec.ld or (0, 0, 0)
+            nb = self.L.dy_wgrad_reduce_desc_fill(C.byref(host, i * sz), slabs.data_ptr(), ns, spec.gweight.data_ptr(), spec.cin, spec.cout,
+                                                  spec.ks, spec.stride, 0, ld[0], ld[1], ld[2], blocks)
+            if nb < 0:
+                raise RuntimeError(f"dy_wgrad_reduce_desc_fill failed for {spec.name}")
+            blocks += nb
+        dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(self.device)
+        self.keep.append(dev)
+        self.call("dy_wgrad_reduce_batched", dev.data_ptr(), len(items), blocks)
 
     def conv_fused(self, spec: ConvSpec, x: Act, out: Act | None = None, res: Act | None = None):
         """Conv.forward_fuse (reference nn/modules/conv.py:57-59): BN folded into weights + bias, SiLU in the epilogue."""
@@ -356,7 +388,7 @@ class Engine:
         if self.tape is not None:
             self.tape.append(lambda: self._conv_bias_bwd(spec, x, dy_ptr_fn))
 
-    def _conv_bias_bwd(self, spec, x, dy_ptr_fn, accumulate=0):
+    def _conv_bias_bwd(self, spec, x, dy_ptr_fn, accumulate=0, defer=True):
         dyp, ld = dy_ptr_fn()
         Ho, Wo = self.out_hw(spec, x)
         npix = x.N * Ho * Wo
@@ -368,7 +400,7 @@ class Engine:
                   C.byref(n))
         tmp = self.scratch("bwdcoef_tmp", 2 * cp * 4)
         self.call("dy_bn_bwd_finalize", part.data_ptr(), n.value, 0, spec.gbias.data_ptr(), tmp.data_ptr(), cp, 1.0, accumulate)
-        self._conv_bwd(spec, x, dyp, ld, Ho, Wo, accumulate)
+        self._conv_bwd(spec, x, dyp, ld, Ho, Wo, accumulate, defer=defer)
 
     def upsample2x(self, x: Act, out: Act | None = None):
         y = out if out is not None else self.new_act(x.N, 2 * x.H, 2 * x.W, x.C)
@@ -526,7 +558,7 @@ class Engine:
                   coef.data_ptr(), bwdcoef.data_ptr(), 0, 0, N, H, W, Cc, 1, None)
         for l in range(3):
             # shared conv3d weights/bias: the three scales accumulate into one gradient
-            self._conv_bias_bwd(conv3d, ps[l], lambda dr=drs[l], Cc=Cc: (dr.data_ptr(), Cc), accumulate=1 if l else 0)
+            self._conv_bias_bwd(conv3d, ps[l], lambda dr=drs[l], Cc=Cc: (dr.data_ptr(), Cc), accumulate=1 if l else 0, defer=False)
 
     # ---- LDConv (reference nn/modules/conv.py:366-410) -----------------------------------------------------------
     def ldconv(self, sp_p: ConvSpec, sp_c: ConvSpec, pn_i32, Np, stride, x: Act, out: Act | None = None):

@@ -75,9 +75,12 @@ class StepPlan:
             crit.bind(ho, self.nmax, gscale=self.state[0:1])
             crit.sync_modes()
             eng.call("dy_detection_loss", C.byref(crit._args))
+            eng.deferred_wgrad = []
             for f in reversed(eng.tape):
                 f()
+            eng.flush_wgrad()
         finally:
+            eng.deferred_wgrad = None
             rec, eng.rec, eng.tape = eng.rec, None, None
         self.ho = ho
         return rec

@@ -74,6 +74,13 @@ int dy_conv_kernel_name(int cin, int cout, int ks, int stride, char* out, int ca
 int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int stride, int* nslabs, long* slab_elems);
 int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
                   int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream);
+/* dw == NULL in dy_conv_wgrad / dy_conv_wgrad_ld defers the slab reduction: the caller keeps that layer's slabs alive, fills one
+ * descriptor per layer (host side, sizeof = dy_wgrad_reduce_desc_bytes(); returns the layer's block count, first_block = the
+ * exclusive prefix sum of those counts) and reduces every layer of the backward pass in ONE launch. */
+int dy_wgrad_reduce_desc_bytes(void);
+int dy_wgrad_reduce_desc_fill(void* desc, const float* slabs, int nslabs, float* dw, int cin, int cout, int ks, int stride,
+                              int accumulate, int ld_taps, int ld_cphys, int ld_cin, int first_block);
+int dy_wgrad_reduce_batched(const void* descs_device, int n, int total_blocks, hipStream_t stream);
 
 /* ---- LDConv, nn/modules/conv.py:350-503: sampling (offset -> 4-corner bilinear gather, :366-410, :456-489) writes
  *      x_off[pix][n*C + c]; the (N,1) column conv (:354) then is a 1x1 conv with K = N*C whose weights are packed /
