@@ -799,6 +799,10 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
       }
     } else if (r >= -1 && (r & 1)) {
       // ------------------------------------------------------------ memory slot
+      // This wave shares its SIMD with a wave of the other group that is streaming MFMAs; at equal priority the arbiter
+      // gave this slot's ~150 instructions about one issue per 25 cycles.  Raised priority lets them go first -- they are
+      // few -- and the matrix stream fills every other cycle.
+      __builtin_amdgcn_s_setprio(3);
       const int j = (r - 1) >> 1;  // chunk whose k-loop this group finished in the previous slot (-1: none yet)
       if (j + 1 < J) {  // pf holds chunk j+1: its k-loop runs in the next slot
         char* const wb = st + swz<CC, STRIDE>(gtid / CPP, gtid % CPP);  // granule i lies GTHR/CPP pixels further: immediates
@@ -838,12 +842,22 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             const bool full = FLAT ? collim >= NT * 16 : (collim >= TW && oy0 + TH <= a.Ho);
             char* const xw = xs + p * XROW + q * (NC * 2);
             const char* const xr = xs + dpix * XROW + piece * 16;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              const int tcol = FLAT ? t * 16 : (t & 1) * 16;       // first pixel column of this N-tile
+            typedef uint2 __attribute__((may_alias)) uint2_a;  // (the 8-byte write and the 16-byte read are different C++ types)
+            typedef uint4 __attribute__((may_alias)) uint4_a;
+            // lanes exchange data through LDS inside one wave.  The hardware keeps a wave's LDS operations in order, but the
+            // compiler reasons per thread and would move N-tile t+1's write above N-tile t's read: wavefront-scope fences
+            // restricted to the LDS address space pin the order (an unqualified fence also emits s_waitcnt vmcnt(0) and
+            // waits for every earlier global store).
+            auto lds_order = []() {
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            };
+            auto tile_col = [](int t) { return FLAT ? t * 16 : (t & 1) * 16; };   // first pixel column of N-tile t
+            auto convert_write = [&](int t) {
               const bool rowok = FLAT ? true : row0 + (t >> 1) < a.Ho;
               union { half2_ h[NC / 2]; uint4 u4[NC / 8 > 0 ? NC / 8 : 1]; uint2 u2; } hv;
-              const float keep = (full || (rowok && tcol + p < collim)) ? 1.f : 0.f;
+              const float keep = (full || (rowok && tile_col(t) + p < collim)) ? 1.f : 0.f;
               const f32x2 k2 = {keep, keep};
 #pragma unroll
               for (int m = 0; m < MT; ++m) {
@@ -866,40 +880,54 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
                   s2[m * 2] += l2 * lo; s2[m * 2 + 1] += h2 * hi;
                 }
               }
-              // (may_alias types: the 8-byte write and the 16-byte read below are different C++ types, and type-based
-              // alias analysis otherwise lets the compiler move N-tile t+1's write above N-tile t's read)
-              typedef uint2 __attribute__((may_alias)) uint2_a;
-              typedef uint4 __attribute__((may_alias)) uint4_a;
               if (NC == 4) {
                 *reinterpret_cast<uint2_a*>(xw) = hv.u2;
               } else {
 #pragma unroll
                 for (int jj = 0; jj < NC / 8; ++jj) reinterpret_cast<uint4_a*>(xw)[jj] = hv.u4[jj];
               }
-              // lanes exchange data through LDS inside one wave: the hardware keeps a wave's LDS operations in order, but
-              // the compiler reasons per thread and would otherwise move the next N-tile's write above this read
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
+            union U4 { uint4 u; half2_ h[4]; };
+            auto dest = [&](int t, int ps, bool& valid) {
+              const bool rowok = FLAT ? true : row0 + (t >> 1) < a.Ho;
+              const int c0 = tile_col(t) + ps * PIXPASS;              // compile-time column of lane group 0
+              const long soff = FLAT ? (long)c0 * a.ldy : ((long)(t >> 1) * a.Wo + c0) * a.ldy;  // scalar
+              valid = rowok && chok && dpix < 16 && c0 + dpix < collim;
+              // lanes without a destination get the tensor base: the accumulate variant LOADS through this pointer before
+              // it tests `valid`, and rows of a partial tile past the last image lie outside the allocation
+              char* const pz = ybase + soff * 2 + loff;
+              return reinterpret_cast<uint4*>(valid ? pz : reinterpret_cast<char*>(a.y));
+            };
+            // software pipeline over the N-tiles: the scratch is written for tile t+1 as soon as tile t's reads have ISSUED
+            // (not returned), so one LDS round trip hides behind the next tile's conversion instead of four in a row
+            U4 d[2][NPASS], o[2][NPASS];
+            TSTAMP(6)
+            convert_write(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              lds_order();
 #pragma unroll
               for (int ps = 0; ps < NPASS; ++ps) {
-                const int c0 = tcol + ps * PIXPASS;                 // compile-time column of lane group 0
-                const long soff = FLAT ? (long)c0 * a.ldy : ((long)(t >> 1) * a.Wo + c0) * a.ldy;  // scalar
-                const bool valid = rowok && chok && dpix < 16 && c0 + dpix < collim;
-                union { uint4 u; half2_ h[4]; } d, o;
-                d.u = *reinterpret_cast<const uint4_a*>(xr + ps * PIXPASS * XROW);
-                uint4* const yp = reinterpret_cast<uint4*>(ybase + soff * 2 + (valid ? loff : 0u));
+                d[t & 1][ps].u = *reinterpret_cast<const uint4_a*>(xr + ps * PIXPASS * XROW);
                 if (ACCUM) {
-                  o.u = *yp;
+                  bool valid;
+                  o[t & 1][ps].u = *dest(t, ps, valid);
+                }
+              }
+              lds_order();
+              if (t + 1 < NT) convert_write(t + 1);
+#pragma unroll
+              for (int ps = 0; ps < NPASS; ++ps) {
+                bool valid;
+                uint4* const yp = dest(t, ps, valid);
+                U4 v = d[t & 1][ps];
+                if (ACCUM) {
 #pragma unroll
                   for (int k = 0; k < 4; ++k)
-                    d.h[k] = __builtin_convertvector(__builtin_convertvector(d.h[k], f32x2) + __builtin_convertvector(o.h[k], f32x2), half2_);
+                    v.h[k] = __builtin_convertvector(__builtin_convertvector(v.h[k], f32x2) + __builtin_convertvector(o[t & 1][ps].h[k], f32x2), half2_);
                 }
-                if (valid && !(a.epi & 256)) *yp = d.u;
+                if (valid && !(a.epi & 256)) *yp = v.u;
               }
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
           };
           if (f32_epi) {
@@ -1006,6 +1034,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
     // nor its registers had to share the slot with the staging registers
     if (r >= -1 && (r & 1) && ((r - 1) >> 1) + 1 < J) advance_pf();
     TSTAMP(4)
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     TSTAMP(5)
   }

@@ -58,7 +58,7 @@ if os.environ.get("DY_TIMING"):
     run(); torch.cuda.synchronize()
     L.dy_conv_timing_fetch(out, 1)
     n = max(out[7], 1)
-    names = ["loop-top", "k_loop", "epilogue(+idle slot)", "stage_write(+vmcnt)", "prefetch_issue", "barrier", "-"]
+    names = ["loop-top", "k_loop", "epilogue N-tiles", "stage_write(+vmcnt)", "prefetch_issue", "barrier", "epilogue setup (+slot idle)"]
     tot = sum(out[i] for i in range(7))
     for i, nm in enumerate(names):
         print(f"  {nm:22s} {out[i]/n:10.0f} cycles/wave  {100*out[i]/tot:5.1f}%")
