@@ -93,6 +93,32 @@ extern "C" int dy_bn_eval_coef(const float* gamma, const float* beta, const floa
   return DY_OK;
 }
 
+// compile-time activation: one instantiation per activation instead of a per-element branch; sigmoid through v_exp + v_rcp
+template <int ACT>
+static __device__ __forceinline__ float act_fwd_t(float z) {
+  // forward keeps the correctly rounded division: the 1-ulp v_rcp_f32 variant is as accurate for any single value, but the
+  // perturbation it puts on every activation was enough to flip a task-aligned top-10 choice in the 64x64 golden case
+  // (first-layer gradient 3.7e-2 -> 1.3e-1 off the reference); the backward factor below may use v_rcp_f32
+  if (ACT == DY_ACT_SILU) return z / (1.f + __expf(-z));
+  if (ACT == DY_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
+  return z;
+}
+template <int ACT>
+static __device__ __forceinline__ float act_grad_t(float z) {
+  if (ACT == DY_ACT_SILU) {
+    const float s = __builtin_amdgcn_rcpf(1.f + __expf(-z));
+    return s * (1.f + z * (1.f - s));
+  }
+  if (ACT == DY_ACT_LEAKY) return z > 0.f ? 1.f : 0.1f;
+  return 1.f;
+}
+#define DY_ACT_DISPATCH(KERNEL, grid, stream, args)                                                        \
+  do {                                                                                                     \
+    if (act == DY_ACT_SILU) hipLaunchKernelGGL(KERNEL<DY_ACT_SILU>, grid, dim3(256), 0, stream, args);      \
+    else if (act == DY_ACT_LEAKY) hipLaunchKernelGGL(KERNEL<DY_ACT_LEAKY>, grid, dim3(256), 0, stream, args); \
+    else hipLaunchKernelGGL(KERNEL<DY_ACT_NONE>, grid, dim3(256), 0, stream, args);                         \
+  } while (0)
+
 // ---------------------------------------------------------------------------------------------- apply (forward)
 static __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == DY_ACT_SILU) return silu_f(z);
@@ -117,6 +143,7 @@ struct ApplyArgs {
   long npix;
 };
 
+template <int ACT>
 __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a) {
   // a thread owns one 8-channel granule for the whole launch: scale/shift live in registers
   const int cpp = a.C >> 3, rows = 256 / cpp;
@@ -128,25 +155,33 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a) {
     sc[j] = a.coef[c0 + j];
     sh[j] = a.coef[a.C + c0 + j];
   }
-  for (long pix = (long)blockIdx.x * rows + row; pix < a.npix; pix += (long)gridDim.x * rows) {
-    const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
+  auto one = [&](long pix, const half8& xv) {
     half8 rv;
     if (a.res) rv = *reinterpret_cast<const half8*>(a.res + pix * a.ldr + c0);
     half8 out;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float z = act_fwd((float)xv[j] * sc[j] + sh[j], a.act);
+      float z = act_fwd_t<ACT>((float)xv[j] * sc[j] + sh[j]);
       if (a.res) z += (float)rv[j];
       out[j] = (f16)z;
     }
     *reinterpret_cast<half8*>(a.y + pix * a.ldy + c0) = out;
+  };
+  const long step = (long)gridDim.x * rows;
+  long pix = (long)blockIdx.x * rows + row;
+  for (; pix + step < a.npix; pix += 2 * step) {  // two pixels per trip: both loads issue before the first use
+    const half8 x0 = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
+    const half8 x1 = *reinterpret_cast<const half8*>(a.x + (pix + step) * a.ldx + c0);
+    one(pix, x0);
+    one(pix + step, x1);
   }
+  if (pix < a.npix) one(pix, *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0));
 }
 
 static inline int ew_blocks(long npix, int C) {
   const int rows = 256 / (C >> 3);
   long blocks = (npix + (long)rows * 4 - 1) / ((long)rows * 4);
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > 2048) blocks = 2048;  // 8 resident blocks per CU: each thread's coefficient prologue is amortised over >=25 pixels
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -156,7 +191,7 @@ extern "C" int dy_bn_act_apply(const void* x, int ldx, const void* res, int ldr,
   if ((C & 7) || (ldx & 7) || (ldy & 7) || (res && (ldr & 7))) return DY_ERR_ALIGN;
   if ((C >> 3) > 256) return DY_ERR_ARG;
   ApplyArgs a{(const f16*)x, (const f16*)res, (f16*)y, coef, ldx, ldr, ldy, C, act, npix};
-  hipLaunchKernelGGL(bn_act_apply_kernel, dim3(ew_blocks(npix, C)), dim3(256), 0, stream, a);
+  DY_ACT_DISPATCH(bn_act_apply_kernel, dim3(ew_blocks(npix, C)), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
@@ -172,6 +207,7 @@ struct BwdRedArgs {
   long npix;
 };
 
+template <int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
   const int cpp = a.C >> 3, rows = 256 / cpp, tid = threadIdx.x;
   const int part = tid % cpp, row = tid / cpp, c0 = part * 8;
@@ -185,13 +221,30 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
     inv[j] = a.coef[3 * a.C + c0 + j];
   }
   if (row < rows) {
-    for (long pix = (long)blockIdx.x * rows + row; pix < a.npix; pix += (long)gridDim.x * rows) {
+    // two pixels per trip: four 16-byte loads in flight per lane before the first use
+    const long step = (long)gridDim.x * rows;
+    long pix = (long)blockIdx.x * rows + row;
+    for (; pix + step < a.npix; pix += 2 * step) {
+      const half8 dv0 = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0);
+      const half8 xv0 = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
+      const half8 dv1 = *reinterpret_cast<const half8*>(a.dy + (pix + step) * a.lddy + c0);
+      const half8 xv1 = *reinterpret_cast<const half8*>(a.x + (pix + step) * a.ldx + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x0 = (float)xv0[j], x1 = (float)xv1[j];
+        const float g0 = (float)dv0[j] * act_grad_t<ACT>(x0 * sc[j] + sh[j]);
+        const float g1 = (float)dv1[j] * act_grad_t<ACT>(x1 * sc[j] + sh[j]);
+        sg[j] += g0 + g1;
+        sgx[j] += (g0 * (x0 - mean[j]) + g1 * (x1 - mean[j])) * inv[j];
+      }
+    }
+    if (pix < a.npix) {
       const half8 dv = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0);
       const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xf = (float)xv[j];
-        const float g = (float)dv[j] * act_grad(xf * sc[j] + sh[j], a.act);
+        const float g = (float)dv[j] * act_grad_t<ACT>(xf * sc[j] + sh[j]);
         sg[j] += g;
         sgx[j] += g * (xf - mean[j]) * inv[j];
       }
@@ -225,7 +278,7 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int lddy, const void* x, int
   if (blocks < 1) blocks = 1;
   if (nparts) *nparts = (int)blocks;
   BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, partials, lddy, ldx, C, act, npix};
-  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  DY_ACT_DISPATCH(bn_act_bwd_reduce_kernel, dim3((int)blocks), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
@@ -279,33 +332,45 @@ struct BwdApplyArgs {
   long npix;
 };
 
+template <int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BwdApplyArgs a) {
   const int cpp = a.C >> 3, rows = 256 / cpp;
   const int part = threadIdx.x % cpp, row = threadIdx.x / cpp, c0 = part * 8;
   if (row >= rows) return;
-  float sc[8], sh[8], mean[8], inv[8], mg[8], mgx[8];
+  // dx = sc*(g - mean_g - xhat*mean_gx) = sc*g - kb*x - kc  with  kb = sc*invstd*mean_gx,  kc = sc*mean_g - kb*mean
+  float sc[8], sh[8], kb[8], kc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     sc[j] = a.coef[c0 + j];
     sh[j] = a.coef[a.C + c0 + j];
-    mean[j] = a.coef[2 * a.C + c0 + j];
-    inv[j] = a.coef[3 * a.C + c0 + j];
-    mg[j] = a.frozen_stats ? 0.f : a.bwdcoef[c0 + j];
-    mgx[j] = a.frozen_stats ? 0.f : a.bwdcoef[a.C + c0 + j];
+    const float mean = a.coef[2 * a.C + c0 + j], inv = a.coef[3 * a.C + c0 + j];
+    const float mg = a.frozen_stats ? 0.f : a.bwdcoef[c0 + j];
+    const float mgx = a.frozen_stats ? 0.f : a.bwdcoef[a.C + c0 + j];
+    kb[j] = sc[j] * inv * mgx;
+    kc[j] = sc[j] * mg - kb[j] * mean;
   }
-  for (long pix = (long)blockIdx.x * rows + row; pix < a.npix; pix += (long)gridDim.x * rows) {
-    const half8 dv = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0);
-    const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
+  auto one = [&](long pix, const half8& dv, const half8& xv) {
     half8 out;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xf = (float)xv[j];
-      const float g = (float)dv[j] * act_grad(xf * sc[j] + sh[j], a.act);
-      const float xh = (xf - mean[j]) * inv[j];
-      out[j] = (f16)(sc[j] * (g - mg[j] - xh * mgx[j]));
+      const float g = (float)dv[j] * act_grad_t<ACT>(xf * sc[j] + sh[j]);
+      out[j] = (f16)(sc[j] * g - (kb[j] * xf + kc[j]));
     }
     *reinterpret_cast<half8*>(a.dx + pix * a.lddx + c0) = out;
+  };
+  const long step = (long)gridDim.x * rows;
+  long pix = (long)blockIdx.x * rows + row;
+  for (; pix + step < a.npix; pix += 2 * step) {
+    const half8 d0 = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0);
+    const half8 x0 = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
+    const half8 d1 = *reinterpret_cast<const half8*>(a.dy + (pix + step) * a.lddy + c0);
+    const half8 x1 = *reinterpret_cast<const half8*>(a.x + (pix + step) * a.ldx + c0);
+    one(pix, d0, x0);
+    one(pix + step, d1, x1);
   }
+  if (pix < a.npix)
+    one(pix, *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0), *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0));
 }
 
 extern "C" int dy_bn_act_bwd_apply(const void* dy, int lddy, const void* x, int ldx, void* dx, int lddx,
@@ -314,7 +379,7 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int lddy, const void* x, int 
   if ((C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7)) return DY_ERR_ALIGN;
   if ((C >> 3) > 256) return DY_ERR_ARG;
   BwdApplyArgs a{(const f16*)dy, (const f16*)x, (f16*)dx, coef, bwdcoef, lddy, ldx, lddx, C, act, frozen_stats, npix};
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_blocks(npix, C)), dim3(256), 0, stream, a);
+  DY_ACT_DISPATCH(bn_act_bwd_apply_kernel, dim3(ew_blocks(npix, C)), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

@@ -57,6 +57,7 @@ def test_model_step_vs_golden(golden, mi, name, mode):
     assert np.median(rel) < (6e-2 if ld else 2e-2) and rel.max() < (0.5 if ld else 0.15)
     if mode == "ciou":
         first = params[names[0]].grad.float().cpu() / scale
+        print("grad_first relerr %.3e l2err %.3e" % (relerr(first, G.t(f"{name}/{mode}/grad_first")), l2err(first, G.t(f"{name}/{mode}/grad_first"))))
         assert (l2err if ld else relerr)(first, G.t(f"{name}/{mode}/grad_first")) < (0.15 if ld else 5e-2)
         sd = m.state_dict()
         rm = list(G[f"{name}/run_mean_names"])
