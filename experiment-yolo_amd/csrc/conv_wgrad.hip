@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
   // which tile the 64 banks exactly when (row distance in dwords) mod 64 is an odd multiple of 8: pitch = data + 32 B for
   // unit-stride rows, data + 16 B where consecutive k are two pixels apart (stride-2 X tile).  The previous layout (rows
   // q*8+qq, pitch data + 16) measured SQ_LDS_BANK_CONFLICT = 42 % of SQ_LDS_IDX_ACTIVE.
-  constexpr int PSX = CIN_C * 2 + ((STRIDE == 2) ? 16 : (CIN_C >= 32 ? 32 : 0));
-  constexpr int PSY = COUT_C * 2 + (COUT_C >= 32 ? 32 : 0);
+  // (in dwords: unit-stride pitch = 8 mod 16 -> 16/32/48/64 channels take 8/24/24/40; stride-2 pitch = 4 mod 8 -> data + 4)
+  constexpr int PSX = (STRIDE == 2) ? CIN_C * 2 + 16 : (((CIN_C / 2 + 7) / 16) * 16 + 8) * 4;
+  constexpr int PSY = (((COUT_C / 2 + 7) / 16) * 16 + 8) * 4;
   constexpr int XBYTES = HHX * HWX * PSX, YBYTES = TH * TW * PSY;
   __shared__ __attribute__((aligned(16))) char smem[XBYTES + YBYTES];
   char* const sx = smem;
@@ -337,6 +338,9 @@ static int dispatch_wgrad(int nci, int mtc, const WgArgs& a, int gx, int gy, hip
   DY_CASE(1, 1) DY_CASE(1, 2) DY_CASE(1, 4)
   DY_CASE(2, 1) DY_CASE(2, 2) DY_CASE(2, 4)
   if (!(KS == 3 && STRIDE == 2)) { DY_CASE(4, 1) DY_CASE(4, 2) DY_CASE(4, 4) }
+  if (KS == 1) {  // 48- / 96-channel sides of the C2f 1x1 convs: three 16-channel tiles in one workgroup instead of three passes
+    DY_CASE(3, 1) DY_CASE(3, 2) DY_CASE(3, 4) DY_CASE(1, 3) DY_CASE(2, 3) DY_CASE(4, 3) DY_CASE(3, 3)
+  }
 #undef DY_CASE
   return DY_ERR_ARG;
 }
@@ -346,8 +350,8 @@ static void wgrad_geometry(int cin, int cout, int ks, int stride, int* cin_p, in
   *cout_p = (cout + 15) / 16 * 16;
   const int cit = *cin_p / 16, cot = *cout_p / 16;
   const int cap = (ks == 3 && stride == 2) ? 2 : 4;
-  *nci = (cit % 4 == 0 && cap >= 4) ? 4 : (cit % 2 == 0 ? 2 : 1);
-  *mtc = cot % 4 == 0 ? 4 : (cot % 2 == 0 ? 2 : 1);
+  *nci = (cit % 4 == 0 && cap >= 4) ? 4 : ((ks == 1 && cit % 3 == 0) ? 3 : (cit % 2 == 0 ? 2 : 1));
+  *mtc = cot % 4 == 0 ? 4 : ((ks == 1 && cot % 3 == 0) ? 3 : (cot % 2 == 0 ? 2 : 1));
 }
 
 extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int stride, int* nslabs,
