@@ -1302,6 +1302,225 @@ static int launch_v3(const ConvArgs& a, int grid_y, hipStream_t s) {
   return DY_OK;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Input gradient of a stride-2 3x3 convolution by output-parity classes.  dX(oy,ox) = sum_t W'[t] dYv(oy+ty-1, ox+tx-1) over
+// the zero-dilated dY: a tap contributes only where both coordinates are even, so an output pixel of parity (py,px) sees
+// 1, 2, 2 or 4 of the 9 taps.  The generic kernel multiplied all 9 taps against a tile that is three quarters zeros; here
+// a wave's four 16-pixel N-tiles ARE the four parity classes of its 2 x 32 output patch (N-tile (py,px) = row 2wg+py,
+// columns px, px+2, ...), every tap (k-step) feeds exactly one of them (4x fewer MFMAs), and the staged tile is the real
+// 5 x 17 dY patch (lanes read unit-stride pixels: conflict-free) instead of the 10 x 34 dilated one.
+// Same ping-pong structure, packed-weight layout and store transpose as conv_mfma_pp_kernel; epilogue: store or accumulate.
+template <int CC, int MT>
+__global__ __launch_bounds__(512) void conv_mfma_dg2_kernel(ConvArgs a, int ntiles) {
+  constexpr int GW = 4, GTHR = GW * 64, NT = 4, TH = 8, TW = 32;
+  constexpr int HW_ = TW / 2 + 1, HH_ = TH / 2 + 1;
+  constexpr int KPT = CC / 32, KSTEPS = 9 * KPT;         // k-steps per tap / per Cin chunk
+  constexpr int CPP = CC / 8;
+  constexpr int NCHUNK16 = HH_ * HW_ * CPP;
+  constexpr int NPF = (NCHUNK16 + GTHR - 1) / GTHR;
+  constexpr int NC = 4 * MT;
+  constexpr int PS = ps_bytes(CC, 1);
+  constexpr int TILE_BYTES = HH_ * HW_ * PS;
+  constexpr unsigned NEVER = 0x80000000u;
+  constexpr int RB = 4 * NC * 2, XROW = RB + 16;
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int wrows = a.nch * KSTEPS * 16 * MT;
+  char* const sw = dsm;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
+  const int g = __builtin_amdgcn_readfirstlane(wave >> 2), wg = wave & 3, gtid = tid & (GTHR - 1);
+  const int wgs = __builtin_amdgcn_readfirstlane(wg);
+  char* const st = dsm + wrows * 64 + g * TILE_BYTES;
+  char* const xs = dsm + wrows * 64 + 2 * TILE_BYTES + wave * (16 * XROW);
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.w + (size_t)blockIdx.y * wrows * 32);
+    for (int c = tid; c < wrows * 4; c += 512) {
+      const int row = c >> 2, qq = c & 3;
+      *reinterpret_cast<uint4*>(sw + row * 64 + ((qq ^ ((0 - (row >> 2)) & 3)) << 4)) = src[c];
+    }
+  }
+  const char* const stb = st + (wg * HW_ + p) * PS + q * 16;
+  const int aoff = p * 64 + ((q ^ ((0 - (p >> 2)) & 3)) << 4);
+
+  unsigned goff[NPF];
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    const int id = gtid + i * GTHR;
+    const int pixel = id / CPP, part = id - pixel * CPP;
+    const int hy = pixel / HW_, hx = pixel - hy * HW_;
+    goff[i] = id < NCHUNK16 ? (unsigned)(((hy * a.Wr + hx) * a.ldx + part * 8) * 2) : NEVER;
+  }
+  struct TileCur { int bx, by, n; };
+  uint4 pf[NPF];
+  auto prefetch = [&](const TileCur& tc, int h) {
+    const int ty0 = tc.by * (TH / 2), tx0 = tc.bx * (TW / 2);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x) + (size_t)tc.n * a.Hr * a.Wr * a.ldx, 0,
+                                                        a.Hr * a.Wr * a.ldx * 2, 0x00020000);
+    const unsigned org = (unsigned)(((ty0 * a.Wr + tx0) * a.ldx + h * CC) * 2);
+    const bool xedge = tx0 + HW_ > a.Wr;   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      unsigned off = goff[i] + org;
+      if (xedge) {
+        const int hx = ((gtid + i * GTHR) / CPP) % HW_;
+        off = tx0 + hx < a.Wr ? off : NEVER;
+      }
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
+      pf[i] = *reinterpret_cast<const uint4*>(&v);
+    }
+  };
+
+  const int gstride = 2 * gridDim.x;
+  const int gt0 = blockIdx.x * 2 + g;
+  const int ntg = gt0 < ntiles ? (ntiles - gt0 + gstride - 1) / gstride : 0;
+  const int J = ntg * a.nch;
+  const int Jmax = ((ntiles - (int)blockIdx.x * 2 + gstride - 1) / gstride) * a.nch;
+  const int sdx = gstride % a.tiles_x, sdy = (gstride / a.tiles_x) % a.tiles_y, sdn = (gstride / a.tiles_x) / a.tiles_y;
+  auto tile_next = [&](TileCur& c) {
+    c.bx += sdx;
+    const int cx = c.bx >= a.tiles_x ? 1 : 0;
+    c.bx -= cx * a.tiles_x;
+    c.by += sdy + cx;
+    const int cy = c.by >= a.tiles_y ? 1 : 0;
+    c.by -= cy * a.tiles_y;
+    c.n += sdn + cy;
+  };
+  TileCur pcur{gt0 % a.tiles_x, (gt0 / a.tiles_x) % a.tiles_y, (gt0 / a.tiles_x) / a.tiles_y}, ecur = pcur;
+  int ph = 0, jp = 0, ch = 0, eh = 0;
+  auto advance_pf = [&]() {
+    if (jp < J) prefetch(pcur, ph);
+    ++jp;
+    if (++ph == a.nch) { ph = 0; tile_next(pcur); }
+  };
+  advance_pf();
+
+  f32x4 acc[MT][NT];
+  for (int s = -1; s <= 2 * Jmax; ++s) {
+    const int r = s - g;
+    if (r >= 0 && !(r & 1)) {
+      if ((r >> 1) < J) {
+        if (ch == 0) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const char* wh = sw + (size_t)(ch * KSTEPS) * (16 * MT) * 64;
+        half8 af[2][MT], bf[2];
+        auto load_frags = [&](int buf, int ks) {
+          const int tap = ks / KPT, sub = ks - tap * KPT, ty = tap / 3, tx = tap - ty * 3;
+          // tap (ty,tx) reaches the parity class (ty != 1, tx != 1); its real dY pixel is one further when the tap index is 2
+          bf[buf] = *reinterpret_cast<const half8*>(stb + (((ty == 2) ? HW_ : 0) + ((tx == 2) ? 1 : 0)) * PS + sub * 64);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) af[buf][m] = *reinterpret_cast<const half8*>(wh + (ks * (16 * MT) + m * 16) * 64 + aoff);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          if (ks + 1 < KSTEPS) load_frags((ks + 1) & 1, ks + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const int tap = ks / KPT, ty = tap / 3, tx = tap - ty * 3;
+          const int t = ((ty != 1) ? 2 : 0) + ((tx != 1) ? 1 : 0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks & 1][m], bf[ks & 1], acc[m][t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        eh = ch;
+        if (++ch == a.nch) ch = 0;
+      }
+    } else if (r >= -1 && (r & 1)) {
+      __builtin_amdgcn_s_setprio(3);
+      const int j = (r - 1) >> 1;
+      if (j + 1 < J) {
+        char* const wb = st + (gtid / CPP) * PS + (gtid % CPP) * 16;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i)
+          if (gtid + i * GTHR < NCHUNK16) *reinterpret_cast<uint4*>(wb + i * (GTHR / CPP) * PS) = pf[i];
+      }
+      if (j >= 0 && j < J && eh == a.nch - 1) {
+        const int n = ecur.n, oy0 = ecur.by * TH, ox0 = ecur.bx * TW;
+        tile_next(ecur);
+        auto epi = [&](auto acc_tag) {
+          constexpr bool ACCUM = decltype(acc_tag)::value;
+          constexpr int PPR = RB / 16, PIXPASS = 64 / PPR, NPASS = PIXPASS >= 16 ? 1 : 16 / PIXPASS;
+          typedef uint2 __attribute__((may_alias)) uint2_a;
+          typedef uint4 __attribute__((may_alias)) uint4_a;
+          auto lds_order = []() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+          };
+          const int dpix = lane / PPR, piece = lane % PPR;
+          const unsigned loff = (unsigned)((2 * dpix * a.ldy + blockIdx.y * (16 * MT) + piece * 8) * 2);  // N-tile pixels are 2 apart
+          const bool chok = (int)(blockIdx.y * (16 * MT) + piece * 8) < a.cout;
+          const int row0 = oy0 + wgs * 2;
+          char* const ybase = reinterpret_cast<char*>(a.y) + ((long)(n * a.Ho + row0) * a.Wo + ox0) * a.ldy * 2;
+          const int collim = a.Wo - ox0;
+          char* const xw = xs + p * XROW + q * (NC * 2);
+          const char* const xr = xs + dpix * XROW + piece * 16;
+          union U4 { uint4 u; half2_ h[4]; };
+          auto convert_write = [&](int t) {
+            union { half2_ h[NC / 2]; uint4 u4[NC / 8 > 0 ? NC / 8 : 1]; uint2 u2; } hv;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const f32x2 lo = {acc[m][t][0], acc[m][t][1]}, hi = {acc[m][t][2], acc[m][t][3]};
+              hv.h[m * 2] = __builtin_convertvector(lo, half2_);
+              hv.h[m * 2 + 1] = __builtin_convertvector(hi, half2_);
+            }
+            if (NC == 4) {
+              *reinterpret_cast<uint2_a*>(xw) = hv.u2;
+            } else {
+#pragma unroll
+              for (int jj = 0; jj < NC / 8; ++jj) reinterpret_cast<uint4_a*>(xw)[jj] = hv.u4[jj];
+            }
+          };
+          auto dest = [&](int t, int ps, bool& valid) {
+            const int py = t >> 1, px = t & 1;
+            const int c0 = px + 2 * ps * PIXPASS;                       // column of lane group 0
+            const long soff = ((long)py * a.Wo + c0) * a.ldy;          // scalar
+            valid = row0 + py < a.Ho && chok && dpix < 16 && c0 + 2 * dpix < collim;
+            char* const pz = ybase + soff * 2 + loff;
+            return reinterpret_cast<uint4*>(valid ? pz : reinterpret_cast<char*>(a.y));
+          };
+          U4 d[2][NPASS], o[2][NPASS];
+          convert_write(0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            lds_order();
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+              d[t & 1][ps].u = *reinterpret_cast<const uint4_a*>(xr + ps * PIXPASS * XROW);
+              if (ACCUM) {
+                bool valid;
+                o[t & 1][ps].u = *dest(t, ps, valid);
+              }
+            }
+            lds_order();
+            if (t + 1 < NT) convert_write(t + 1);
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+              bool valid;
+              uint4* const yp = dest(t, ps, valid);
+              U4 v = d[t & 1][ps];
+              if (ACCUM) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  v.h[k] = __builtin_convertvector(__builtin_convertvector(v.h[k], f32x2) + __builtin_convertvector(o[t & 1][ps].h[k], f32x2), half2_);
+              }
+              if (valid) *yp = v.u;
+            }
+          }
+        };
+        if (a.epi & DY_EPI_ACCUM) epi(std::true_type{});
+        else epi(std::false_type{});
+      }
+      if (j + 1 < J) advance_pf();
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+  }
+}
+
 // ---- v4 (ping-pong) host side
 #define DY_NUM_CUS 256  // MI355X
 static bool g_force_v3 = getenv("DY_CONV_V3") != nullptr;
@@ -1381,6 +1600,32 @@ static int dispatch_cc_mt(int cc, int mt, const ConvArgs& a, int gx, int gy, hip
 
 extern "C" int dy_conv_num_partials(int n, int h, int w, int cin, int cout, int ks, int stride, int dil);
 
+static bool g_no_dg2 = getenv("DY_CONV_NO_DG2") != nullptr;
+static size_t dg2_lds_bytes(int cc, int mt, int nch) {
+  return (size_t)nch * 9 * (cc / 32) * 16 * mt * 64 + 2 * (size_t)(5 * 17 * ps_bytes(cc, 1)) + 8 * 16 * (size_t)(32 * mt + 16);
+}
+template <int CC, int MT>
+static int launch_dg2(const ConvArgs& a, int grid_y, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = conv_mfma_dg2_kernel<CC, MT>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DY_WLDS_BUDGET) != hipSuccess)
+      return DY_ERR_LAUNCH;
+    attr_set = true;
+  }
+  ConvArgs b = a;
+  b.tiles_x = cdiv(a.Wo, 32);
+  b.tiles_y = cdiv(a.Ho, 8);
+  const int ntiles = b.tiles_x * b.tiles_y * a.N;
+  const size_t lds = dg2_lds_bytes(CC, MT, a.nch);
+  const int per_cu = 2 * lds <= 160 * 1024 ? 2 : 1;
+  int gx = cdiv(ntiles, 2);
+  if (gx > DY_NUM_CUS * per_cu) gx = DY_NUM_CUS * per_cu;
+  hipLaunchKernelGGL(kern, dim3(gx, grid_y), dim3(512), lds, s, b, ntiles);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
 extern "C" int dy_conv_forward(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                                float* partials, int n, int h, int w, int cin, int cout, int ks, int stride, int dil,
                                int out_h, int out_w, int epi, int* num_partials, hipStream_t stream) {
@@ -1415,6 +1660,12 @@ extern "C" int dy_conv_forward(const void* x, int ldx, const void* w_packed, con
   if (num_partials) *num_partials = dy_conv_num_partials(n, h, w, cin, cout, ks, stride, dil);
   if ((epi & DY_EPI_STATS) && !partials) return DY_ERR_ARG;
   if (gx <= 0) return DY_ERR_ARG;
+  if (dil == 2 && !g_no_dg2 && !g_force_v1 && (cc == 32 || cc == 64) && !(epi & ~DY_EPI_ACCUM) && !((uintptr_t)y & 15) && !(ldy & 7) &&
+      cout % 8 == 0 && dg2_lds_bytes(cc, mt, nch) <= DY_WLDS_BUDGET && (double)h * w * ldx * 2.0 < 2147483648.0) {
+#define DY_DG2(C, M) if (cc == C && mt == M) return launch_dg2<C, M>(a, ng, stream);
+    DY_DG2(32, 1) DY_DG2(32, 2) DY_DG2(32, 4) DY_DG2(64, 1) DY_DG2(64, 2) DY_DG2(64, 4)
+#undef DY_DG2
+  }
   if (ks == 1) return dispatch_cc_mt<1, 1, 2>(cc, mt, a, gx, ng, stream);
   if (stride == 1) return dispatch_cc_mt<3, 1, 2>(cc, mt, a, gx, ng, stream);
   return dispatch_cc_mt<3, 2, 1>(cc, mt, a, gx, ng, stream);
