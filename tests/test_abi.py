@@ -52,3 +52,15 @@ def test_no_fallback_on_cpu():
     m = Conv(16, 16, 3)
     with pytest.raises(RuntimeError, match="GPU only|no CPU fallback"):
         m(torch.zeros(1, 16, 8, 8))
+
+
+def test_conv_kernel_name_helper():
+    """bench.py groups its live timings by the kernel instantiation dy_conv_forward launches (rocprofv3 spelling)."""
+    import ctypes as C
+    from ultralytics.hip import lib
+    L = lib()
+    buf = C.create_string_buffer(128)
+    assert L.dy_conv_kernel_name(64, 64, 3, 1, buf, 128) == 0 and buf.value == b"conv_mfma_pp_kernel<32, 4, 3, 1, 2>"
+    assert L.dy_conv_kernel_name(64, 64, 1, 1, buf, 128) == 0 and buf.value.startswith(b"conv_mfma_pp_kernel<64, 4, 1, 1,")
+    assert L.dy_conv_kernel_name(64, 64, 5, 1, buf, 128) != 0
+    assert L.dy_wgrad_reduce_desc_bytes() >= 64

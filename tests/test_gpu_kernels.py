@@ -165,3 +165,77 @@ def test_pool_upsample_add():
     (u + u).backward(gy)
     assert relerr(s.st.buf.float().permute(0, 3, 1, 2), u + u) < 1e-3
     assert relerr(xa.st.gbuf.float().permute(0, 3, 1, 2), xr.grad) < 4e-3
+
+
+def test_wgrad_deferred_batched_reduce_matches_immediate():
+    """dy_conv_wgrad with dw == NULL + dy_wgrad_reduce_batched (what StepPlan's backward trace uses: every layer's slabs
+    reduced by one launch) gives the same fp32 gradients as the immediate per-layer reduction."""
+    eng = _eng()
+    torch.manual_seed(3)
+    specs, xs, dys = [], [], []
+    for cin, cout, ks, s, H, W in [(16, 32, 3, 1, 12, 20), (32, 48, 1, 1, 9, 33), (16, 32, 3, 2, 16, 16)]:
+        w = h16(torch.randn(cout, cin, ks, ks) / (cin * ks * ks) ** 0.5)
+        sp = _spec(eng, w, None, ks, s)
+        xa = _act(eng, h16(torch.randn(2, cin, H, W)))
+        xa.needs_grad = False
+        Ho, Wo = eng.out_hw(sp, xa)
+        specs.append(sp); xs.append(xa); dys.append((_act(eng, h16(torch.randn(2, cout, Ho, Wo))), Ho, Wo))
+    ref = []
+    for sp, xa, (dya, Ho, Wo) in zip(specs, xs, dys):
+        eng._conv_bwd(sp, xa, dya.ptr, dya.ld, Ho, Wo)
+        torch.cuda.synchronize()
+        ref.append(sp.gweight.clone())
+        sp.gweight.zero_()
+    eng.deferred_wgrad = []
+    for sp, xa, (dya, Ho, Wo) in zip(specs, xs, dys):
+        eng._conv_bwd(sp, xa, dya.ptr, dya.ld, Ho, Wo)
+    assert len(eng.deferred_wgrad) == 3
+    eng.flush_wgrad()
+    torch.cuda.synchronize()
+    assert eng.deferred_wgrad is None
+    for sp, r in zip(specs, ref):
+        assert torch.equal(sp.gweight, r)  # same slabs, same summation order
+
+
+def test_scalseq_backward_all_levels_matches_per_level():
+    """dy_scalseq_tail_backward_all (one pass per mode) against the per-level entry point it replaced in the engine."""
+    import ctypes as C
+    eng = _eng()
+    L = eng.L
+    torch.manual_seed(5)
+    N, H, W, Cc = 2, 16, 24, 16
+    s = torch.cuda.current_stream().cuda_stream
+    r = [torch.randn(N, H >> l, W >> l, Cc, device="cuda").half() for l in range(3)]
+    dy = torch.randn(N, H, W, Cc, device="cuda").half()
+    coef = torch.stack([torch.rand(Cc) + 0.5, torch.randn(Cc) * 0.1, torch.randn(Cc) * 0.1, torch.rand(Cc) + 0.5]).cuda().contiguous()
+    rargs = (r[0].data_ptr(), Cc, r[1].data_ptr(), Cc, r[2].data_ptr(), Cc, dy.data_ptr(), Cc)
+    # mode 0: BN partial sums
+    part = torch.zeros(3 * 1024 * 2 * Cc, device="cuda")
+    tot = 0
+    for l in range(3):
+        n = C.c_int(0)
+        assert L.dy_scalseq_tail_backward(*rargs, 0, 0, coef.data_ptr(), 0, part.data_ptr() + tot * 2 * Cc * 4, 1024, N, H, W, Cc, l, 0,
+                                          C.byref(n), s) == 0
+        tot += n.value
+    torch.cuda.synchronize()
+    ref_sum = part[: tot * 2 * Cc].view(tot, 2, Cc).sum(0)
+    part2 = torch.zeros(2048 * 2 * Cc, device="cuda")
+    n = C.c_int(0)
+    assert L.dy_scalseq_tail_backward_all(*rargs, 0, 0, 0, 0, 0, 0, coef.data_ptr(), 0, part2.data_ptr(), 2048, N, H, W, Cc, 0,
+                                          C.byref(n), s) == 0
+    torch.cuda.synchronize()
+    got_sum = part2[: n.value * 2 * Cc].view(n.value, 2, Cc).sum(0)
+    assert relerr(got_sum, ref_sum) < 1e-5
+    # mode 1: dr0/dr1/dr2
+    bw = (ref_sum / (3 * N * H * W)).contiguous()
+    refs = []
+    for l in range(3):
+        d = torch.zeros(N, H >> l, W >> l, Cc, dtype=torch.float16, device="cuda")
+        assert L.dy_scalseq_tail_backward(*rargs, d.data_ptr(), Cc, coef.data_ptr(), bw.data_ptr(), 0, 0, N, H, W, Cc, l, 1, None, s) == 0
+        refs.append(d)
+    outs = [torch.zeros_like(d) for d in refs]
+    assert L.dy_scalseq_tail_backward_all(*rargs, outs[0].data_ptr(), Cc, outs[1].data_ptr(), Cc, outs[2].data_ptr(), Cc, coef.data_ptr(),
+                                          bw.data_ptr(), 0, 0, N, H, W, Cc, 1, None, s) == 0
+    torch.cuda.synchronize()
+    for l in range(3):
+        assert relerr(outs[l].float(), refs[l].float()) < 2e-3, l
