@@ -88,9 +88,10 @@ class StepPlan:
     def forward_backward(self, batch):
         """Stage the batch, run fwd+loss+bwd; gradients (scaled by the loss scale) land in rt.flat_g."""
         img = batch["img"]
-        if img.dtype == torch.uint8:
-            img = img.float() / 255
-        self.img.copy_(img, non_blocking=True)
+        if img.data_ptr() != self.img.data_ptr():  # a producer that writes straight into ``plan.img`` (the static input of the
+            if img.dtype == torch.uint8:           # recorded launch list) skips this staging copy
+                img = img.float() / 255
+            self.img.copy_(img, non_blocking=True)
         n = self.crit.set_targets(batch, cap=self.B * self.nmax)
         if n > self.B * self.nmax:
             raise RuntimeError(f"{n} targets exceed the plan capacity {self.B}x{self.nmax}")
