@@ -900,20 +900,23 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             };
             // software pipeline over the N-tiles: the scratch is written for tile t+1 as soon as tile t's reads have ISSUED
             // (not returned), so one LDS round trip hides behind the next tile's conversion instead of four in a row
-            U4 d[2][NPASS], o[2][NPASS];
+            U4 d[2][NPASS], o[ACCUM ? NT : 1][NPASS];
             TSTAMP(6)
+            if (ACCUM) {  // every old value of the tile is requested up front: one exposed HBM latency per tile, not one per N-tile
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                  bool valid;
+                  o[t][ps].u = *dest(t, ps, valid);
+                }
+            }
             convert_write(0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
               lds_order();
 #pragma unroll
-              for (int ps = 0; ps < NPASS; ++ps) {
-                d[t & 1][ps].u = *reinterpret_cast<const uint4_a*>(xr + ps * PIXPASS * XROW);
-                if (ACCUM) {
-                  bool valid;
-                  o[t & 1][ps].u = *dest(t, ps, valid);
-                }
-              }
+              for (int ps = 0; ps < NPASS; ++ps) d[t & 1][ps].u = *reinterpret_cast<const uint4_a*>(xr + ps * PIXPASS * XROW);
               lds_order();
               if (t + 1 < NT) convert_write(t + 1);
 #pragma unroll
@@ -924,7 +927,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
                 if (ACCUM) {
 #pragma unroll
                   for (int k = 0; k < 4; ++k)
-                    v.h[k] = __builtin_convertvector(__builtin_convertvector(v.h[k], f32x2) + __builtin_convertvector(o[t & 1][ps].h[k], f32x2), half2_);
+                    v.h[k] = __builtin_convertvector(__builtin_convertvector(v.h[k], f32x2) + __builtin_convertvector(o[ACCUM ? t : 0][ps].h[k], f32x2), half2_);
                 }
                 if (valid && !(a.epi & 256)) *yp = v.u;
               }
@@ -1482,19 +1485,22 @@ __global__ __launch_bounds__(512) void conv_mfma_dg2_kernel(ConvArgs a, int ntil
             char* const pz = ybase + soff * 2 + loff;
             return reinterpret_cast<uint4*>(valid ? pz : reinterpret_cast<char*>(a.y));
           };
-          U4 d[2][NPASS], o[2][NPASS];
+          U4 d[2][NPASS], o[ACCUM ? NT : 1][NPASS];
+          if (ACCUM) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int ps = 0; ps < NPASS; ++ps) {
+                bool valid;
+                o[t][ps].u = *dest(t, ps, valid);
+              }
+          }
           convert_write(0);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             lds_order();
 #pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-              d[t & 1][ps].u = *reinterpret_cast<const uint4_a*>(xr + ps * PIXPASS * XROW);
-              if (ACCUM) {
-                bool valid;
-                o[t & 1][ps].u = *dest(t, ps, valid);
-              }
-            }
+            for (int ps = 0; ps < NPASS; ++ps) d[t & 1][ps].u = *reinterpret_cast<const uint4_a*>(xr + ps * PIXPASS * XROW);
             lds_order();
             if (t + 1 < NT) convert_write(t + 1);
 #pragma unroll
@@ -1505,7 +1511,7 @@ __global__ __launch_bounds__(512) void conv_mfma_dg2_kernel(ConvArgs a, int ntil
               if (ACCUM) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                  v.h[k] = __builtin_convertvector(__builtin_convertvector(v.h[k], f32x2) + __builtin_convertvector(o[t & 1][ps].h[k], f32x2), half2_);
+                  v.h[k] = __builtin_convertvector(__builtin_convertvector(v.h[k], f32x2) + __builtin_convertvector(o[ACCUM ? t : 0][ps].h[k], f32x2), half2_);
               }
               if (valid) *yp = v.u;
             }
