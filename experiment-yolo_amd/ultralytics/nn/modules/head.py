@@ -32,6 +32,27 @@ class HeadOut:
         return [torch.cat((b, c[..., : self.nc]), -1).permute(0, 3, 1, 2) for b, c in zip(self.box, self.cls)]
 
 
+class LazyFeats:
+    """List-like view of the reference-format per-level feature maps; the cat/permute copies happen on first access."""
+
+    def __init__(self, ho):
+        self._ho, self._list = ho, None
+
+    def _get(self):
+        if self._list is None:
+            self._list = self._ho.as_reference_list()
+        return self._list
+
+    def __len__(self):
+        return len(self._ho.box)
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
+
+
 class Detect(HipModule):
     """YOLOv8 Detect head: per level cv2 = Conv3x3 -> Conv3x3 -> Conv2d1x1(64), cv3 = ... -> Conv2d1x1(nc)."""
     dynamic = False
@@ -69,7 +90,9 @@ class Detect(HipModule):
         ncp = (self.nc + 7) // 8 * 8
         nb = 4 * self.reg_max
         boxes = [torch.empty((x.N, x.H, x.W, nb), dtype=torch.float32, device=eng.device) for x in xs]
-        clss = [torch.zeros((x.N, x.H, x.W, ncp), dtype=torch.float32, device=eng.device) for x in xs]
+        # the 1x1 class conv writes channels [0, nc): padding channels (nc rounded up to 8) need a defined value only if they exist
+        alloc = torch.empty if ncp == self.nc else torch.zeros
+        clss = [alloc((x.N, x.H, x.W, ncp), dtype=torch.float32, device=eng.device) for x in xs]
         eng.hold(*boxes, *clss)
         ho = HeadOut(boxes, clss, self.nc, [float(s) for s in self.stride])
         if eng.tape is not None:
@@ -86,9 +109,10 @@ class Detect(HipModule):
 
     def _export(self, rt, y):
         if isinstance(y, HeadOut):
-            feats = y.as_reference_list()
             if self.training:
-                return feats
+                return y.as_reference_list()
             from ...utils.ops import decode_predictions
-            return decode_predictions(y), feats
+            # (y, x) like the reference's inference return (head.py:74); the per-level (B, no, H, W) maps are re-formatted from
+            # the NHWC head outputs only when somebody indexes them
+            return decode_predictions(y), LazyFeats(y)
         return super()._export(rt, y)
