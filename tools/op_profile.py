@@ -12,8 +12,9 @@ from ultralytics.hip.train import StepPlan  # noqa: E402
 from ultralytics.nn.tasks import DetectionModel  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+cfg = os.path.join(os.path.dirname(CFG), sys.argv[2] + ".yaml") if len(sys.argv) > 2 else CFG  # e.g. op_profile.py 64 yolov8n-LD-P2
 torch.manual_seed(0)
-model = DetectionModel(CFG, verbose=False).cuda().train()
+model = DetectionModel(cfg, verbose=False).cuda().train()
 plan = StepPlan(model, B, 640, nmax=8)
 batch = {k: v.cuda() for k, v in synth_batch(1, B, 640, 6).items()}
 plan.set_hyper([0.01] * 3, 0.937, [0, 5e-4, 0])
@@ -32,6 +33,9 @@ for name, a, ms in prof:
         d = f"{cin}->{cout} k{ks} s{s} @{h}x{w}"
         p = ks // 2
         by = n * h * w * cin * 2 + n * ((h + 2 * p - ks) // s + 1) * ((w + 2 * p - ks) // s + 1) * cout * 2
+    elif name == "dy_ldconv_sample_backward":
+        d = f"C={a[15]} Np={a[16]} s{a[17]} {a[11]}x{a[12]}->{a[13]}x{a[14]} n={a[10]} dx={'y' if a[7] else 'n'}"
+        by = a[10] * a[13] * a[14] * a[16] * a[15] * 2
     elif name in ("dy_bn_act_apply",):
         d = f"npix={a[7]} C={a[8]}"
         by = a[7] * a[8] * 2 * 2
