@@ -41,6 +41,8 @@ CONV_CASES = [  # cin, cout, ks, s, H, W
     (16, 32, 3, 1, 12, 20), (64, 64, 3, 1, 40, 40), (32, 64, 3, 2, 26, 34), (64, 128, 3, 2, 16, 16), (128, 64, 3, 1, 9, 11),
     (3, 16, 3, 2, 32, 48), (16, 32, 3, 2, 13, 21), (48, 32, 1, 1, 7, 9), (256, 128, 1, 1, 10, 10), (96, 64, 1, 1, 13, 5), (32, 6, 1, 1, 8, 8),
     (16, 16, 3, 1, 33, 35), (64, 80, 1, 1, 6, 6), (192, 128, 1, 1, 5, 7),
+    # padded cout group (48 -> MT = 4), 128-channel layers with narrowed cout groups, parity-class stride-2 dgrad at odd sizes
+    (32, 48, 3, 1, 10, 14), (128, 128, 3, 1, 12, 12), (64, 64, 3, 2, 15, 17), (128, 64, 3, 2, 9, 9), (64, 48, 1, 1, 11, 3),
 ]
 
 
