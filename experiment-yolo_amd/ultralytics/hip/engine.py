@@ -118,7 +118,7 @@ class Act:
 
 class Recorder:
     def __init__(self):
-        self.ops = []  # (cfunc, argtuple, name)
+        self.ops = []  # (cfunc, argtuple, name, on_side_stream); cfunc None = fork/join marker
 
 
 class ConvSpec:
@@ -156,19 +156,56 @@ class Engine:
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def call(self, name, *args):
+    def call(self, name, *args, side=False):
+        """Launch (and, while tracing, record) one C-ABI call.  ``side=True`` puts it on the engine's side stream: only for work
+        nothing on the main stream depends on until the next ``join()`` (weight gradients), bracketed by ``fork()``."""
         fn = getattr(self.L, name)
-        full = args + (self.stream,)
-        rc = fn(*full)
+        s = self.side_stream.cuda_stream if side else self.stream
+        rc = fn(*args, s)
         check(rc, name)
         if self.rec is not None:
-            self.rec.ops.append((fn, args, name))
+            self.rec.ops.append((fn, args, name, side))
+
+    # ---- two-stream plumbing: fork = "side waits for everything issued on main so far", join = "main waits for side" ----
+    side_wgrad = False      # StepPlan switches it on for its backward trace
+    _side_stream = None
+    _FORK, _JOIN = "<fork>", "<join>"
+
+    @property
+    def side_stream(self):
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(self.device)
+        return self._side_stream
+
+    def _sync(self, kind):
+        main, side = torch.cuda.current_stream(self.device), self.side_stream
+        ev = torch.cuda.Event()
+        if kind == self._FORK:
+            ev.record(main)
+            side.wait_event(ev)
+        else:
+            ev.record(side)
+            main.wait_event(ev)
+
+    def fork(self):
+        self._sync(self._FORK)
+        if self.rec is not None:
+            self.rec.ops.append((None, (), self._FORK, False))
+
+    def join(self):
+        self._sync(self._JOIN)
+        if self.rec is not None:
+            self.rec.ops.append((None, (), self._JOIN, False))
 
     def replay(self, rec):
-        """Re-issue a recorded launch list on the CURRENT stream (which may be a capturing stream)."""
+        """Re-issue a recorded launch list on the CURRENT stream (which may be a capturing stream); side-stream launches and
+        their fork/join points are reproduced (under capture they become parallel branches of the graph)."""
         s = self.stream
-        for fn, args, name in rec.ops:
-            rc = fn(*args, s)
+        for fn, args, name, side in rec.ops:
+            if fn is None:
+                self._sync(name)
+                continue
+            rc = fn(*args, self.side_stream.cuda_stream if side else s)
             if rc != 0:
                 check(rc, name)
 
@@ -317,7 +354,13 @@ class Engine:
                   spec.cout, spec.act, C.byref(n))
         self.call("dy_bn_bwd_finalize", part.data_ptr(), n.value, spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(),
                   spec.bwdcoef.data_ptr(), spec.cout, float(npix), 0)
-        draw = self.scratch("draw", npix * spec.cout * 2)
+        if self.side_wgrad and self.deferred_wgrad is not None:
+            # the weight gradient reads this buffer on the side stream while the main stream moves on to the next layer:
+            # it cannot be the shared scratch
+            draw = torch.empty(npix * spec.cout, dtype=torch.float16, device=self.device)
+            self.hold(draw)
+        else:
+            draw = self.scratch("draw", npix * spec.cout * 2)
         self.call("dy_bn_act_bwd_apply", y.gptr, y.ld, raw.ptr, raw.ld, draw.data_ptr(), spec.cout, spec.coef.data_ptr(),
                   spec.bwdcoef.data_ptr(), npix, spec.cout, spec.act, 0)
         self._conv_bwd(spec, x, draw.data_ptr(), spec.cout, y.H, y.W)
@@ -338,13 +381,18 @@ class Engine:
         else:
             slabs = self.scratch("slabs", ns.value * se.value * 4)
             dw = spec.gweight.data_ptr()
+        # deferred weight gradients are off the critical path (needed only by the batched reduction at the end of the
+        # backward pass): with ``side_wgrad`` they run on the side stream beside the input-gradient chain
+        side = deferred and self.side_wgrad
+        if side:
+            self.fork()
         if spec.ld is not None:
             n, cphys, cin = spec.ld
             self.call("dy_conv_wgrad_ld", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), dw, x.N, x.H, x.W,
-                      spec.cout, cin, n, cphys, accumulate_w)
+                      spec.cout, cin, n, cphys, accumulate_w, side=side)
         else:
             self.call("dy_conv_wgrad", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), dw, x.N, x.H, x.W,
-                      spec.cin, spec.cout, spec.ks, spec.stride, accumulate_w)
+                      spec.cin, spec.cout, spec.ks, spec.stride, accumulate_w, side=side)
         if x.needs_grad:
             acc = x.grad_target()
             self.call("dy_conv_forward", dy_ptr, lddy, spec.wpack_t.data_ptr(), 0, x.gptr, x.ld, 0, x.N, Ho, Wo,
@@ -355,6 +403,8 @@ class Engine:
     def flush_wgrad(self):
         """Reduce the slabs of every deferred layer into its fp32 weight gradient: one launch, one descriptor per layer."""
         items, self.deferred_wgrad = self.deferred_wgrad, None
+        if self.side_wgrad:
+            self.join()
         if not items:
             return
         sz = self.L.dy_wgrad_reduce_desc_bytes()

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -21,8 +22,10 @@ from .engine import Recorder
 
 class StepPlan:
     def __init__(self, model, batch_size, imgsz, nmax=16, optimizer="SGD", hyp=None, world_size=1, use_graph=False,
-                 init_scale=65536.0):
+                 init_scale=65536.0, side_wgrad=None):
         self.model = model
+        # weight gradients on a second stream beside the input-gradient chain (env DY_SIDE_WGRAD=0/1 overrides the default)
+        self.side_wgrad = bool(int(os.environ.get("DY_SIDE_WGRAD", "0"))) if side_wgrad is None else bool(side_wgrad)
         dev = next(model.parameters()).device
         self.rt = model._runtime(dev)
         self.eng = self.rt.eng
@@ -76,11 +79,13 @@ class StepPlan:
             crit.sync_modes()
             eng.call("dy_detection_loss", C.byref(crit._args))
             eng.deferred_wgrad = []
+            eng.side_wgrad = self.side_wgrad
             for f in reversed(eng.tape):
                 f()
             eng.flush_wgrad()
         finally:
             eng.deferred_wgrad = None
+            eng.side_wgrad = False
             rec, eng.rec, eng.tape = eng.rec, None, None
         self.ho = ho
         return rec
@@ -175,7 +180,7 @@ class StepPlan:
     def profile_ops(self, reps=3):
         """Event-timed, un-captured replay of the forward/backward launch list on the launch stream.
         Returns [(name, args, avg_ms)] per recorded C-ABI call."""
-        ops = self.rec_fb.ops
+        ops = [o for o in self.rec_fb.ops if o[0] is not None]  # everything on one stream here: fork/join markers dropped
         s = self.eng.stream
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 1)]
         tot = [0.0] * len(ops)
@@ -184,7 +189,7 @@ class StepPlan:
             # event intervals then hold kernel time + the back-to-back dispatch gap, not the host's ctypes launch latency
             torch.cuda._sleep(60_000_000)
             evs[0].record()
-            for i, (fn, args, name) in enumerate(ops):
+            for i, (fn, args, name, _side) in enumerate(ops):
                 rc = fn(*args, s)
                 if rc != 0:
                     check(rc, name)
