@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libdealyolo_hip.so"))
+LIB_PATH = os.environ.get("DY_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libdealyolo_hip.so"))
 
 DY_EPI_STATS, DY_EPI_BIAS, DY_EPI_SILU, DY_EPI_F32OUT, DY_EPI_ACCUM = 1, 2, 4, 8, 16
 DY_ACT_NONE, DY_ACT_SILU, DY_ACT_LEAKY = 0, 1, 2
