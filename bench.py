@@ -164,6 +164,8 @@ def main():
                 tj = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")))
                 if tj.get("kernel") == roof["kernel"]:
                     traffic = tj["traffic_bytes"]
+                else:
+                    traffic = tj.get("traffic_bytes_by_kernel", {}).get(roof["kernel"])
             except Exception:
                 pass
             roof = {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS,

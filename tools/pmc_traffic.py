@@ -32,6 +32,23 @@ def per_launch(sub, prefix, counter):
 
 fetch_kb, nf = per_launch("prof_fetch", "f", "FETCH_SIZE")
 write_kb, nw = per_launch("prof_write", "w", "WRITE_SIZE")
+
+
+def all_conv_kernels():
+    """Per-launch HBM traffic of every conv kernel instantiation (bench.py's dominant kernel can differ between boxes when
+    two instantiations have nearly the same total time)."""
+    acc = {}
+    for sub, prefix, counter, slot in (("prof_fetch", "f", "FETCH_SIZE", 0), ("prof_write", "w", "WRITE_SIZE", 1)):
+        for r in csv.DictReader(open(os.path.join(G, sub, f"{prefix}_counter_collection.csv"))):
+            name = r["Kernel_Name"]
+            if r["Counter_Name"] != counter or "conv_mfma" not in name:
+                continue
+            key = name[name.index("conv_mfma"):name.index(">") + 1] if ">" in name else name
+            e = acc.setdefault(key, [0.0, 0, 0.0, 0])
+            e[slot * 2] += float(r["Counter_Value"])
+            e[slot * 2 + 1] += 1
+    return {k: (2.0 * v[0] / max(v[1], 1) + v[2] / max(v[3], 1)) * 1024.0 for k, v in acc.items()}
+
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(G, "prof_stats", "st_kernel_stats.csv")))}
 srow = next((v for k, v in stats.items() if kern in k), None)
 out = {
@@ -46,6 +63,7 @@ out = {
     "rocprof_stats_avg_us": float(srow["AverageNs"]) / 1e3 if srow else None,
     "rocprof_stats_calls": int(srow["Calls"]) if srow else None,
     "round": tag,
+    "traffic_bytes_by_kernel": all_conv_kernels(),
 }
 json.dump(out, open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
