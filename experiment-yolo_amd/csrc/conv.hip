@@ -11,6 +11,9 @@
 #include <stdio.h>
 #include <type_traits>
 
+// measurement hook (tools/conv_bench.py DY_EPI=256): run the kernel without its output stores to price the store path
+#define DY_EPI_DEBUG_NOSTORE 256
+
 struct ConvArgs {
   const f16* x;
   const f16* w;
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
                   for (int k = 0; k < 4; ++k)
                     v.h[k] = __builtin_convertvector(__builtin_convertvector(v.h[k], f32x2) + __builtin_convertvector(o[ACCUM ? t : 0][ps].h[k], f32x2), half2_);
                 }
-                if (valid && !(a.epi & 256)) *yp = v.u;
+                if (valid && !(a.epi & DY_EPI_DEBUG_NOSTORE)) *yp = v.u;
               }
             }
           };
