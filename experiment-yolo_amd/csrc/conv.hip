@@ -1643,6 +1643,9 @@ extern "C" int dy_conv_forward(const void* x, int ldx, const void* w_packed, con
   if (cin != cp || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return DY_ERR_ALIGN;
   if (!(epi & DY_EPI_F32OUT) && (((uintptr_t)y & 15) || (ldy & 3))) return DY_ERR_ALIGN;
   if (dil != 1 && !(dil == 2 && ks == 3 && stride == 1)) return DY_ERR_ARG;
+  // the staging loads address the input through 32-bit buffer offsets: the whole tensor (1x1) or one image (3x3) must stay
+  // below 2 GiB -- fail loudly rather than wrap
+  if ((ks == 1 ? (double)n : 1.0) * h * w * ldx * 2.0 >= 2147483648.0) return DY_ERR_ARG;
   ConvArgs a{};
   a.x = (const f16*)x; a.w = (const f16*)w_packed; a.bias = bias; a.y = y; a.partials = partials;
   a.ldx = ldx; a.ldy = ldy; a.N = n; a.Hr = h; a.Wr = w;

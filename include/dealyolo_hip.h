@@ -63,6 +63,7 @@ int dy_pack_weights_batched(const void* descs_device, int n, int total_blocks, h
  * dil=2: x is read as a zero-dilated map of size (2h,2w) -- the input gradient of a stride-2 conv; out_h/out_w (>0)
  * then give the extent of the forward input (2h or 2h-1), otherwise pass 0 to derive the output extent.
  * partials: [num_partials][2][cout_p] floats, required with DY_EPI_STATS. */
+/* size limit: the input is addressed with 32-bit byte offsets -- n*h*w*ldx*2 (1x1) or h*w*ldx*2 (3x3, per image) < 2 GiB, else DY_ERR_ARG */
 int dy_conv_forward(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy, float* partials,
                     int n, int h, int w, int cin, int cout, int ks, int stride, int dil, int out_h, int out_w, int epi,
                     int* num_partials, hipStream_t stream);
