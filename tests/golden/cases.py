@@ -70,3 +70,57 @@ def loss_cases():
         "tiny": _boxes([[0, 4, 0.51, 0.49, 0.01, 0.012], [0, 2, 0.2, 0.8, 0.02, 0.02], [1, 1, 0.7, 0.3, 0.3, 0.3]]),
         "ragged": _boxes([[0, 0, 0.3, 0.3, 0.2, 0.2]] + [[1, i % 6, 0.1 + 0.08 * i, 0.5, 0.15, 0.2 + 0.02 * i] for i in range(9)]),
     }
+
+
+def metric_cases():
+    """Synthetic detection/label sets for the validation path: (name, seed, n_images, nc, max_labels, max_dets, jitter)."""
+    return [("small", 11, 4, 3, 6, 12, 0.04), ("crowded", 12, 3, 2, 24, 60, 0.08), ("sparse", 13, 5, 6, 3, 5, 0.02),
+            ("large", 14, 6, 6, 40, 300, 0.06)]
+
+
+def metric_geometry(name, n_images, imgsz=640):
+    """Per image (ori_shape (h, w), ratio_pad ((gain, gain), (padw, padh))) as the dataloader would report it: identity for
+    most cases, a letterboxed 480x640 / 1080x1920 original for the images of 'crowded' and 'large'."""
+    out = []
+    for i in range(n_images):
+        if name == "crowded":
+            out.append(((480, 640), ((1.0, 1.0), (0.0, 80.0))))
+        elif name == "large" and i % 2:
+            g = imgsz / 1920
+            out.append(((1080, 1920), ((g, g), (0.0, round((imgsz - 1080 * g) / 2 - 0.1)))))
+        else:
+            out.append(((imgsz, imgsz), ((1.0, 1.0), (0.0, 0.0))))
+    return out
+
+
+def synth_detections(seed, n_images, nc, max_labels, max_dets, jitter, imgsz=640):
+    """Per image: labels (cls, normalised xywh) and NMS-style detections (xyxy px, conf, cls) sorted by confidence: each label
+    spawns 0-3 jittered detections (some with the wrong class), plus random false positives; image 0 has no detections and the
+    last image has no labels when n_images > 3."""
+    rng = np.random.default_rng(seed)
+    batch_idx, cls, bboxes, preds = [], [], [], []
+    for i in range(n_images):
+        nl = 0 if (i == n_images - 1 and n_images > 3) else int(rng.integers(1, max_labels + 1))
+        c = rng.integers(0, nc, nl)
+        xy = rng.random((nl, 2)) * 0.7 + 0.15
+        wh = rng.random((nl, 2)) * 0.25 + 0.03
+        batch_idx += [i] * nl
+        cls += list(c)
+        bboxes += list(np.concatenate([xy, wh], 1))
+        dets = []
+        if i != 0:
+            for k in range(nl):
+                for _ in range(int(rng.integers(0, 4))):
+                    d_xy = xy[k] + rng.normal(0, jitter, 2) * wh[k] * 4
+                    d_wh = wh[k] * np.exp(rng.normal(0, jitter * 3, 2))
+                    dc = c[k] if rng.random() > 0.15 else rng.integers(0, nc)
+                    dets.append([*(d_xy - d_wh / 2) * imgsz, *(d_xy + d_wh / 2) * imgsz, rng.random() * 0.9 + 0.05, dc])
+            for _ in range(int(rng.integers(0, max(2, max_dets // 4)))):
+                f_xy, f_wh = rng.random(2) * 0.8 + 0.1, rng.random(2) * 0.2 + 0.02
+                dets.append([*(f_xy - f_wh / 2) * imgsz, *(f_xy + f_wh / 2) * imgsz, rng.random() * 0.6 + 0.01, rng.integers(0, nc)])
+        dets = np.asarray(dets, dtype=np.float32).reshape(-1, 6)
+        dets = dets[np.argsort(-dets[:, 4], kind="stable")][:max_dets]
+        preds.append(dets)
+    batch = dict(batch_idx=np.asarray(batch_idx, dtype=np.float32), cls=np.asarray(cls, dtype=np.float32).reshape(-1, 1),
+                 bboxes=np.asarray(bboxes, dtype=np.float32).reshape(-1, 4))
+    return batch, preds

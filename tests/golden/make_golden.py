@@ -39,7 +39,7 @@ from ultralytics.utils.metrics import WiseIouLoss  # noqa: E402
 from ultralytics.utils.torch_utils import ModelEMA, initialize_weights  # noqa: E402
 
 from oracle import graph as og  # noqa: E402
-from cases import MODES, loss_cases, module_cases, module_shapes, rnd, synth_batch  # noqa: E402
+from cases import MODES, loss_cases, metric_cases, metric_geometry, module_cases, module_shapes, rnd, synth_batch, synth_detections  # noqa: E402
 
 CFG_DIR = os.path.join(_refimport.REF, "ultralytics/cfg/models")
 torch.set_num_threads(8)
@@ -409,7 +409,55 @@ def gen_fullsize():
     npz("fullsize", **arrs)
 
 
+
+def gen_metrics():
+    """Validation path: the reference's own box_iou, BaseValidator.match_predictions (numpy greedy
+    matching) and ap_per_class on synthetic detection sets, plus DetMetrics.mean_results."""
+    from ultralytics.engine.validator import BaseValidator
+    from ultralytics.utils.metrics import DetMetrics, ap_per_class, box_iou
+    arrs = {}
+    iouv = torch.linspace(0.5, 0.95, 10)
+    holder = SimpleNamespace(iouv=iouv)
+    for name, seed, n_images, nc, max_labels, max_dets, jitter in metric_cases():
+        batch, preds = synth_detections(seed, n_images, nc, max_labels, max_dets, jitter)
+        geo = metric_geometry(name, n_images)
+        stats = dict(tp=[], conf=[], pred_cls=[], target_cls=[])
+        for si, pred in enumerate(preds):
+            # DetectionValidator._prepare_batch / _prepare_pred (models/yolo/detect/val.py:93-115), verbatim call sequence
+            idx = batch["batch_idx"] == si
+            tcls = torch.from_numpy(batch["cls"][idx]).squeeze(-1)
+            ori_shape, ratio_pad = geo[si]
+            tbox = torch.from_numpy(batch["bboxes"][idx])
+            if len(tcls):
+                tbox = ops.xywh2xyxy(tbox) * torch.tensor((640, 640))[[1, 0, 1, 0]]
+                ops.scale_boxes((640, 640), tbox, ori_shape, ratio_pad=ratio_pad)
+            pred = torch.from_numpy(pred).clone()
+            ops.scale_boxes((640, 640), pred[:, :4], ori_shape, ratio_pad=ratio_pad)
+            tp = torch.zeros(len(pred), 10, dtype=torch.bool)
+            if len(pred) and len(tcls):
+                iou = box_iou(tbox, pred[:, :4])
+                tp = BaseValidator.match_predictions(holder, pred[:, 5], tcls, iou)
+                arrs[f"{name}/iou{si}"] = iou
+            arrs[f"{name}/tp{si}"] = tp
+            if len(pred) == 0 and len(tcls) == 0:
+                continue
+            if len(pred) == 0:
+                stats["tp"].append(tp); stats["conf"].append(torch.zeros(0)); stats["pred_cls"].append(torch.zeros(0))
+            else:
+                stats["tp"].append(tp); stats["conf"].append(pred[:, 4]); stats["pred_cls"].append(pred[:, 5])
+            stats["target_cls"].append(tcls)
+        st = {k: torch.cat(v, 0).numpy() for k, v in stats.items()}
+        res = ap_per_class(st["tp"], st["conf"], st["pred_cls"], st["target_cls"], plot=False, names={i: str(i) for i in range(nc)})
+        for key, v in zip(("tp_c", "fp_c", "p", "r", "f1", "ap", "classes", "p_curve", "r_curve", "f1_curve"), res[:10]):
+            arrs[f"{name}/{key}"] = v
+        dm = DetMetrics(names={i: str(i) for i in range(nc)})
+        dm.process(st["tp"], st["conf"], st["pred_cls"], st["target_cls"])
+        arrs[f"{name}/mean_results"] = np.asarray(dm.mean_results(), dtype=np.float64)  # mp, mr, map50, map
+        arrs[f"{name}/fitness"] = np.asarray(dm.fitness)
+    npz("metrics", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["modules", "models", "loss", "nms", "trainer", "fullsize"]
+    which = sys.argv[1:] or ["modules", "models", "loss", "nms", "trainer", "fullsize", "metrics"]
     for w in which:
         globals()["gen_" + w]()
