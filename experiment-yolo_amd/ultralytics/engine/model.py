@@ -53,5 +53,12 @@ class YOLO:
 
     __call__ = predict
 
-    def val(self, **kw):
-        raise NotImplementedError("validation / mAP is the first 'next' row of SURVEY.md section 8f")
+    def val(self, data=None, **kw):
+        """``data``: a re-iterable of batch dicts (as for ``train``).  Returns the metrics dict of the reference's
+        DetMetrics.results_dict (precision, recall, mAP50, mAP50-95, fitness)."""
+        if data is None or isinstance(data, (str, Path)):
+            raise NotImplementedError("dataset YAML loading belongs to the CPU data pipeline (SURVEY.md section 8f); pass an "
+                                      "iterable of batch dicts")
+        from ..models.yolo.detect import DetectionValidator
+        self.validator = DetectionValidator(dataloader=data, args=kw or None)
+        return self.validator(model=self.model)

@@ -44,6 +44,8 @@ SIGNATURES = {
     "dy_wgrad_reduce_desc_bytes": (i32, []),
     "dy_wgrad_reduce_desc_fill": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32]),
     "dy_wgrad_reduce_batched": (i32, [vp, i32, i32, vp]),
+    "dy_match_predictions": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "dy_box_iou": (i32, [vp, i32, vp, i32, vp, vp]),
     "dy_conv_num_partials": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "dy_wgrad_workspace": (i32, [i32, i32, i32, i32, i32, i32, i32, ip, lp]),
     "dy_conv_wgrad": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -199,6 +199,18 @@ int dy_optimizer_step(float* params, const float* grads, float* mom, float* adam
                       long n_buffers, const float* hyper, float* state, float* partials, int mode, hipStream_t stream);
 int dy_axpy_f32(float* y, const float* x, float a, long n, hipStream_t stream);
 
+/* ---- validation: the per-batch half of DetectionValidator.update_metrics in ONE launch --
+ *      _prepare_batch/_prepare_pred (models/yolo/detect/val.py:93-115: xywh2xyxy * imgsz, scale_boxes + clip_boxes),
+ *      box_iou (utils/metrics.py:53-73) and BaseValidator.match_predictions (engine/validator.py:217-257, numpy path).
+ *      preds (Ntot,6) x1 y1 x2 y2 conf cls packed over the batch, pred_off (B+1); targets as the collate function gives
+ *      them (batch_idx, cls, xywh normalised); geom (B,5) = gain, padw, padh, ori_h, ori_w per image; iouv (niou <= 16);
+ *      tp (Ntot,niou) uint8; predn (Ntot,6) native-space predictions or NULL; *status |= 1 if an image has > 1024 labels. */
+int dy_match_predictions(const float* preds, const int* pred_off, const float* t_batch_idx, const float* t_cls,
+                         const float* t_boxes, int n_targets, const float* geom, const float* iouv, int niou, int B,
+                         int img_h, int img_w, unsigned char* tp, float* predn, int* status, hipStream_t stream);
+/* utils/metrics.py:53-73 box_iou: (n,4) x (m,4) xyxy fp32 -> (n,m) */
+int dy_box_iou(const float* box1, int n, const float* box2, int m, float* out, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,3 +31,20 @@ def test_oracle_metrics_vs_reference(golden, case):
     assert (res["classes"] == G[f"{name}/classes"]).all()
     assert np.allclose(om.mean_results(res), G[f"{name}/mean_results"], atol=1e-12)
     assert abs(om.fitness(res) - float(G[f"{name}/fitness"])) < 1e-12
+
+
+@pytest.mark.parametrize("case", metric_cases(), ids=lambda c: c[0])
+def test_host_ap_per_class_mirror_vs_reference(golden, case):
+    """ultralytics.utils.metrics.ap_per_class / DetMetrics (host arithmetic of the product) on the oracle's statistics."""
+    from ultralytics.utils.metrics import DetMetrics, ap_per_class
+    name, seed, n_images, nc, ml, md, jit = case
+    G = golden("metrics")
+    batch, preds = synth_detections(seed, n_images, nc, ml, md, jit)
+    st = {k: np.concatenate(v, 0) for k, v in om.validate_batch(preds, batch, geometry=metric_geometry(name, n_images)).items()}
+    out = ap_per_class(st["tp"], st["conf"], st["pred_cls"], st["target_cls"])
+    for got, gk in zip(out[:10], ("tp_c", "fp_c", "p", "r", "f1", "ap", "classes", "p_curve", "r_curve", "f1_curve")):
+        assert np.allclose(got, G[f"{name}/{gk}"], atol=1e-12), gk
+    dm = DetMetrics(names={i: str(i) for i in range(nc)})
+    dm.process(st["tp"], st["conf"], st["pred_cls"], st["target_cls"])
+    assert np.allclose(dm.mean_results(), G[f"{name}/mean_results"], atol=1e-12)
+    assert abs(dm.fitness - float(G[f"{name}/fitness"])) < 1e-12
