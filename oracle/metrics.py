@@ -56,7 +56,7 @@ def compute_ap(recall, precision):
     mpre = np.concatenate(([1.0], precision, [0.0]))
     mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
     x = np.linspace(0, 1, 101)
-    return np.trapz(np.interp(x, mrec, mpre), x)
+    return (getattr(np, "trapezoid", None) or np.trapz)(np.interp(x, mrec, mpre), x)
 
 
 def ap_per_class(tp, conf, pred_cls, target_cls, eps=1e-16):
