@@ -22,6 +22,11 @@ def test_product_does_not_touch_oracle_or_reference():
         assert "/root/reference" not in src or path.endswith(".h"), f"{path} reads the reference tree"
 
 
+def test_tools_do_not_import_oracle():
+    for path in _py_files(os.path.join(ROOT, "tools")):
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", open(path).read(), flags=re.M), f"{path} imports the oracle"
+
+
 def test_gpu_side_entry_points_do_not_read_reference():
     for f in ("bench.py", "__graft_entry__.py"):
         assert "/root/reference" not in open(os.path.join(ROOT, f)).read()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Validation-path measurement: images/s of DetectionValidator.update_metrics (one
+"""(Lives under tests/ because it times the CPU oracle beside the HIP path: only tests/, smoke() and bench.py's cpu_baseline
+leg may touch oracle/.)  Validation-path measurement: images/s of DetectionValidator.update_metrics (one
 dy_match_predictions launch per batch) next to the CPU oracle's per-image loop (the reference's structure: IoU matrix to the
 host, numpy sort/unique per threshold), and an end-to-end YOLO.val() on synthetic batches.
 usage: val_bench.py [batch] [dets_per_image] [labels_per_image]"""
