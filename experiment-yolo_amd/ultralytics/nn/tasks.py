@@ -306,11 +306,67 @@ class DetectionModel(BaseModel):
         return v8DetectionLoss(self)
 
 
+class _Opaque:
+    """Stand-in for a pickled class this package does not define (loss objects, namespaces, callbacks ... hanging off a
+    reference checkpoint): takes any state and is never executed."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+
+
+def torch_safe_load(weight):
+    """torch.load for checkpoints in the reference's on-disk format (reference tasks.py:649-703): whole-module pickles
+    whose class paths (``ultralytics.nn.modules.conv.Conv`` ...) resolve to this package's classes of the same name;
+    classes under ``ultralytics.*`` that do not exist here unpickle as inert ``_Opaque`` objects.  Returns (ckpt, file)."""
+    import pickle
+    import types
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                if module.split(".")[0] == "ultralytics":
+                    return type(name, (_Opaque,), {"__module__": module})
+                raise
+
+    shim = types.SimpleNamespace(Unpickler=_Unpickler, load=pickle.load, loads=pickle.loads, __name__="pickle")
+    ckpt = torch.load(weight, map_location="cpu", weights_only=False, pickle_module=shim)
+    if not isinstance(ckpt, dict):
+        ckpt = {"model": ckpt}
+    return ckpt, weight
+
+
+def _rebuild(src, ckpt):
+    """A usable DetectionModel from what a checkpoint carries: a pickled module (reference or ours: only its ``yaml`` and
+    ``state_dict()`` are trusted -- the unpickled object itself never ran this package's constructors) or a state dict
+    next to a ``yaml`` entry (this package's trainer)."""
+    if isinstance(src, nn.Module):
+        cfg, sd = getattr(src, "yaml", None), src.state_dict()
+        names, args = getattr(src, "names", None), getattr(src, "args", None)
+    else:
+        cfg, sd, names, args = ckpt.get("yaml"), src, None, None
+    if not isinstance(cfg, dict):
+        raise TypeError("checkpoint carries no model YAML: cannot rebuild the network")
+    model = DetectionModel(deepcopy(cfg), ch=cfg.get("ch", 3), verbose=False)
+    model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    if isinstance(names, dict) and len(names) == len(model.names):
+        model.names = names
+    model.args = ckpt.get("train_args", args if isinstance(args, dict) else {})
+    model.pt_path = None
+    return model
+
+
 def attempt_load_weights(weights, device=None, inplace=True, fuse=False):
-    """Load a checkpoint written by the trainer (reference tasks.py:706-746): whole-module pickles or state dicts."""
-    ckpt = torch.load(weights, map_location="cpu", weights_only=False)
-    model = (ckpt.get("ema") or ckpt["model"]) if isinstance(ckpt, dict) else ckpt
-    model = model.float()
+    """Load a checkpoint (reference tasks.py:706-777 attempt_load_weights / attempt_load_one_weight): the reference's
+    whole-module ``.pt`` files (fp16 ``model`` / ``ema``) as well as this package's state-dict checkpoints."""
+    ckpt, _ = torch_safe_load(weights)
+    src = ckpt.get("ema") if ckpt.get("ema") is not None else ckpt["model"]
+    model = _rebuild(src, ckpt)
     if device is not None:
         model = model.to(device)
     if fuse and hasattr(model, "fuse"):

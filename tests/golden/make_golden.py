@@ -457,6 +457,23 @@ def gen_metrics():
     npz("metrics", **arrs)
 
 
+
+def gen_ckpt():
+    """A checkpoint in the reference's on-disk format (engine/trainer.py:898-923: whole-module pickle, fp16) holding the
+    REFERENCE DetectionModel built from its own YAML with the shared deterministic state: exercises the loader of
+    ultralytics.nn.tasks.attempt_load_weights.  The file is data: tensors + class paths."""
+    from copy import deepcopy
+    name = "yolov8n-ASF-P2P2"
+    m = DetectionModel(os.path.join(CFG_DIR, name + ".yaml"), ch=3, verbose=False)
+    g = og.build_graph(og.load_yaml(os.path.join(CFG_DIR, name + ".yaml")))
+    m.load_state_dict(og.fill_state(og.state_layout(g), 21), strict=True)
+    m.args = dict(get_cfg(DEFAULT_CFG).__dict__) if not hasattr(m, "args") else m.args
+    ckpt = {"epoch": 3, "best_fitness": 0.25, "model": deepcopy(m).half(), "ema": None, "updates": 57, "optimizer": None,
+            "train_args": {"imgsz": 640, "batch": 64, "model": name + ".yaml"}, "date": "2026-01-01T00:00:00", "version": "8.1.9"}
+    path = os.path.join(HERE, "ref_ckpt.pt")
+    torch.save(ckpt, path)
+    print(f"ref_ckpt.pt  {os.path.getsize(path) / 1024:.1f} KiB")
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["modules", "models", "loss", "nms", "trainer", "fullsize", "metrics"]
     for w in which:

@@ -135,3 +135,20 @@ def test_optimizer_trace_vs_golden(golden):
         fl = torch.cat([plan.rt.flat_p, plan.rt.flat_b]).double().abs().sum()
         assert abs(float(fl) - row[10]) < 2e-4 * row[10], "abs-sum of the state after the step"
     assert relerr(m.state_dict()["model.0.conv.weight"], G.t("SGD/final_w0")) < 2e-2
+
+
+def test_reference_checkpoint_runs_like_a_native_model():
+    """A model rebuilt from the reference-format checkpoint (tests/golden/ref_ckpt.pt) computes exactly what a natively built
+    model with the same (fp16-rounded) state computes."""
+    import os
+    from conftest import ROOT
+    from ultralytics.nn.tasks import DetectionModel, attempt_load_weights
+    a = attempt_load_weights(os.path.join(ROOT, "tests", "golden", "ref_ckpt.pt"), device="cuda:0")
+    b = DetectionModel(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"), ch=3, verbose=False)
+    g = og.build_graph(og.load_yaml(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml")))
+    b.load_state_dict({k: (v.half().float() if v.is_floating_point() else v) for k, v in og.fill_state(og.state_layout(g), 21).items()})
+    b.cuda().eval()
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(4)).cuda()
+    ya, _ = a(x)
+    yb, _ = b(x)
+    assert torch.equal(ya, yb)

@@ -65,3 +65,26 @@ def test_optimizer_groups_match_reference(golden):
     assert [len(g) for g in groups] == G["SGD/group_sizes"].tolist()
     ref = param_groups(m.state_dict().keys())
     assert [sorted(g) for g in groups] == [sorted(g) for g in ref]
+
+
+def test_load_reference_format_checkpoint():
+    """tests/golden/ref_ckpt.pt is a whole-module fp16 pickle written by the REFERENCE classes (make_golden.py::gen_ckpt, the
+    on-disk format of engine/trainer.py:898-923).  attempt_load_weights must rebuild this package's DetectionModel from it."""
+    import os
+    import torch
+    from oracle import graph as og
+    from conftest import CFG_DIR, ROOT
+    from ultralytics.nn.tasks import DetectionModel, attempt_load_weights, torch_safe_load
+    path = os.path.join(ROOT, "tests", "golden", "ref_ckpt.pt")
+    ckpt, _ = torch_safe_load(path)
+    assert ckpt["epoch"] == 3 and ckpt["updates"] == 57 and ckpt["ema"] is None
+    m = attempt_load_weights(path)
+    assert isinstance(m, DetectionModel) and not m.training
+    g = og.build_graph(og.load_yaml(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml")))
+    want = og.fill_state(og.state_layout(g), 21)
+    got = m.state_dict()
+    assert set(got) == set(want)
+    for k, v in want.items():
+        ref = v.half().float() if v.is_floating_point() else v  # the reference stores .half() weights
+        assert torch.equal(got[k].cpu().float(), ref.float()), k
+    assert m.args.get("imgsz") == 640
