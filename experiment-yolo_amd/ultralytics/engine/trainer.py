@@ -114,8 +114,12 @@ class DetectionTrainer:
                             f"{nb * batch_size * self.world_size / (time.time() - t0):.1f} img/s")
         return hist
 
-    def save_model(self, path):
-        """state_dict checkpoint (model + EMA); whole-module pickles of the reference format are a section 8f item."""
+    def save_model(self, path, reference_format=False):
+        """state_dict checkpoint (model + EMA), or -- ``reference_format=True`` -- the reference's whole-module fp16 layout
+        (engine/trainer.py:898-923) that the reference's ``attempt_load_weights`` reads directly."""
+        if reference_format:
+            from ..nn.tasks import save_reference_format
+            return save_reference_format(path, self.model, ema=self.ema.ema, updates=self.plan.ema_updates, train_args=vars(self.args))
         torch.save({"model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
                     "ema": {k: v.detach().cpu() for k, v in self.ema.state_dict().items()},
                     "updates": self.plan.ema_updates, "train_args": vars(self.args), "yaml": self.model.yaml}, path)

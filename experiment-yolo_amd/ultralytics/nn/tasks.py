@@ -361,6 +361,50 @@ def _rebuild(src, ckpt):
     return model
 
 
+def reference_module_copy(model):
+    """A detached fp16 copy of ``model`` shaped like the object the reference pickles (engine/trainer.py:907-908
+    ``deepcopy(model).half()``): same class paths and attribute names, no engine state, ``nn.Upsample`` for the up-sampling
+    layers, the ``anchors`` / ``strides`` / ``args`` / ``warehouse_manager`` attributes the reference's classes expect.
+    The reference unpickles it into its own classes and runs it; LDConv's backward hook is not part of a pickle and the
+    reference re-registers it only when it builds the module itself."""
+    stash = {}
+    for m in model.modules():
+        stash[m] = {k: m.__dict__.pop(k) for k in ("rt", "_pn_i32") if k in m.__dict__}
+    try:
+        cp = deepcopy(model)
+    finally:
+        for m, d in stash.items():
+            m.__dict__.update(d)
+    cp = cp.cpu().half()
+    cp.__dict__.pop("_cout", None)
+    cp.__dict__.setdefault("warehouse_manager", None)
+    if not isinstance(cp.__dict__.get("args"), dict):
+        cp.__dict__["args"] = {}
+    seq = cp.model
+    for name, m in list(seq._modules.items()):
+        if isinstance(m, Upsample):
+            up = nn.Upsample(m.size, m.scale_factor, m.mode)
+            for k in ("i", "f", "type", "np"):
+                if hasattr(m, k):
+                    setattr(up, k, getattr(m, k))
+            seq._modules[name] = up
+        elif isinstance(m, Detect):
+            m.__dict__.setdefault("shape", None)
+            m.__dict__["anchors"], m.__dict__["strides"] = torch.empty(0), torch.empty(0)
+    return cp
+
+
+def save_reference_format(path, model, ema=None, updates=0, epoch=-1, best_fitness=None, train_args=None):
+    """Write a checkpoint with the reference's keys and object layout (engine/trainer.py:898-923); ``attempt_load_weights``
+    of either side reads it back."""
+    import datetime
+    ckpt = {"epoch": epoch, "best_fitness": best_fitness, "model": reference_module_copy(model),
+            "ema": reference_module_copy(ema) if ema is not None else None, "updates": updates, "optimizer": None,
+            "train_args": dict(train_args or {}), "date": datetime.datetime.now().isoformat(), "version": "8.1.9"}
+    torch.save(ckpt, path)
+    return path
+
+
 def attempt_load_weights(weights, device=None, inplace=True, fuse=False):
     """Load a checkpoint (reference tasks.py:706-777 attempt_load_weights / attempt_load_one_weight): the reference's
     whole-module ``.pt`` files (fp16 ``model`` / ``ema``) as well as this package's state-dict checkpoints."""

@@ -88,3 +88,24 @@ def test_load_reference_format_checkpoint():
         ref = v.half().float() if v.is_floating_point() else v  # the reference stores .half() weights
         assert torch.equal(got[k].cpu().float(), ref.float()), k
     assert m.args.get("imgsz") == 640
+
+
+def test_reference_format_checkpoint_roundtrip(tmp_path):
+    """save_reference_format -> attempt_load_weights: weights survive (as fp16), the pickled object carries no engine state
+    and has the attribute layout the reference's classes expect (checked against the reference itself in the build container
+    by tests/golden/check_export.py)."""
+    import os
+    import torch
+    import torch.nn as nn
+    from conftest import CFG_DIR
+    from ultralytics.nn.tasks import DetectionModel, attempt_load_weights, save_reference_format, torch_safe_load
+    m = DetectionModel(os.path.join(CFG_DIR, "yolov8n-LD-P2.yaml"), ch=3, verbose=False)
+    path = save_reference_format(str(tmp_path / "last.pt"), m, updates=9, epoch=2, train_args={"imgsz": 640})
+    ckpt, _ = torch_safe_load(path)
+    obj = ckpt["model"]
+    assert ckpt["updates"] == 9 and next(obj.parameters()).dtype == torch.float16
+    assert all("rt" not in mod.__dict__ and "_pn_i32" not in mod.__dict__ for mod in obj.modules())
+    assert any(type(mod) is nn.Upsample for mod in obj.modules()) and obj.model[-1].anchors.numel() == 0 and obj.warehouse_manager is None
+    back = attempt_load_weights(path)
+    for (k, a), (_, b) in zip(m.state_dict().items(), back.state_dict().items()):
+        assert torch.equal(a.half().float() if a.is_floating_point() else a, b if not b.is_floating_point() else b.float()), k
