@@ -31,8 +31,8 @@ def test_gpu_side_entry_points_do_not_read_reference():
     for f in ("bench.py", "__graft_entry__.py"):
         assert "/root/reference" not in open(os.path.join(ROOT, f)).read()
     for path in _py_files(os.path.join(ROOT, "tests")):
-        if os.sep + "golden" + os.sep in path and os.path.basename(path) in ("make_golden.py", "_refimport.py"):
-            continue  # fixture generator: build container only
+        if os.sep + "golden" + os.sep in path and os.path.basename(path) in ("make_golden.py", "_refimport.py", "check_export.py"):
+            continue  # fixture generator / export check: build container only
         assert "/root/reference" not in open(path).read() or os.path.basename(path) == "test_layout.py", path
 
 
