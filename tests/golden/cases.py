@@ -124,3 +124,27 @@ def synth_detections(seed, n_images, nc, max_labels, max_dets, jitter, imgsz=640
     batch = dict(batch_idx=np.asarray(batch_idx, dtype=np.float32), cls=np.asarray(cls, dtype=np.float32).reshape(-1, 1),
                  bboxes=np.asarray(bboxes, dtype=np.float32).reshape(-1, 4))
     return batch, preds
+
+
+def planted_batches(seed, n_batches, B, imgsz, nc, k=3, wh=(0.12, 0.35)):
+    """Learnable synthetic detection data: dim noise background, k axis-aligned rectangles per image whose
+    colour identifies the class.  Returns a list of batch dicts of numpy arrays (img float32 in [0,1], batch_idx, cls, bboxes)."""
+    palette = np.array([[0.9, 0.1, 0.1], [0.1, 0.9, 0.1], [0.1, 0.1, 0.9], [0.9, 0.9, 0.1], [0.9, 0.1, 0.9], [0.1, 0.9, 0.9],
+                        [0.9, 0.5, 0.1], [0.5, 0.1, 0.9]], np.float32)
+    out = []
+    for b in range(n_batches):
+        rng = np.random.default_rng(seed * 7919 + b)
+        img = rng.random((B, 3, imgsz, imgsz), dtype=np.float32) * 0.25
+        bi, cl, bb = [], [], []
+        for i in range(B):
+            for _ in range(k):
+                c = int(rng.integers(0, nc))
+                w, h = rng.random(2) * (wh[1] - wh[0]) + wh[0]
+                cx, cy = rng.random() * (1 - w) + w / 2, rng.random() * (1 - h) + h / 2
+                x1, x2 = int((cx - w / 2) * imgsz), int((cx + w / 2) * imgsz)
+                y1, y2 = int((cy - h / 2) * imgsz), int((cy + h / 2) * imgsz)
+                img[i, :, y1:y2, x1:x2] = palette[c][:, None, None] + rng.random((3, y2 - y1, x2 - x1), dtype=np.float32) * 0.1
+                bi.append(i); cl.append(c); bb.append([cx, cy, w, h])
+        out.append(dict(img=img, batch_idx=np.asarray(bi, np.float32), cls=np.asarray(cl, np.float32).reshape(-1, 1),
+                        bboxes=np.asarray(bb, np.float32)))
+    return out

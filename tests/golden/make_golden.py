@@ -39,7 +39,7 @@ from ultralytics.utils.metrics import WiseIouLoss  # noqa: E402
 from ultralytics.utils.torch_utils import ModelEMA, initialize_weights  # noqa: E402
 
 from oracle import graph as og  # noqa: E402
-from cases import MODES, loss_cases, metric_cases, metric_geometry, module_cases, module_shapes, rnd, synth_batch, synth_detections  # noqa: E402
+from cases import MODES, loss_cases, metric_cases, metric_geometry, module_cases, planted_batches, module_shapes, rnd, synth_batch, synth_detections  # noqa: E402
 
 CFG_DIR = os.path.join(_refimport.REF, "ultralytics/cfg/models")
 torch.set_num_threads(8)
@@ -473,6 +473,89 @@ def gen_ckpt():
     path = os.path.join(HERE, "ref_ckpt.pt")
     torch.save(ckpt, path)
     print(f"ref_ckpt.pt  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+MAP_PROTOCOL = dict(name="yolov8n-ASF-P2P2", nc=4, imgsz=320, batch=16, nb=8, epochs=30, nval=2, init_seed=5)
+
+
+def gen_map():
+    """mAP parity protocol (north-star: 'mAP50 on a held-out synthetic set within +-0.2 of the reference'): the REFERENCE
+    model / loss / build_optimizer / optimizer_step / ModelEMA train DEAL-YOLO-N for 30 epochs x 8 batches of 16 planted-
+    rectangle images (320x320, 4 classes, no augmentation), driven as engine/trainer.py:780-815 does, from the shared
+    reference-like initial state; the EMA model is then scored on 32 held-out images with the reference's own
+    non_max_suppression (conf 0.001, iou 0.7, multi_label) + match_predictions + ap_per_class."""
+    import time
+    from ultralytics.engine.validator import BaseValidator
+    from ultralytics.utils.metrics import DetMetrics, box_iou
+    P = MAP_PROTOCOL
+    cfg = os.path.join(CFG_DIR, P["name"] + ".yaml")
+    y = og.load_yaml(cfg)
+    y["nc"] = P["nc"]
+    g = og.build_graph(y)
+    torch.manual_seed(0)
+    m = DetectionModel(cfg, ch=3, nc=P["nc"], verbose=False)
+    args = get_cfg(DEFAULT_CFG)
+    m.args = args
+    m.load_state_dict(og.default_init_state(g, seed=P["init_seed"]), strict=True)
+    for k, v in m.named_parameters():
+        v.requires_grad = ".dfl" not in k
+    bs, nb, epochs = P["batch"], P["nb"], P["epochs"]
+    fake = SimpleNamespace(args=args, model=m)
+    accumulate = max(round(args.nbs / bs), 1)
+    wd = args.weight_decay * bs * accumulate / args.nbs
+    fake.optimizer = BaseTrainer.build_optimizer(fake, model=m, name="SGD", lr=args.lr0, momentum=args.momentum, decay=wd)
+    fake.scaler = torch.cuda.amp.GradScaler(enabled=False)
+    fake.ema = ModelEMA(m)
+    lf = lambda x: max(1 - x / epochs, 0) * (1.0 - args.lrf) + args.lrf  # noqa: E731
+    for pg in fake.optimizer.param_groups:
+        pg["initial_lr"] = pg["lr"]
+    nw = max(round(args.warmup_epochs * nb), 100)
+    last_opt_step = -1
+    train = [{k: torch.from_numpy(v) for k, v in b.items()} for b in planted_batches(1, nb, bs, P["imgsz"], P["nc"])]
+    hist = []
+    t0 = time.time()
+    for epoch in range(epochs):
+        m.train()
+        for j, x in enumerate(fake.optimizer.param_groups):  # scheduler.step() value of this epoch (LambdaLR on initial_lr)
+            x["lr"] = x["initial_lr"] * lf(epoch)
+        tl = None
+        for i, batch in enumerate(train):
+            ni = i + nb * epoch
+            if ni <= nw:
+                xi = [0, nw]
+                accumulate = max(1, int(np.interp(ni, xi, [1, args.nbs / bs]).round()))
+                for j, x in enumerate(fake.optimizer.param_groups):
+                    x["lr"] = np.interp(ni, xi, [args.warmup_bias_lr if j == 0 else 0.0, x["initial_lr"] * lf(epoch)])
+                    if "momentum" in x:
+                        x["momentum"] = np.interp(ni, xi, [args.warmup_momentum, args.momentum])
+            loss, items = m(batch)
+            loss.backward()
+            if ni - last_opt_step >= accumulate:
+                BaseTrainer.optimizer_step(fake)
+                last_opt_step = ni
+            tl = items if tl is None else (tl * i + items) / (i + 1)
+        hist.append(tl.detach().numpy().copy())
+        print(f"epoch {epoch + 1}/{epochs} {hist[-1].round(3)}  {time.time() - t0:.0f}s", flush=True)
+    ema = fake.ema.ema.eval()
+    holder = SimpleNamespace(iouv=torch.linspace(0.5, 0.95, 10))
+    stats = dict(tp=[], conf=[], pred_cls=[], target_cls=[])
+    with torch.no_grad():
+        for b in planted_batches(2, P["nval"], bs, P["imgsz"], P["nc"]):
+            preds = ops.non_max_suppression(ema(torch.from_numpy(b["img"])), 0.001, 0.7, multi_label=True, max_det=300)
+            for si, pred in enumerate(preds):
+                idx = b["batch_idx"] == si
+                tcls = torch.from_numpy(b["cls"][idx]).squeeze(-1)
+                tbox = ops.xywh2xyxy(torch.from_numpy(b["bboxes"][idx])) * P["imgsz"]
+                tp = torch.zeros(len(pred), 10, dtype=torch.bool)
+                if len(pred) and len(tcls):
+                    tp = BaseValidator.match_predictions(holder, pred[:, 5], tcls, box_iou(tbox, pred[:, :4]))
+                stats["tp"].append(tp); stats["conf"].append(pred[:, 4]); stats["pred_cls"].append(pred[:, 5]); stats["target_cls"].append(tcls)
+    st = {k: torch.cat(v, 0).numpy() for k, v in stats.items()}
+    dm = DetMetrics(names={i: str(i) for i in range(P["nc"])})
+    dm.process(st["tp"], st["conf"], st["pred_cls"], st["target_cls"])
+    print("reference mean_results (P, R, mAP50, mAP50-95):", dm.mean_results())
+    npz("map_parity", loss_hist=np.stack(hist), mean_results=np.asarray(dm.mean_results(), np.float64), n_det=np.asarray(len(st["conf"])),
+        protocol=np.asarray([P["nc"], P["imgsz"], P["batch"], P["nb"], P["epochs"], P["nval"], P["init_seed"]]))
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["modules", "models", "loss", "nms", "trainer", "fullsize", "metrics"]
