@@ -5,8 +5,10 @@
 // (fp32, from the p_conv 3x3 MFMA conv), gathers the four corners straight from the NHWC fp16 map (channel-contiguous
 // 16-byte granules) and writes the N samples of every output pixel channel-major as x_off[pix][n*C + c], which turns the
 // reference's (N,1)-kernel column conv (:354, 'b c h w n -> b c (h n) w' :494-503) into a plain 1x1 MFMA conv with
-// K = N*C.  Backward: scatter-add of the sample gradients into an fp32 accumulator (atomics) and the offset gradient
-// through dg/dp with the reference's clamp semantics (no gradient through floor; clamp passes gradient inside [0, H-1]).
+// K = N*C.  Backward: the offset gradient through dg/dp with the reference's clamp semantics (no gradient through floor;
+// clamp passes gradient inside [0, H-1]) and the input gradient as a deterministic GATHER -- every input pixel walks the
+// samples that can touch it, bounded by the largest |offset| of the layer, which the offset-gradient kernel measures on
+// the device -- with the fp32-atomic scatter kept as the fallback for layers whose offsets have grown past LD_RMAX pixels.
 #include "common.h"
 #include "dealyolo_hip.h"
 
@@ -73,12 +75,22 @@ __global__ __launch_bounds__(256) void ldconv_sample_kernel(LdArgs a) {
   }
 }
 
+// Largest |offset| of a layer travels as the bit pattern of its absolute value (integer max orders non-negative floats and
+// puts NaN above everything).  Returns the candidate radius R >= 1 for the gather kernel, or 0 when the layer has to take
+// the scatter fallback (|offset| > rmax - 0.01, inf or NaN).
+static __device__ __forceinline__ int ld_gather_radius(unsigned bits, int rmax) {
+  const float mx = __uint_as_float(bits);
+  if (!(mx <= (float)rmax - 0.01f)) return 0;
+  return (int)ceilf(mx + 0.01f);
+}
+
 // One thread per (output pixel, sample n, channel): the C lanes of a sample are adjacent, so every atomic wave-instruction
 // adds runs of C contiguous floats (the shape float atomics run at full rate in; one-lane-per-row scatter is ~17x slower,
 // MI355X_MICROARCH.md "Global float atomics"), the sample's geometry is computed by the group's first lane and broadcast,
 // and the offset gradient is a log2(C)-step shuffle reduction over the group.
-__global__ __launch_bounds__(256) void ldconv_sample_bwd_kernel(LdArgs a, int G) {
+__global__ __launch_bounds__(256) void ldconv_sample_bwd_kernel(LdArgs a, int G, const unsigned* maxabs, int rmax) {
   // G = lanes per sample: the largest power of two <= 64 dividing C; each lane walks C/G channels G apart.
+  if (maxabs && ld_gather_radius(*maxabs, rmax) > 0) return;  // the gather kernel owns this layer
   const int C = a.C;
   const long total = (long)a.N * a.h * a.w * a.Np * G;
   const long span = ((total + 255) / 256) * 256;
@@ -138,7 +150,8 @@ __global__ __launch_bounds__(256) void ldconv_sample_bwd_kernel(LdArgs a, int G)
 // reduction over the C/8 lanes of the sample.  The per-channel mapping of the scatter kernel spends five 2-byte loads per
 // lane on the same data (1.24 ms -> 0.23 ms for the 640^2 stem).  Where the input gradient IS needed the fp32 atomics set the
 // pace (splitting that kernel into this one + a lean scatter measured 14 % slower), so the fused kernel above stays.
-__global__ __launch_bounds__(256) void ldconv_doff_kernel(LdArgs a, int LG) {
+__global__ __launch_bounds__(256) void ldconv_doff_kernel(LdArgs a, int LG, unsigned* maxabs) {
+  unsigned mbits = 0;
   const long total = (long)a.N * a.h * a.w * a.Np * LG;  // LG = C/8 rounded up to a power of two (<= 64)
   const long span = ((total + 255) / 256) * 256;
   const int cpp = a.C >> 3;
@@ -153,6 +166,11 @@ __global__ __launch_bounds__(256) void ldconv_doff_kernel(LdArgs a, int LG) {
     bool ir, ic;
     long img;
     ld_coords(a, pix, n, r0, r1, c0, c1, pr, pc, ir, ic, img);
+    if (maxabs) {
+      const float* o = a.off + pix * a.ldoff_in;
+      const unsigned br = __float_as_uint(o[n]) & 0x7fffffffu, bc = __float_as_uint(o[a.Np + n]) & 0x7fffffffu;
+      mbits = max(mbits, max(br, bc));
+    }
     const float ar0 = 1.f + ((float)r0 - pr), ar1 = 1.f - ((float)r1 - pr);
     const float ac0 = 1.f + ((float)c0 - pc), ac1 = 1.f - ((float)c1 - pc);
     float dpr = 0.f, dpc = 0.f;
@@ -179,6 +197,84 @@ __global__ __launch_bounds__(256) void ldconv_doff_kernel(LdArgs a, int LG) {
       f16* d = a.doff + pix * a.lddoff;
       d[n] = (f16)(ir ? dpr : 0.f);
       d[a.Np + n] = (f16)(ic ? dpc : 0.f);
+    }
+  }
+  if (maxabs) {  // one atomic per wave, and only while it can still raise the running maximum
+    for (int o = 1; o < 64; o <<= 1) mbits = max(mbits, (unsigned)__shfl_xor((int)mbits, o, 64));
+    if (lane == 0 && mbits > __atomic_load_n(maxabs, __ATOMIC_RELAXED)) atomicMax(maxabs, mbits);
+  }
+}
+
+// Input gradient by gather.  Thread = (input pixel, GP granules of 8 channels).  A sample (oy, ox, n) has its base point at
+// (oy*s + pn_r[n], ox*s + pn_c[n]) and lands within R = ceil(max|offset|) of it, so the samples whose corner rows can equal
+// r have base rows in [r-1-R, r+R] (everything below it for the clamped last row r = H-1; the clamped first row needs no
+// extension because bases are >= 0), likewise for columns.  Every candidate is then tested EXACTLY with ld_coords'
+// arithmetic: row weight = [r0==r](1+(r0-pr)) + [r1==r](1-(r1-pr)) (both terms when the clamp folds the two corners onto
+// one row), the same for columns, and the sum of the scatter's four corner products factorises into row*col.  Over-wide
+// candidate ranges only cost time.  fp32 accumulation in a fixed order: run-to-run deterministic, unlike the atomics.
+template <int GP>
+__global__ __launch_bounds__(256) void ldconv_gather_bwd_kernel(LdArgs a, f16* dx, int lddx, int accumulate, const unsigned* maxabs, int rmax) {
+  const int R = ld_gather_radius(*maxabs, rmax);
+  if (R == 0) return;  // scatter fallback owns this layer
+  const int Np = a.Np, s = a.stride, C = a.C;
+  const int tpp = (C >> 3) / GP;
+  const long total = (long)a.N * a.H * a.W * tpp;
+  const float Hm = (float)(a.H - 1), Wm = (float)(a.W - 1);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int part = (int)(idx % tpp);
+    long t = idx / tpp;
+    const int c = (int)(t % a.W);
+    t /= a.W;
+    const int r = (int)(t % a.H);
+    const long img = t / a.H;
+    float acc[GP][8];
+#pragma unroll
+    for (int g = 0; g < GP; ++g)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+    for (int n = 0; n < Np; ++n) {
+      const int pnr = a.pn[n], pnc = a.pn[Np + n];
+      const int nr = r - 1 - R - pnr, nc_ = c - 1 - R - pnc;
+      const int oy_lo = nr > 0 ? (nr + s - 1) / s : 0;
+      const int ox_lo = nc_ > 0 ? (nc_ + s - 1) / s : 0;
+      int oy_hi = (r + R - pnr) / s, ox_hi = (c + R - pnc) / s;
+      if (r == a.H - 1 || oy_hi > a.h - 1) oy_hi = a.h - 1;
+      if (c == a.W - 1 || ox_hi > a.w - 1) ox_hi = a.w - 1;
+      for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const long prow = (img * a.h + oy) * a.w;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+          const long pix = prow + ox;
+          const float* o = a.off + pix * a.ldoff_in;
+          const float ur = (float)(oy * s) + (float)pnr + o[n];  // identical to ld_coords
+          const float fr = floorf(ur);
+          const int r0 = (int)fminf(fmaxf(fr, 0.f), Hm), r1 = (int)fminf(fmaxf(fr + 1.f, 0.f), Hm);
+          if (r0 != r && r1 != r) continue;
+          const float uc = (float)(ox * s) + (float)pnc + o[Np + n];
+          const float fc = floorf(uc);
+          const int c0 = (int)fminf(fmaxf(fc, 0.f), Wm), c1 = (int)fminf(fmaxf(fc + 1.f, 0.f), Wm);
+          if (c0 != c && c1 != c) continue;
+          const float pr = fminf(fmaxf(ur, 0.f), Hm), pc = fminf(fmaxf(uc, 0.f), Wm);
+          const float wr = (r0 == r ? 1.f + ((float)r0 - pr) : 0.f) + (r1 == r ? 1.f - ((float)r1 - pr) : 0.f);
+          const float wc = (c0 == c ? 1.f + ((float)c0 - pc) : 0.f) + (c1 == c ? 1.f - ((float)c1 - pc) : 0.f);
+          const float wgt = wr * wc;
+          const f16* gp = a.dxo + pix * a.lddxo + n * C + part * (GP * 8);
+#pragma unroll
+          for (int g = 0; g < GP; ++g) {
+            const half8 g8 = *reinterpret_cast<const half8*>(gp + g * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[g][j] += wgt * (float)g8[j];
+          }
+        }
+      }
+    }
+    f16* d = dx + ((img * a.H + r) * a.W + c) * lddx + part * (GP * 8);
+#pragma unroll
+    for (int g = 0; g < GP; ++g) {
+      half8 o8;
+      if (accumulate) o8 = *reinterpret_cast<const half8*>(d + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o8[j] = (f16)(acc[g][j] + (accumulate ? (float)o8[j] : 0.f));
+      *reinterpret_cast<half8*>(d + g * 8) = o8;
     }
   }
 }
@@ -211,19 +307,21 @@ extern "C" int dy_ldconv_sample_backward(const void* x, int ldx, const float* of
     while (LG < (C >> 3) && LG < 64) LG <<= 1;
     long nb = ((long)n * h * w * Np * LG + 255) / 256;
     if (nb > 16384) nb = 16384;
-    hipLaunchKernelGGL(ldconv_doff_kernel, dim3((int)nb), dim3(256), 0, stream, a, LG);
+    hipLaunchKernelGGL(ldconv_doff_kernel, dim3((int)nb), dim3(256), 0, stream, a, LG, (unsigned*)nullptr);
     DY_CHECK_LAUNCH();
     return DY_OK;
   }
   long blocks = ((long)n * h * w * Np * G + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(ldconv_sample_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, a, G);
+  hipLaunchKernelGGL(ldconv_sample_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, a, G, (const unsigned*)nullptr, 0);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
 
 // dst(fp16, strided) (+)= src(fp32 dense): folds the fp32 scatter accumulator into the activation-gradient buffer
-__global__ __launch_bounds__(256) void f32_to_f16_add_kernel(const float* src, f16* dst, int ld, int C, long npix, int accumulate) {
+__global__ __launch_bounds__(256) void f32_to_f16_add_kernel(const float* src, f16* dst, int ld, int C, long npix, int accumulate,
+                                                             const unsigned* maxabs, int rmax) {
+  if (maxabs && ld_gather_radius(*maxabs, rmax) > 0) return;
   const int cpp = C >> 3;
   const long total = npix * cpp;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -244,7 +342,56 @@ extern "C" int dy_f32_to_f16_add(const float* src, void* dst, int ld, long npix,
   long blocks = (npix * (C >> 3) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(f32_to_f16_add_kernel, dim3((int)blocks), dim3(256), 0, stream, src, (f16*)dst, ld, C, npix, accumulate);
+  hipLaunchKernelGGL(f32_to_f16_add_kernel, dim3((int)blocks), dim3(256), 0, stream, src, (f16*)dst, ld, C, npix, accumulate,
+                     (const unsigned*)nullptr, 0);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+__global__ __launch_bounds__(256) void ld_zero_if_fallback_kernel(float4* p, long n16, const unsigned* maxabs, int rmax) {
+  if (ld_gather_radius(*maxabs, rmax) > 0) return;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+#define LD_RMAX 4  // candidate radius up to which the gather beats the atomics ((2R+2)^2 tests per input pixel and sample point)
+
+extern "C" int dy_ldconv_sample_backward_gather(const void* x, int ldx, const float* off, int ldoff, const int* pn, const void* dxo,
+                                                int lddxo, void* dx, int lddx, int accumulate, float* dx32, void* doff,
+                                                int lddoff, void* scratch, int n, int H, int W, int h, int w, int C, int Np,
+                                                int stride, hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (lddxo & 7) || (lddx & 7)) return DY_ERR_ALIGN;
+  if (!dx || !dx32 || !scratch || !doff) return DY_ERR_ARG;
+  LdArgs a{};
+  a.x = (const f16*)x; a.off = off; a.dxo = (const f16*)dxo; a.dx32 = dx32; a.doff = (f16*)doff; a.pn = pn;
+  a.ldx = ldx; a.lddxo = lddxo; a.ldoff_in = ldoff; a.lddoff = lddoff;
+  a.N = n; a.H = H; a.W = W; a.h = h; a.w = w; a.C = C; a.Np = Np; a.stride = stride;
+  unsigned* maxabs = (unsigned*)scratch;
+  if (hipMemsetAsync(maxabs, 0, 4, stream) != hipSuccess) return DY_ERR_LAUNCH;
+  int LG = 1;
+  while (LG < (C >> 3) && LG < 64) LG <<= 1;
+  long nb = ((long)n * h * w * Np * LG + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(ldconv_doff_kernel, dim3((int)nb), dim3(256), 0, stream, a, LG, maxabs);
+  const int cpp = C >> 3;
+  const int GP = (cpp % 4 == 0 && cpp >= 8) ? 4 : (cpp % 2 == 0 ? 2 : 1);
+  long gb = ((long)n * H * W * (cpp / GP) + 255) / 256;
+  if (gb > 65536) gb = 65536;
+  if (GP == 4) hipLaunchKernelGGL(ldconv_gather_bwd_kernel<4>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, LD_RMAX);
+  else if (GP == 2) hipLaunchKernelGGL(ldconv_gather_bwd_kernel<2>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, LD_RMAX);
+  else hipLaunchKernelGGL(ldconv_gather_bwd_kernel<1>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, LD_RMAX);
+  // fallback chain: every kernel returns at once unless the offsets outgrew LD_RMAX (decided on the device: no host sync,
+  // same launch sequence every step, so the whole thing captures into a hipGraph)
+  const long n16 = (long)n * H * W * C / 4;
+  hipLaunchKernelGGL(ld_zero_if_fallback_kernel, dim3(2048), dim3(256), 0, stream, (float4*)dx32, n16, maxabs, LD_RMAX);
+  int G = 64;
+  while (C % G) G >>= 1;
+  long blocks = ((long)n * h * w * Np * G + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(ldconv_sample_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, a, G, maxabs, LD_RMAX);
+  long cb = ((long)n * H * W * cpp + 255) / 256;
+  if (cb > 8192) cb = 8192;
+  hipLaunchKernelGGL(f32_to_f16_add_kernel, dim3((int)cb), dim3(256), 0, stream, dx32, (f16*)dx, lddx, C, (long)n * H * W, accumulate,
+                     maxabs, LD_RMAX);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

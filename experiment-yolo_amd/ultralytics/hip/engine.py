@@ -13,6 +13,7 @@ Design:
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -626,16 +627,21 @@ class Engine:
         if self.tape is not None:
             def bwd():
                 assert xo.grad_ready()
-                dx32 = None
-                if x.needs_grad:
-                    dx32 = self.scratch("ld_dx32", x.npix * x.C * 4)
+                if not x.needs_grad:  # stem: offset gradient only
+                    self.call("dy_ldconv_sample_backward", x.ptr, x.ld, off.data_ptr(), 2 * Np, pn_i32.data_ptr(), xo.gptr, xo.ld,
+                              0, doff.data_ptr(), doff.shape[-1], x.N, x.H, x.W, h, w, x.C, Np, stride)
+                    return
+                dx32 = self.scratch("ld_dx32", x.npix * x.C * 4)  # touched only when the offsets outgrow the gather radius
+                acc = x.grad_target()
+                if os.environ.get("DY_LD_SCATTER", "0") == "1":  # measurement switch: the atomic path on its own
                     self.call("dy_fill_zero", dx32.data_ptr(), x.npix * x.C * 4)
-                self.call("dy_ldconv_sample_backward", x.ptr, x.ld, off.data_ptr(), 2 * Np, pn_i32.data_ptr(), xo.gptr, xo.ld,
-                          0 if dx32 is None else dx32.data_ptr(), doff.data_ptr(), doff.shape[-1], x.N, x.H, x.W, h, w, x.C, Np,
-                          stride)
-                if dx32 is not None:
-                    acc = x.grad_target()
+                    self.call("dy_ldconv_sample_backward", x.ptr, x.ld, off.data_ptr(), 2 * Np, pn_i32.data_ptr(), xo.gptr, xo.ld,
+                              dx32.data_ptr(), doff.data_ptr(), doff.shape[-1], x.N, x.H, x.W, h, w, x.C, Np, stride)
                     self.call("dy_f32_to_f16_add", dx32.data_ptr(), x.gptr, x.ld, x.npix, x.C, acc)
+                    return
+                self.call("dy_ldconv_sample_backward_gather", x.ptr, x.ld, off.data_ptr(), 2 * Np, pn_i32.data_ptr(), xo.gptr, xo.ld,
+                          x.gptr, x.ld, acc, dx32.data_ptr(), doff.data_ptr(), doff.shape[-1], self.scratch("ld_maxabs", 16).data_ptr(),
+                          x.N, x.H, x.W, h, w, x.C, Np, stride)
             self.tape.append(bwd)
         return self.conv_bn_act(sp_c, xo, out)
 

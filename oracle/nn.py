@@ -31,14 +31,14 @@ def conv_bn_silu(sd, p, x, k, s, training, act=True):
     return F.silu(y) if act else y
 
 
-def ldconv(sd, p, x, N, s, training):
-    """LDConv.forward, nn/modules/conv.py:366-410 with helpers :413-503."""
+def ld_sample(x, off, pn, N, s):
+    """The sampling stage of LDConv.forward, nn/modules/conv.py:368-404 (_get_p :446-454, _get_x_q :456-489): offsets
+    (B,2N,h,w) -> bilinear 4-corner samples (B,C,h,w,N)."""
     B, C, H, W = x.shape
-    off = F.conv2d(x, sd[f"{p}.p_conv.weight"], sd[f"{p}.p_conv.bias"], s, 1)  # (B,2N,h,w)
     h, w = off.shape[2:]
     rows = torch.arange(0, h * s, s, dtype=x.dtype).view(1, 1, h, 1)
     cols = torch.arange(0, w * s, s, dtype=x.dtype).view(1, 1, 1, w)
-    pn = sd[f"{p}.p_n"].to(x.dtype)
+    pn = pn.to(x.dtype)
     pr = rows + pn[:, :N] + off[:, :N]  # sample row coordinate (first N channels)  :446-454
     pc = cols + pn[:, N:] + off[:, N:]  # sample col coordinate (last N channels)
     pr, pc = pr.permute(0, 2, 3, 1), pc.permute(0, 2, 3, 1)  # (B,h,w,N)
@@ -57,8 +57,16 @@ def ldconv(sd, p, x, N, s, training):
         idx = (r.long() * W + c.long()).reshape(B, 1, -1).expand(-1, C, -1)
         return xf.gather(2, idx).view(B, C, h, w, N)
 
-    xo = (g_lt.unsqueeze(1) * take(r0, c0) + g_rb.unsqueeze(1) * take(r1, c1)
-          + g_lb.unsqueeze(1) * take(r0, c1) + g_rt.unsqueeze(1) * take(r1, c0))
+    return (g_lt.unsqueeze(1) * take(r0, c0) + g_rb.unsqueeze(1) * take(r1, c1)
+            + g_lb.unsqueeze(1) * take(r0, c1) + g_rt.unsqueeze(1) * take(r1, c0))
+
+
+def ldconv(sd, p, x, N, s, training):
+    """LDConv.forward, nn/modules/conv.py:366-410 with helpers :413-503."""
+    B, C, H, W = x.shape
+    off = F.conv2d(x, sd[f"{p}.p_conv.weight"], sd[f"{p}.p_conv.bias"], s, 1)  # (B,2N,h,w)
+    h, w = off.shape[2:]
+    xo = ld_sample(x, off, sd[f"{p}.p_n"], N, s)
     xo = xo.permute(0, 1, 2, 4, 3).reshape(B, C, h * N, w)  # 'b c h w n -> b c (h n) w'  :494-503
     y = F.conv2d(xo, sd[f"{p}.conv.0.weight"], sd.get(f"{p}.conv.0.bias"), (N, 1))
     y = _bn(sd, f"{p}.conv.1", y, training, BN2D_EPS, BN2D_MOM)
