@@ -7,8 +7,9 @@
 // reference's (N,1)-kernel column conv (:354, 'b c h w n -> b c (h n) w' :494-503) into a plain 1x1 MFMA conv with
 // K = N*C.  Backward: the offset gradient through dg/dp with the reference's clamp semantics (no gradient through floor;
 // clamp passes gradient inside [0, H-1]) and the input gradient as a deterministic GATHER -- every input pixel walks the
-// samples that can touch it, bounded by the largest |offset| of the layer, which the offset-gradient kernel measures on
-// the device -- with the fp32-atomic scatter kept as the fallback for layers whose offsets have grown past LD_RMAX pixels.
+// samples that can touch it, within a radius set by the largest |offset| of the layer (measured on the device by the
+// offset-gradient kernel) and capped at rmax; the few samples whose offsets reach further are scattered with fp32 atomics
+// into a side accumulator that the gather kernel folds in.
 #include "common.h"
 #include "dealyolo_hip.h"
 
@@ -76,21 +77,17 @@ __global__ __launch_bounds__(256) void ldconv_sample_kernel(LdArgs a) {
 }
 
 // Largest |offset| of a layer travels as the bit pattern of its absolute value (integer max orders non-negative floats and
-// puts NaN above everything).  Returns the candidate radius R >= 1 for the gather kernel, or 0 when the layer has to take
-// the scatter fallback (|offset| > rmax - 0.01, inf or NaN).
-static __device__ __forceinline__ int ld_gather_radius(unsigned bits, int rmax) {
-  const float mx = __uint_as_float(bits);
-  if (!(mx <= (float)rmax - 0.01f)) return 0;
-  return (int)ceilf(mx + 0.01f);
-}
+// puts NaN above everything).  A sample is NEAR when both its offsets are <= rmax - 0.01 in magnitude (the slack covers the
+// fp32 rounding of base + offset); the gather handles near samples, the atomic side pass the FAR ones (incl. inf / NaN).
+static __device__ __forceinline__ bool ld_has_far(unsigned bits, int rmax) { return !(__uint_as_float(bits) <= (float)rmax - 0.01f); }
+static __device__ __forceinline__ bool ld_is_far(float o_r, float o_c, float thr) { return !(fabsf(o_r) <= thr) || !(fabsf(o_c) <= thr); }
 
 // One thread per (output pixel, sample n, channel): the C lanes of a sample are adjacent, so every atomic wave-instruction
 // adds runs of C contiguous floats (the shape float atomics run at full rate in; one-lane-per-row scatter is ~17x slower,
 // MI355X_MICROARCH.md "Global float atomics"), the sample's geometry is computed by the group's first lane and broadcast,
 // and the offset gradient is a log2(C)-step shuffle reduction over the group.
-__global__ __launch_bounds__(256) void ldconv_sample_bwd_kernel(LdArgs a, int G, const unsigned* maxabs, int rmax) {
+__global__ __launch_bounds__(256) void ldconv_sample_bwd_kernel(LdArgs a, int G) {
   // G = lanes per sample: the largest power of two <= 64 dividing C; each lane walks C/G channels G apart.
-  if (maxabs && ld_gather_radius(*maxabs, rmax) > 0) return;  // the gather kernel owns this layer
   const int C = a.C;
   const long total = (long)a.N * a.h * a.w * a.Np * G;
   const long span = ((total + 255) / 256) * 256;
@@ -211,11 +208,14 @@ __global__ __launch_bounds__(256) void ldconv_doff_kernel(LdArgs a, int LG, unsi
 // extension because bases are >= 0), likewise for columns.  Every candidate is then tested EXACTLY with ld_coords'
 // arithmetic: row weight = [r0==r](1+(r0-pr)) + [r1==r](1-(r1-pr)) (both terms when the clamp folds the two corners onto
 // one row), the same for columns, and the sum of the scatter's four corner products factorises into row*col.  Over-wide
-// candidate ranges only cost time.  fp32 accumulation in a fixed order: run-to-run deterministic, unlike the atomics.
+// candidate ranges only cost time.  fp32 accumulation in a fixed order: run-to-run deterministic (the far side pass, when a
+// layer has far samples at all, is not).
 template <int GP>
 __global__ __launch_bounds__(256) void ldconv_gather_bwd_kernel(LdArgs a, f16* dx, int lddx, int accumulate, const unsigned* maxabs, int rmax) {
-  const int R = ld_gather_radius(*maxabs, rmax);
-  if (R == 0) return;  // scatter fallback owns this layer
+  const unsigned mb = *maxabs;
+  const bool has_far = ld_has_far(mb, rmax);
+  const int R = has_far ? rmax : (int)ceilf(__uint_as_float(mb) + 0.01f);  // >= 1
+  const float thr = (float)rmax - 0.01f;
   const int Np = a.Np, s = a.stride, C = a.C;
   const int tpp = (C >> 3) / GP;
   const long total = (long)a.N * a.H * a.W * tpp;
@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void ldconv_gather_bwd_kernel(LdArgs a, f16* d
         for (int ox = ox_lo; ox <= ox_hi; ++ox) {
           const long pix = prow + ox;
           const float* o = a.off + pix * a.ldoff_in;
+          if (has_far && ld_is_far(o[n], o[Np + n], thr)) continue;  // the side pass owns it
           const float ur = (float)(oy * s) + (float)pnr + o[n];  // identical to ld_coords
           const float fr = floorf(ur);
           const int r0 = (int)fminf(fmaxf(fr, 0.f), Hm), r1 = (int)fminf(fmaxf(fr + 1.f, 0.f), Hm);
@@ -267,7 +268,17 @@ __global__ __launch_bounds__(256) void ldconv_gather_bwd_kernel(LdArgs a, f16* d
         }
       }
     }
-    f16* d = dx + ((img * a.H + r) * a.W + c) * lddx + part * (GP * 8);
+    const long ipix = (img * a.H + r) * a.W + c;
+    if (has_far) {
+      const float4* f = reinterpret_cast<const float4*>(a.dx32 + ipix * C + part * (GP * 8));
+#pragma unroll
+      for (int g = 0; g < GP; ++g) {
+        const float4 f0 = f[2 * g], f1 = f[2 * g + 1];
+        acc[g][0] += f0.x; acc[g][1] += f0.y; acc[g][2] += f0.z; acc[g][3] += f0.w;
+        acc[g][4] += f1.x; acc[g][5] += f1.y; acc[g][6] += f1.z; acc[g][7] += f1.w;
+      }
+    }
+    f16* d = dx + ipix * lddx + part * (GP * 8);
 #pragma unroll
     for (int g = 0; g < GP; ++g) {
       half8 o8;
@@ -313,15 +324,13 @@ extern "C" int dy_ldconv_sample_backward(const void* x, int ldx, const float* of
   }
   long blocks = ((long)n * h * w * Np * G + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(ldconv_sample_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, a, G, (const unsigned*)nullptr, 0);
+  hipLaunchKernelGGL(ldconv_sample_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, a, G);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
 
 // dst(fp16, strided) (+)= src(fp32 dense): folds the fp32 scatter accumulator into the activation-gradient buffer
-__global__ __launch_bounds__(256) void f32_to_f16_add_kernel(const float* src, f16* dst, int ld, int C, long npix, int accumulate,
-                                                             const unsigned* maxabs, int rmax) {
-  if (maxabs && ld_gather_radius(*maxabs, rmax) > 0) return;
+__global__ __launch_bounds__(256) void f32_to_f16_add_kernel(const float* src, f16* dst, int ld, int C, long npix, int accumulate) {
   const int cpp = C >> 3;
   const long total = npix * cpp;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -342,25 +351,54 @@ extern "C" int dy_f32_to_f16_add(const float* src, void* dst, int ld, long npix,
   long blocks = (npix * (C >> 3) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(f32_to_f16_add_kernel, dim3((int)blocks), dim3(256), 0, stream, src, (f16*)dst, ld, C, npix, accumulate,
-                     (const unsigned*)nullptr, 0);
+  hipLaunchKernelGGL(f32_to_f16_add_kernel, dim3((int)blocks), dim3(256), 0, stream, src, (f16*)dst, ld, C, npix, accumulate);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
 
-__global__ __launch_bounds__(256) void ld_zero_if_fallback_kernel(float4* p, long n16, const unsigned* maxabs, int rmax) {
-  if (ld_gather_radius(*maxabs, rmax) > 0) return;
+__global__ __launch_bounds__(256) void ld_zero_if_far_kernel(float4* p, long n16, const unsigned* maxabs, int rmax) {
+  if (!ld_has_far(*maxabs, rmax)) return;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-#define LD_RMAX 4  // candidate radius up to which the gather beats the atomics ((2R+2)^2 tests per input pixel and sample point)
+// Side pass: fp32-atomic scatter of the FAR samples only (same lane mapping as ldconv_sample_bwd_kernel).
+__global__ __launch_bounds__(256) void ldconv_scatter_far_kernel(LdArgs a, int G, const unsigned* maxabs, int rmax) {
+  if (!ld_has_far(*maxabs, rmax)) return;
+  const int C = a.C;
+  const float thr = (float)rmax - 0.01f;
+  const long total = (long)a.N * a.h * a.w * a.Np * G;
+  const int gl = threadIdx.x & (G - 1);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long t = idx / G;
+    const int n = (int)(t % a.Np);
+    const long pix = t / a.Np;
+    const float* o = a.off + pix * a.ldoff_in;
+    if (!ld_is_far(o[n], o[a.Np + n], thr)) continue;
+    int r0, r1, c0, c1;
+    float pr, pc;
+    bool ir, ic;
+    long img;
+    ld_coords(a, pix, n, r0, r1, c0, c1, pr, pc, ir, ic, img);
+    const float ar0 = 1.f + ((float)r0 - pr), ar1 = 1.f - ((float)r1 - pr);
+    const float ac0 = 1.f + ((float)c0 - pc), ac1 = 1.f - ((float)c1 - pc);
+    float* db = a.dx32 + img * a.H * a.W * C;
+    const f16* gb = a.dxo + pix * a.lddxo + n * C;
+    for (int c = gl; c < C; c += G) {
+      const float g = (float)gb[c];
+      atomicAdd(db + ((long)r0 * a.W + c0) * C + c, g * (ar0 * ac0));
+      atomicAdd(db + ((long)r1 * a.W + c1) * C + c, g * (ar1 * ac1));
+      atomicAdd(db + ((long)r0 * a.W + c1) * C + c, g * (ar0 * ac1));
+      atomicAdd(db + ((long)r1 * a.W + c0) * C + c, g * (ar1 * ac0));
+    }
+  }
+}
 
 extern "C" int dy_ldconv_sample_backward_gather(const void* x, int ldx, const float* off, int ldoff, const int* pn, const void* dxo,
                                                 int lddxo, void* dx, int lddx, int accumulate, float* dx32, void* doff,
-                                                int lddoff, void* scratch, int n, int H, int W, int h, int w, int C, int Np,
-                                                int stride, hipStream_t stream) {
+                                                int lddoff, void* scratch, int rmax, int n, int H, int W, int h, int w, int C,
+                                                int Np, int stride, hipStream_t stream) {
   if ((C & 7) || (ldx & 7) || (lddxo & 7) || (lddx & 7)) return DY_ERR_ALIGN;
-  if (!dx || !dx32 || !scratch || !doff) return DY_ERR_ARG;
+  if (!dx || !dx32 || !scratch || !doff || rmax < 1 || rmax > 16) return DY_ERR_ARG;
   LdArgs a{};
   a.x = (const f16*)x; a.off = off; a.dxo = (const f16*)dxo; a.dx32 = dx32; a.doff = (f16*)doff; a.pn = pn;
   a.ldx = ldx; a.lddxo = lddxo; a.ldoff_in = ldoff; a.lddoff = lddoff;
@@ -372,26 +410,22 @@ extern "C" int dy_ldconv_sample_backward_gather(const void* x, int ldx, const fl
   long nb = ((long)n * h * w * Np * LG + 255) / 256;
   if (nb > 16384) nb = 16384;
   hipLaunchKernelGGL(ldconv_doff_kernel, dim3((int)nb), dim3(256), 0, stream, a, LG, maxabs);
+  // side pass for far samples: both kernels return at once when the layer has none (decided on the device: no host sync,
+  // the same launch sequence every step, so the chain captures into a hipGraph)
+  const long n16 = (long)n * H * W * C / 4;
+  hipLaunchKernelGGL(ld_zero_if_far_kernel, dim3(2048), dim3(256), 0, stream, (float4*)dx32, n16, maxabs, rmax);
+  int G = 64;
+  while (C % G) G >>= 1;
+  long blocks = ((long)n * h * w * Np * G + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ldconv_scatter_far_kernel, dim3((int)blocks), dim3(256), 0, stream, a, G, maxabs, rmax);
   const int cpp = C >> 3;
   const int GP = (cpp % 4 == 0 && cpp >= 8) ? 4 : (cpp % 2 == 0 ? 2 : 1);
   long gb = ((long)n * H * W * (cpp / GP) + 255) / 256;
   if (gb > 65536) gb = 65536;
-  if (GP == 4) hipLaunchKernelGGL(ldconv_gather_bwd_kernel<4>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, LD_RMAX);
-  else if (GP == 2) hipLaunchKernelGGL(ldconv_gather_bwd_kernel<2>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, LD_RMAX);
-  else hipLaunchKernelGGL(ldconv_gather_bwd_kernel<1>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, LD_RMAX);
-  // fallback chain: every kernel returns at once unless the offsets outgrew LD_RMAX (decided on the device: no host sync,
-  // same launch sequence every step, so the whole thing captures into a hipGraph)
-  const long n16 = (long)n * H * W * C / 4;
-  hipLaunchKernelGGL(ld_zero_if_fallback_kernel, dim3(2048), dim3(256), 0, stream, (float4*)dx32, n16, maxabs, LD_RMAX);
-  int G = 64;
-  while (C % G) G >>= 1;
-  long blocks = ((long)n * h * w * Np * G + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(ldconv_sample_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, a, G, maxabs, LD_RMAX);
-  long cb = ((long)n * H * W * cpp + 255) / 256;
-  if (cb > 8192) cb = 8192;
-  hipLaunchKernelGGL(f32_to_f16_add_kernel, dim3((int)cb), dim3(256), 0, stream, dx32, (f16*)dx, lddx, C, (long)n * H * W, accumulate,
-                     maxabs, LD_RMAX);
+  if (GP == 4) hipLaunchKernelGGL(ldconv_gather_bwd_kernel<4>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, rmax);
+  else if (GP == 2) hipLaunchKernelGGL(ldconv_gather_bwd_kernel<2>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, rmax);
+  else hipLaunchKernelGGL(ldconv_gather_bwd_kernel<1>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, rmax);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

@@ -51,7 +51,7 @@ SIGNATURES = {
     "dy_conv_wgrad": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_ldconv_sample": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_ldconv_sample_backward": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "dy_ldconv_sample_backward_gather": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_ldconv_sample_backward_gather": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_f32_to_f16_add": (i32, [vp, vp, i32, i64, i32, i32, vp]),
     "dy_pack_weights_ld": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "dy_conv_wgrad_ld": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

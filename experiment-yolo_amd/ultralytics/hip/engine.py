@@ -641,7 +641,7 @@ class Engine:
                     return
                 self.call("dy_ldconv_sample_backward_gather", x.ptr, x.ld, off.data_ptr(), 2 * Np, pn_i32.data_ptr(), xo.gptr, xo.ld,
                           x.gptr, x.ld, acc, dx32.data_ptr(), doff.data_ptr(), doff.shape[-1], self.scratch("ld_maxabs", 16).data_ptr(),
-                          x.N, x.H, x.W, h, w, x.C, Np, stride)
+                          int(os.environ.get("DY_LD_RMAX", "2")), x.N, x.H, x.W, h, w, x.C, Np, stride)
             self.tape.append(bwd)
         return self.conv_bn_act(sp_c, xo, out)
 

@@ -93,12 +93,13 @@ int dy_ldconv_sample_backward(const void* x, int ldx, const float* off, int ldof
                               int lddxo, float* dx32, void* doff, int lddoff, int n, int H, int W, int h, int w, int C,
                               int Np, int stride, hipStream_t stream);
 /* The same backward with the input gradient computed by a deterministic gather and written (accumulate=0) or added
- * (accumulate=1) straight into the fp16 gradient map dx (n,H,W,lddx).  The candidate radius comes from the largest |offset|
- * of the layer, measured on the device into scratch (>= 4 bytes); layers whose offsets exceed 4 pixels take the atomic
- * scatter through dx32 (n*H*W*C floats, caller-owned, need not be zeroed) inside the same call -- no host decision. */
+ * (accumulate=1) straight into the fp16 gradient map dx (n,H,W,lddx).  Samples whose offsets stay within rmax pixels
+ * (1..16) are gathered, with the candidate radius shrunk to the largest |offset| of the layer, measured on the device into
+ * scratch (>= 4 bytes); the far ones go through fp32 atomics into dx32 (n*H*W*C floats, caller-owned, need not be
+ * zeroed, untouched when the layer has no far sample) and are folded in by the gather -- no host decision anywhere. */
 int dy_ldconv_sample_backward_gather(const void* x, int ldx, const float* off, int ldoff, const int* pn, const void* dxo,
                                      int lddxo, void* dx, int lddx, int accumulate, float* dx32, void* doff, int lddoff,
-                                     void* scratch, int n, int H, int W, int h, int w, int C, int Np, int stride,
+                                     void* scratch, int rmax, int n, int H, int W, int h, int w, int C, int Np, int stride,
                                      hipStream_t stream);
 int dy_f32_to_f16_add(const float* src, void* dst, int ld, long npix, int C, int accumulate, hipStream_t stream);
 int dy_pack_weights_ld(const float* w, void* out, int cout, int cin, int ld_taps, int ld_cphys, int transposed,

@@ -1,6 +1,6 @@
-"""-m gpu: the LDConv sampling backward through the C-ABI -- the deterministic gather (dy_ldconv_sample_backward_gather),
-its in-call atomic fallback for large offsets, and the plain scatter entry -- against torch autograd over the oracle's
-restatement of the reference's sampling stage (oracle.nn.ld_sample, nn/modules/conv.py:368-404)."""
+"""-m gpu: the LDConv sampling backward through the C-ABI -- the deterministic gather (dy_ldconv_sample_backward_gather)
+with its atomic side pass for samples beyond the gather radius, and the plain scatter entry -- against torch autograd over
+the oracle's restatement of the reference's sampling stage (oracle.nn.ld_sample, nn/modules/conv.py:368-404)."""
 import pytest
 import torch
 
@@ -8,8 +8,9 @@ from gpu_util import h16, relerr
 
 pytestmark = pytest.mark.gpu
 
-# (C, Np, stride, H, W, offset magnitude): sub-pixel / typical trained range / beyond the gather radius (fallback) /
-# far outside the map (every clamp branch); odd sizes, C with 1 / 2 / 4 granules per thread
+# (C, Np, stride, H, W, offset magnitude): sub-pixel / typical trained range / beyond the gather radius (near samples
+# gathered, far ones through the side pass) / far outside the map (every clamp branch); odd sizes, C with 1 / 2 / 4 granules
+# per thread
 CASES = [(16, 3, 2, 24, 36, 0.0), (16, 3, 2, 24, 36, 0.9), (32, 1, 1, 17, 23, 1.7), (64, 3, 2, 15, 21, 2.5), (128, 1, 1, 9, 12, 3.9),
          (8, 3, 2, 20, 28, 1.2), (24, 1, 1, 11, 13, 0.7), (32, 3, 2, 16, 16, 6.0), (16, 1, 1, 10, 14, 40.0), (32, 5, 1, 12, 10, 1.5)]
 
@@ -24,7 +25,7 @@ def _reference(x, off, gxo, Np, s):
     return xo.detach(), x.grad, off.grad
 
 
-def _run(C_, Np, s, H, W, mag, mode, accumulate=0):
+def _run(C_, Np, s, H, W, mag, mode, accumulate=0, rmax=2):
     from oracle.graph import ld_p_n
     from ultralytics.hip import check, lib
     g = torch.Generator().manual_seed(C_ * 1000 + Np * 100 + H)
@@ -53,7 +54,7 @@ def _run(C_, Np, s, H, W, mag, mode, accumulate=0):
     if mode == "gather":
         check(lib().dy_ldconv_sample_backward_gather(xd.data_ptr(), C_, offd.data_ptr(), 2 * Np, pn.data_ptr(), gd.data_ptr(), Np * C_,
                                                      dx.data_ptr(), C_, accumulate, dx32.data_ptr(), doff.data_ptr(), lddoff,
-                                                     scratch.data_ptr(), B, H, W, h, w, C_, Np, s, None), "dy_ldconv_sample_backward_gather")
+                                                     scratch.data_ptr(), rmax, B, H, W, h, w, C_, Np, s, None), "dy_ldconv_sample_backward_gather")
         measured = scratch[:1].view(torch.float32).item()
         assert abs(measured - off.abs().max().item()) < 1e-6
     else:
@@ -68,9 +69,10 @@ def _run(C_, Np, s, H, W, mag, mode, accumulate=0):
     return (xo_g, xo_ref), (gx, gx_ref + prev), (goff, goff_ref), dx
 
 
+@pytest.mark.parametrize("rmax", [1, 2, 4])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "C{}_N{}_s{}_{}x{}_off{}".format(*c))
-def test_gather_backward_matches_autograd(case):
-    (xo, xo_ref), (gx, gx_ref), (goff, goff_ref), _ = _run(*case, mode="gather")
+def test_gather_backward_matches_autograd(case, rmax):
+    (xo, xo_ref), (gx, gx_ref), (goff, goff_ref), _ = _run(*case, mode="gather", rmax=rmax)
     assert relerr(xo, xo_ref) < 2e-3
     assert relerr(gx, gx_ref) < 2e-3  # one fp16 rounding of an fp32 sum
     assert relerr(goff, goff_ref) < 3e-3
@@ -86,6 +88,7 @@ def test_gather_accumulates_and_agrees_with_scatter(case):
 
 
 def test_gather_is_bitwise_reproducible():
-    a = _run(*CASES[3], mode="gather")[3]
-    b = _run(*CASES[3], mode="gather")[3]
+    """No far sample (|offset| <= 2.5 < rmax = 4): no atomics anywhere, so two runs agree bit for bit."""
+    a = _run(*CASES[3], mode="gather", rmax=4)[3]
+    b = _run(*CASES[3], mode="gather", rmax=4)[3]
     assert torch.equal(a, b)

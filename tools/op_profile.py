@@ -37,8 +37,8 @@ for name, a, ms in prof:
         d = f"C={a[15]} Np={a[16]} s{a[17]} {a[11]}x{a[12]}->{a[13]}x{a[14]} n={a[10]} dx={'y' if a[7] else 'n'}"
         by = a[10] * a[13] * a[14] * a[16] * a[15] * 2
     elif name == "dy_ldconv_sample_backward_gather":
-        d = f"C={a[19]} Np={a[20]} s{a[21]} {a[15]}x{a[16]}->{a[17]}x{a[18]} n={a[14]}"
-        by = a[14] * (a[17] * a[18] * a[20] + 2 * a[15] * a[16]) * a[19] * 2  # dxo + x (offset gradient) in, dx out
+        d = f"C={a[20]} Np={a[21]} s{a[22]} {a[16]}x{a[17]}->{a[18]}x{a[19]} n={a[15]}"
+        by = a[15] * (a[18] * a[19] * a[21] + 2 * a[16] * a[17]) * a[20] * 2  # dxo + x (offset gradient) in, dx out
     elif name in ("dy_bn_act_apply",):
         d = f"npix={a[7]} C={a[8]}"
         by = a[7] * a[8] * 2 * 2
