@@ -36,6 +36,45 @@ extern "C" int dy_import_image(const float* x, void* y, int n, int c, int h, int
   return DY_OK;
 }
 
+// uint8 NHWC RGB (what an image decoder / the data loader's pinned batch holds) -> fp16 NHWC, channels zero-padded to Cp,
+// value = float(u8) / 255 exactly as the reference's preprocess_batch (models/yolo/detect/train.py:59) before the fp16 cast.
+// Four pixels per thread: 12 input bytes as three dwords, four 16-byte stores per 8-channel granule.
+__global__ __launch_bounds__(256) void import_image_u8_kernel(const unsigned char* x, f16* y, long npix, int Cp) {
+  const long quads = npix >> 2;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
+    const unsigned* p = reinterpret_cast<const unsigned*>(x + q * 12);
+    const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
+    const unsigned char b[12] = {(unsigned char)w0, (unsigned char)(w0 >> 8), (unsigned char)(w0 >> 16), (unsigned char)(w0 >> 24),
+                                 (unsigned char)w1, (unsigned char)(w1 >> 8), (unsigned char)(w1 >> 16), (unsigned char)(w1 >> 24),
+                                 (unsigned char)w2, (unsigned char)(w2 >> 8), (unsigned char)(w2 >> 16), (unsigned char)(w2 >> 24)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = j < 3 ? (f16)((float)b[3 * k + j] / 255.f) : (f16)0.f;
+      f16* d = y + (q * 4 + k) * Cp;
+      *reinterpret_cast<half8*>(d) = v;
+      for (int c0 = 8; c0 < Cp; c0 += 8) *reinterpret_cast<half8*>(d + c0) = half8{};
+    }
+  }
+  // tail (npix not a multiple of 4)
+  for (long pix = (quads << 2) + (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
+    half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = j < 3 ? (f16)((float)x[pix * 3 + j] / 255.f) : (f16)0.f;
+    *reinterpret_cast<half8*>(y + pix * Cp) = v;
+    for (int c0 = 8; c0 < Cp; c0 += 8) *reinterpret_cast<half8*>(y + pix * Cp + c0) = half8{};
+  }
+}
+extern "C" int dy_import_image_u8(const void* x, void* y, int n, int h, int w, int cp, hipStream_t stream) {
+  if ((cp & 7) || cp < 8) return DY_ERR_ALIGN;
+  if ((uintptr_t)x & 3) return DY_ERR_ALIGN;
+  const long npix = (long)n * h * w;
+  hipLaunchKernelGGL(import_image_u8_kernel, dim3(grid_for((npix + 3) / 4)), dim3(256), 0, stream, (const unsigned char*)x, (f16*)y, npix, cp);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
 // ---- generic 8-channel-granule element-wise kernels
 struct EwArgs {
   const f16* a;

@@ -1,8 +1,12 @@
-"""Batch sources in the dataloader's batch-dict format (reference data/dataset.py:207-224).  The real CPU data pipeline
-(YOLO-format reader, mosaic/HSV/affine) is out of scope; this synthetic source follows the
-recipe of SURVEY.md section 8(d)."""
+"""Batch sources in the dataloader's batch-dict format (reference data/dataset.py:207-224): the YOLO-format dataset reader
+and loader (dataset.py / build.py / utils.py, SURVEY.md section 8f row 2 -- augmentation-free subset) and a synthetic source
+following the recipe of SURVEY.md section 8(d)."""
 import numpy as np
 import torch
+
+from .build import HipDataLoader, build_dataloader, build_yolo_dataset  # noqa: F401
+from .dataset import YOLODataset  # noqa: F401
+from .utils import check_det_dataset  # noqa: F401
 
 
 class SyntheticDetection:

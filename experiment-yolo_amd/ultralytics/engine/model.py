@@ -35,10 +35,19 @@ class YOLO:
         return self
 
     def train(self, data=None, batch=16, imgsz=640, **kw):
-        """``data``: a re-iterable of batch dicts (img float [0,1] | uint8, batch_idx, cls, bboxes)."""
-        if data is None or isinstance(data, (str, Path)):
-            raise NotImplementedError("dataset YAML loading belongs to the CPU data pipeline (SURVEY.md section 8f); pass an "
-                                      "iterable of batch dicts, e.g. ultralytics.data.SyntheticDetection(...)")
+        """``data``: a dataset YAML (YOLO-format folders; reference data/utils.py:252) or a re-iterable of batch dicts (img float
+        [0,1] | uint8, batch_idx, cls, bboxes), e.g. ultralytics.data.SyntheticDetection(...)."""
+        if data is None:
+            raise ValueError("data=<dataset yaml> or an iterable of batch dicts is required")
+        if isinstance(data, (str, Path)):
+            from ..data import check_det_dataset
+            nc = check_det_dataset(data)["nc"]
+            if nc != self.model.model[-1].nc:  # the reference rebuilds the model with the dataset's class count
+                if self.ckpt_path is not None:
+                    raise ValueError(f"checkpoint has {self.model.model[-1].nc} classes, dataset has {nc}")
+                self.model = DetectionModel(self.model.yaml, nc=nc, verbose=False)
+            self.trainer = DetectionTrainer(self.model, overrides=dict(batch=batch, imgsz=imgsz, data=str(data), **kw))
+            return self.trainer.train_on_dataset(data, batch, imgsz)
         self.trainer = DetectionTrainer(self.model, overrides=dict(batch=batch, imgsz=imgsz, **kw))
         return self.trainer.train(data, batch, imgsz)
 
@@ -53,12 +62,19 @@ class YOLO:
 
     __call__ = predict
 
-    def val(self, data=None, **kw):
-        """``data``: a re-iterable of batch dicts (as for ``train``).  Returns the metrics dict of the reference's
-        DetMetrics.results_dict (precision, recall, mAP50, mAP50-95, fitness)."""
-        if data is None or isinstance(data, (str, Path)):
-            raise NotImplementedError("dataset YAML loading belongs to the CPU data pipeline (SURVEY.md section 8f); pass an "
-                                      "iterable of batch dicts")
+    def val(self, data=None, batch=32, **kw):
+        """``data``: a dataset YAML (its 'val' split, rectangular batches as in the reference) or a re-iterable of batch dicts.
+        Returns the metrics dict of the reference's DetMetrics.results_dict (precision, recall, mAP50, mAP50-95, fitness)."""
         from ..models.yolo.detect import DetectionValidator
-        self.validator = DetectionValidator(dataloader=data, args=kw or None)
+        if data is None:
+            raise ValueError("data=<dataset yaml> or an iterable of batch dicts is required")
+        if isinstance(data, (str, Path)):
+            from ..data import check_det_dataset
+            d = check_det_dataset(data)
+            tr = DetectionTrainer(self.model, overrides=dict(batch=batch, **kw))
+            self.model.names = d["names"]
+            data = tr.get_dataloader(d["val"], batch, 0, "val", d)
+            self.validator = DetectionValidator(dataloader=data, args=tr.args)
+        else:
+            self.validator = DetectionValidator(dataloader=data, args=kw or None)
         return self.validator(model=self.model)

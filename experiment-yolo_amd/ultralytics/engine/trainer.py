@@ -2,7 +2,8 @@
 warm-up interpolation of lr / momentum / accumulate, linear | cosine LR, parameter groups, global-norm clip 10, SGD-nesterov
 | Adam(W) ('auto' rule), EMA, one process per GPU with a single RCCL all-reduce per step.  The batch source is any iterable
 of the dataloader's batch dicts (img, batch_idx, cls, bboxes; reference data/dataset.py:207-224): the CPU data pipeline
-itself is out of scope."""
+(``ultralytics.data``: YOLO-format reader + pinned-buffer loader, augmentation-free) plugs in through ``get_dataloader`` /
+``train(data=<yaml>)``."""
 from __future__ import annotations
 
 import math
@@ -99,6 +100,8 @@ class DetectionTrainer:
         self.setup(nb, batch_size, imgsz)
         hist = []
         for epoch in range(a.epochs):
+            if getattr(self, "_epoch_hook", None):
+                self._epoch_hook(epoch)  # DistributedSampler.set_epoch (engine/trainer.py:766-767)
             t0, tloss = time.time(), None
             for i, batch in enumerate(loader):
                 ni = i + nb * epoch
@@ -112,6 +115,43 @@ class DetectionTrainer:
             if self.rank == 0:
                 LOGGER.info(f"epoch {epoch + 1}/{a.epochs}  box/cls/dfl {[round(float(x), 4) for x in hist[-1]]}  "
                             f"{nb * batch_size * self.world_size / (time.time() - t0):.1f} img/s")
+        return hist
+
+    # ---- dataset-backed entry points (reference models/yolo/detect/train.py:33-55, engine/trainer.py:517-548) -------------
+    def get_dataloader(self, dataset_path, batch_size=16, rank=0, mode="train", data=None):
+        """Loader over a YOLO-format image folder.  Train: shuffled, fixed-size batches (``drop_last`` -- the recorded launch
+        list has one batch size; the reference also trains on the ragged tail), images delivered as uint8 NHWC on the device;
+        val: the reference's rectangular batches, uint8 NCHW on the host side until ``preprocess``."""
+        from ..data import build_dataloader, build_yolo_dataset
+        a = self.args
+        if mode == "train":
+            on = [k for k in ("mosaic", "mixup", "copy_paste", "hsv_h", "hsv_s", "hsv_v", "degrees", "translate", "scale", "shear",
+                              "perspective", "flipud", "fliplr") if getattr(a, k, 0)]
+            if on:
+                LOGGER.warning(f"WARNING augmentations {on} are not on this path (cv2 pipeline): training without them")
+        ds = build_yolo_dataset(a, dataset_path, batch_size, data, mode=mode, rect=mode == "val", stride=32,
+                                layout="nhwc" if mode == "train" else "nchw")
+        return build_dataloader(ds, batch_size, a.workers, shuffle=mode == "train", rank=rank if self.world_size > 1 else -1,
+                                world_size=self.world_size, device=self.device if mode == "train" else None, drop_last=mode == "train")
+
+    def train_on_dataset(self, data_yaml, batch_size, imgsz):
+        """``YOLO.train(data=<yaml>)``: check the dataset YAML, build the loaders, train, validate the EMA model on 'val'."""
+        from ..data import check_det_dataset
+        from ..models.yolo.detect import DetectionValidator
+        self.data = check_det_dataset(data_yaml)
+        self.model.names = self.data["names"]
+        loader = self.get_dataloader(self.data["train"], batch_size, self.rank, "train", self.data)
+        if len(loader) == 0:
+            raise ValueError(f"the training split holds {len(loader.dataset)} images, fewer than one batch of {batch_size}")
+        self._epoch_hook = loader.set_epoch
+        most = max((len(lb["cls"]) for lb in loader.dataset.labels), default=1)
+        self.args.nmax = max(8, (most + 7) // 8 * 8)  # per-image label capacity of the recorded loss kernels
+        hist = self.train(loader, batch_size, imgsz)
+        self.metrics = None
+        if self.args.val and self.rank == 0:
+            vloader = self.get_dataloader(self.data["val"], batch_size * 2, 0, "val", self.data)
+            self.validator = DetectionValidator(dataloader=vloader, args=self.args)
+            self.metrics = self.validator(model=self.ema.ema)
         return hist
 
     def save_model(self, path, reference_format=False):

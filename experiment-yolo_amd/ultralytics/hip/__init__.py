@@ -62,6 +62,7 @@ SIGNATURES = {
     "dy_bn_bwd_finalize": (i32, [vp, i32, vp, vp, vp, i32, f32, i32, vp]),
     "dy_bn_act_bwd_apply": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, i64, i32, i32, i32, vp]),
     "dy_import_image": (i32, [vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "dy_import_image_u8": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "dy_add": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]),
     "dy_upsample2x": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_maxpool5": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),

@@ -303,6 +303,15 @@ class Engine:
         self.call("dy_import_image", img.data_ptr(), out.ptr, N, Cc, H, W, cp, float(mul))
         return out
 
+    def import_image_u8(self, img, cp=8):
+        """NHWC uint8 RGB image batch (the loader's format) -> NHWC fp16 Act, value/255, channels zero-padded to ``cp``."""
+        N, H, W, Cc = img.shape
+        assert img.dtype == torch.uint8 and img.is_contiguous() and Cc == 3
+        out = self.new_act(N, H, W, cp)
+        out.needs_grad = False
+        self.call("dy_import_image_u8", img.data_ptr(), out.ptr, N, H, W, cp)
+        return out
+
     def _conv_raw(self, spec, x, y_ptr, ldy, epi, partials_ptr=0, bias=None):
         self.call("dy_conv_forward", x.ptr, x.ld, spec.wpack.data_ptr(), _ptr(bias), y_ptr, ldy, partials_ptr, x.N, x.H, x.W,
                   x.C, spec.cout, spec.ks, spec.stride, 1, 0, 0, epi, None)

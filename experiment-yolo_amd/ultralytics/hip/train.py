@@ -47,6 +47,7 @@ class StepPlan:
         self.state[0] = init_scale
         self.partials = torch.zeros(4096, dtype=torch.float32, device=dev)
         self.img = torch.zeros((batch_size, 3, *self.imgsz), dtype=torch.float32, device=dev)
+        self.input_u8 = False  # decided by the first batch: uint8 NHWC (the loader's format) or float NCHW (the public tensor API)
         self.rec_fb = None
         self.rec_opt, self.graph_opt = {}, {}
         self.graph_fb = None
@@ -73,7 +74,7 @@ class StepPlan:
         eng.training = True
         try:
             rt.pack_all(transposed=True)
-            x = eng.import_image(self.img, 8)
+            x = eng.import_image_u8(self.img, 8) if self.input_u8 else eng.import_image(self.img, 8)
             ho = model.forward_act(x)
             crit.bind(ho, self.nmax, gscale=self.state[0:1])
             crit.sync_modes()
@@ -93,9 +94,20 @@ class StepPlan:
     def forward_backward(self, batch):
         """Stage the batch, run fwd+loss+bwd; gradients (scaled by the loss scale) land in rt.flat_g."""
         img = batch["img"]
+        u8 = img.dtype == torch.uint8 and img.dim() == 4 and img.shape[-1] == 3 and img.shape[1] != 3  # (B,H,W,3)
+        if self.rec_fb is None and u8:
+            self.input_u8 = True
+            self.img = torch.zeros((self.B, *self.imgsz, 3), dtype=torch.uint8, device=self.img.device)
+        if self.input_u8 and not u8:
+            raise TypeError("this plan was recorded for uint8 NHWC batches (the loader's format); got "
+                            f"{img.dtype} {tuple(img.shape)}")
         if img.data_ptr() != self.img.data_ptr():  # a producer that writes straight into ``plan.img`` (the static input of the
-            if img.dtype == torch.uint8:           # recorded launch list) skips this staging copy
+            if u8 and not self.input_u8:           # recorded launch list) skips this staging copy
+                img = img.permute(0, 3, 1, 2)
+            if img.dtype == torch.uint8 and not self.input_u8:
                 img = img.float() / 255
+            if tuple(img.shape) != tuple(self.img.shape):
+                raise ValueError(f"batch images {tuple(img.shape)} do not match the plan's {tuple(self.img.shape)}")
             self.img.copy_(img, non_blocking=True)
         n = self.crit.set_targets(batch, cap=self.B * self.nmax)
         if n > self.B * self.nmax:

@@ -38,6 +38,8 @@ class DetectionValidator:
     def preprocess(self, batch):
         dev = self.device
         img = batch["img"].to(dev, non_blocking=True)
+        if img.dtype == torch.uint8 and img.shape[-1] == 3 and img.shape[1] != 3:  # the loader's NHWC layout
+            img = img.permute(0, 3, 1, 2)
         batch["img"] = img.float() / 255 if img.dtype == torch.uint8 else img.float()
         for k in ("batch_idx", "cls", "bboxes"):
             batch[k] = batch[k].to(dev)

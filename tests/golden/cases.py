@@ -2,6 +2,8 @@
 
 Only inputs are defined here (shapes, seeds, target boxes); expected outputs live in the .npz fixtures.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -148,3 +150,53 @@ def planted_batches(seed, n_batches, B, imgsz, nc, k=3, wh=(0.12, 0.35)):
         out.append(dict(img=img, batch_idx=np.asarray(bi, np.float32), cls=np.asarray(cl, np.float32).reshape(-1, 1),
                         bboxes=np.asarray(bb, np.float32)))
     return out
+
+
+# ----------------------------------------------------------------------------- YOLO-format fixture dataset (data pipeline)
+DATASET_NC = 4
+DATASET_IMGSZ = 64
+
+
+def dataset_spec():
+    """name -> (h, w, label-file text | None).  Long side == 64 everywhere (no interpolation on the reference side, which
+    would need cv2).  Label edge cases follow reference data/utils.py:96-165."""
+    train = {
+        "t00": (64, 64, "0 0.30 0.30 0.20 0.25\n1 0.70 0.60 0.30 0.20\n3 0.50 0.85 0.40 0.10\n"),
+        "t01": (64, 64, ""),                                                   # empty label file -> background
+        "t02": (64, 64, None),                                                 # label file missing -> background
+        "t03": (48, 64, "2 0.5 0.5 0.25 0.5\n2 0.5 0.5 0.25 0.5\n1 0.2 0.2 0.1 0.3\n"),   # duplicate row removed (rows come back sorted)
+        "t04": (64, 48, "0 0.5 0.5 0.02 0.02\n1 0.4 0.6 0.5 0.3\n"),          # first box < 2 px: dropped by the candidate filter
+        "t05": (64, 64, "3 0.02 0.5 0.2 0.3\n0 0.98 0.97 0.5 0.5\n"),         # boxes reaching outside: clipped
+        "t06": (64, 64, "0 -0.1 0.5 0.2 0.2\n"),                              # negative value -> corrupt, image dropped
+        "t07": (64, 64, "0 0.5 1.2 0.2 0.2\n"),                               # non-normalised -> corrupt
+        "t08": (64, 64, "0 0.5 0.5 0.2 0.2 0.9\n"),                           # six columns -> corrupt
+        "t09": (64, 64, "7 0.5 0.5 0.2 0.2\n"),                               # class id beyond nc -> corrupt
+        "t10": (40, 64, "1 0.5 0.5 0.9 0.04\n2 0.25 0.5 0.3 0.6\n"),          # 0.04*40 = 1.6 px high: dropped
+        "t11": (64, 40, "0 0.5 0.01 0.4 0.3\n3 0.6 0.6 0.2 0.2\n"),           # loses > 90 % ... of nothing: keeps (area ratio 0.53)
+        "t12": (64, 64, "2 0.5 0.005 0.5 0.2\n1 0.5 0.5 0.1 0.1\n"),          # clipped to < 10 % of its area?  no: 0.1/0.2 -> h2 < 2 px dropped
+    }
+    val = {
+        "v00": (64, 64, "0 0.3 0.3 0.2 0.2\n"), "v01": (48, 64, "1 0.5 0.5 0.5 0.5\n2 0.2 0.2 0.1 0.1\n"),
+        "v02": (64, 48, "3 0.6 0.4 0.3 0.3\n"), "v03": (32, 64, ""), "v04": (64, 32, "0 0.5 0.5 0.9 0.9\n"),
+        "v05": (64, 56, "1 0.1 0.9 0.15 0.15\n2 0.9 0.1 0.15 0.15\n"), "v06": (40, 64, None),
+    }
+    return dict(train=train, val=val)
+
+
+def write_dataset(root):
+    """Materialise the fixture dataset under ``root`` (PNG + BGR *.npy siblings + labels + data.yaml)."""
+    import zlib
+    from PIL import Image
+    for split, items in dataset_spec().items():
+        os.makedirs(os.path.join(root, "images", split), exist_ok=True)
+        os.makedirs(os.path.join(root, "labels", split), exist_ok=True)
+        for name, (h, w, txt) in items.items():
+            rng = np.random.default_rng(zlib.crc32(name.encode()))
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)  # RGB
+            Image.fromarray(img).save(os.path.join(root, "images", split, name + ".png"))
+            np.save(os.path.join(root, "images", split, name + ".npy"), img[..., ::-1].copy())  # the reference's caches are BGR
+            if txt is not None:
+                with open(os.path.join(root, "labels", split, name + ".txt"), "w") as f:
+                    f.write(txt)
+    with open(os.path.join(root, "data.yaml"), "w") as f:
+        f.write("path: .\ntrain: images/train\nval: images/val\nnc: 4\nnames: [a, b, c, d]\n")

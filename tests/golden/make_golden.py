@@ -39,7 +39,7 @@ from ultralytics.utils.metrics import WiseIouLoss  # noqa: E402
 from ultralytics.utils.torch_utils import ModelEMA, initialize_weights  # noqa: E402
 
 from oracle import graph as og  # noqa: E402
-from cases import MODES, loss_cases, metric_cases, metric_geometry, module_cases, planted_batches, module_shapes, rnd, synth_batch, synth_detections  # noqa: E402
+from cases import DATASET_IMGSZ, write_dataset, MODES, loss_cases, metric_cases, metric_geometry, module_cases, planted_batches, module_shapes, rnd, synth_batch, synth_detections  # noqa: E402
 
 CFG_DIR = os.path.join(_refimport.REF, "ultralytics/cfg/models")
 torch.set_num_threads(8)
@@ -556,6 +556,66 @@ def gen_map():
     print("reference mean_results (P, R, mAP50, mAP50-95):", dm.mean_results())
     npz("map_parity", loss_hist=np.stack(hist), mean_results=np.asarray(dm.mean_results(), np.float64), n_det=np.asarray(len(st["conf"])),
         protocol=np.asarray([P["nc"], P["imgsz"], P["batch"], P["nb"], P["epochs"], P["nval"], P["init_seed"]]))
+
+def gen_data():
+    """Data pipeline: the REFERENCE YOLODataset + build_dataloader over the fixture dataset of
+    cases.write_dataset -- train mode with every augmentation gain at zero (2 epochs, shuffled) and val mode (rect batches).
+    cv2 is absent here; the three calls this path makes into it are given their documented meaning below (constant border,
+    the rotation matrix formula of the OpenCV docs); images come from the *.npy siblings, and nothing is interpolated."""
+    import math
+    import shutil
+    import tempfile
+    import cv2
+    from ultralytics.data import build_dataloader, build_yolo_dataset
+
+    def copy_make_border(img, top, bottom, left, right, border_type, value=(0, 0, 0)):
+        out = np.empty((img.shape[0] + top + bottom, img.shape[1] + left + right, img.shape[2]), img.dtype)
+        out[...] = np.asarray(value, img.dtype)
+        out[top:top + img.shape[0], left:left + img.shape[1]] = img
+        return out
+
+    def rotation_matrix(angle, center, scale):
+        a, b = scale * math.cos(math.radians(angle)), scale * math.sin(math.radians(angle))
+        return np.array([[a, b, (1 - a) * center[0] - b * center[1]], [-b, a, b * center[0] + (1 - a) * center[1]]])
+
+    def no_resize(*a, **k):
+        raise RuntimeError("interpolation is outside the pinned subset")
+
+    cv2.copyMakeBorder, cv2.getRotationMatrix2D, cv2.resize = copy_make_border, rotation_matrix, no_resize
+    cv2.BORDER_CONSTANT, cv2.INTER_LINEAR = 0, 1
+    root = tempfile.mkdtemp(prefix="dy_dataset_")
+    write_dataset(root)
+    zero = dict(mosaic=0.0, mixup=0.0, copy_paste=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, degrees=0.0, translate=0.0, scale=0.0, shear=0.0,
+                perspective=0.0, flipud=0.0, fliplr=0.0)
+    cfg = get_cfg(DEFAULT_CFG, overrides=dict(imgsz=DATASET_IMGSZ, task="detect", **zero))
+    data = {"names": {0: "a", 1: "b", 2: "c", 3: "d"}, "nc": 4}
+    arrs = {}
+
+    def put(tag, batch):
+        arrs[f"{tag}/img"] = batch["img"]
+        arrs[f"{tag}/cls"] = batch["cls"].reshape(-1, 1)
+        arrs[f"{tag}/bboxes"] = batch["bboxes"].reshape(-1, 4)
+        arrs[f"{tag}/batch_idx"] = batch["batch_idx"]
+        arrs[f"{tag}/files"] = np.array([os.path.basename(f) for f in batch["im_file"]])
+        arrs[f"{tag}/ori_shape"] = np.array(batch["ori_shape"])
+        arrs[f"{tag}/resized_shape"] = np.array(batch["resized_shape"])
+        if "ratio_pad" in batch:
+            arrs[f"{tag}/ratio_pad"] = np.array([[rp[0][0], rp[0][1], rp[1][0], rp[1][1]] for rp in batch["ratio_pad"]], dtype=np.float64)
+
+    ds = build_yolo_dataset(cfg, os.path.join(root, "images", "train"), 4, data, mode="train")
+    loader = build_dataloader(ds, 4, 0, shuffle=True, rank=-1)
+    arrs["train/nb"] = len(loader)
+    for ep in range(2):
+        for i, batch in enumerate(loader):
+            put(f"train/e{ep}/b{i}", batch)
+    ds = build_yolo_dataset(cfg, os.path.join(root, "images", "val"), 4, data, mode="val", rect=True, stride=32)
+    loader = build_dataloader(ds, 4, 0, shuffle=False, rank=-1)
+    arrs["val/nb"] = len(loader)
+    for i, batch in enumerate(loader):
+        put(f"val/b{i}", batch)
+    npz("data", **arrs)
+    shutil.rmtree(root)
+
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["modules", "models", "loss", "nms", "trainer", "fullsize", "metrics"]

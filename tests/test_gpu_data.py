@@ -1,0 +1,68 @@
+"""-m gpu: the loader-facing side of the step -- the uint8 NHWC import kernel, a StepPlan recorded for the loader's batches,
+and YOLO.train / YOLO.val driven by a dataset YAML (fixture dataset of golden.cases.write_dataset)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden.cases import write_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def test_import_u8_matches_float_division():
+    from ultralytics.hip import check, lib
+    for n, h, w in ((2, 5, 7), (1, 64, 64), (3, 33, 31)):
+        x = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda")
+        y = torch.full((n, h, w, 8), 7.0, dtype=torch.float16, device="cuda")
+        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, None), "dy_import_image_u8")
+        torch.cuda.synchronize()
+        ref = torch.zeros((n, h, w, 8), dtype=torch.float16, device="cuda")
+        ref[..., :3] = (x.float() / 255).half()
+        assert torch.equal(y, ref)
+
+
+def test_plan_recorded_for_u8_batches_equals_the_float_plan():
+    from ultralytics.hip.train import StepPlan
+    from ultralytics.nn.tasks import DetectionModel
+    g = torch.Generator().manual_seed(3)
+    B, S = 4, 128
+    img = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g)
+    n = 12
+    lab = dict(batch_idx=torch.arange(B).repeat_interleave(3).float(), cls=torch.randint(0, 6, (n, 1), generator=g).float(),
+               bboxes=torch.cat([torch.rand(n, 2, generator=g) * 0.6 + 0.2, torch.rand(n, 2, generator=g) * 0.2 + 0.05], 1))
+    out = []
+    for fmt in ("u8", "f32"):
+        torch.manual_seed(0)
+        m = DetectionModel("yolov8n-ASF-P2P2.yaml", verbose=False).cuda().train()
+        plan = StepPlan(m, B, S, nmax=8, optimizer="SGD", use_graph=False)
+        batch = {k: v.cuda() for k, v in lab.items()}
+        batch["img"] = img.cuda() if fmt == "u8" else (img.permute(0, 3, 1, 2).float() / 255).cuda()
+        plan.forward_backward(batch)
+        torch.cuda.synchronize()
+        out.append((plan.crit.scalars.clone(), plan.rt.flat_g.clone()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    with pytest.raises(TypeError):  # the recorded launch list reads ONE input format (this plan: float NCHW -> fine; u8 plan: not)
+        plan_u8 = StepPlan(m, B, S, nmax=8, optimizer="SGD", use_graph=False)
+        lab_d = {k: v.cuda() for k, v in lab.items()}
+        plan_u8.forward_backward({**lab_d, "img": img.cuda()})
+        plan_u8.forward_backward({**lab_d, "img": torch.rand(B, 3, S, S).cuda()})
+
+
+def test_train_and_val_from_a_dataset_yaml(tmp_path):
+    from ultralytics import YOLO
+    root = str(tmp_path / "ds")
+    write_dataset(root)
+    zero = dict(mosaic=0.0, mixup=0.0, copy_paste=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, degrees=0.0, translate=0.0, scale=0.0, shear=0.0,
+                perspective=0.0, flipud=0.0, fliplr=0.0)
+    y = YOLO("yolov8n-ASF-P2P2.yaml")
+    hist = y.train(data=os.path.join(root, "data.yaml"), batch=4, imgsz=64, epochs=3, optimizer="SGD", workers=2, hipgraph=True, **zero)
+    assert y.model.model[-1].nc == 4  # rebuilt for the dataset's class count
+    assert len(hist) == 3 and all(np.isfinite(np.asarray(h, dtype=np.float64)).all() for h in hist)
+    assert y.trainer.plan.input_u8  # the loader's uint8 NHWC batches went through dy_import_image_u8
+    m = y.trainer.metrics
+    assert set(m) >= {"metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)", "fitness"}
+    assert y.trainer.validator.seen == 7
+    m2 = y.val(data=os.path.join(root, "data.yaml"), batch=4)
+    assert set(m2) == set(m)

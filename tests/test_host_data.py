@@ -1,0 +1,125 @@
+"""CPU: the YOLO-format dataset reader + loader against tests/golden/data.npz, which holds what the
+REFERENCE's YOLODataset + build_dataloader produced for the fixture dataset of golden.cases.write_dataset (train mode with
+all augmentation gains zero, two shuffled epochs; val mode with rectangular batches).  Images, labels, order, shapes and
+ratio_pad must be identical; plus the host-side behaviours the golden cannot hold (PNG decoding without the *.npy caches,
+interpolated sizes, DDP sharding, data YAML checks)."""
+import os
+import shutil
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from golden.cases import DATASET_IMGSZ, write_dataset
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "data.npz")
+
+
+@pytest.fixture(scope="module")
+def root(tmp_path_factory):
+    r = str(tmp_path_factory.mktemp("dataset"))
+    write_dataset(r)
+    return r
+
+
+def _loader(root, mode, layout="nchw", **kw):
+    from ultralytics.data import build_dataloader, build_yolo_dataset, check_det_dataset
+    data = check_det_dataset(os.path.join(root, "data.yaml"))
+    cfg = SimpleNamespace(imgsz=DATASET_IMGSZ, rect=False, cache=False, fraction=1.0)
+    ds = build_yolo_dataset(cfg, data[mode], 4, data, mode=mode, rect=mode == "val", stride=32, layout=layout)
+    return build_dataloader(ds, 4, 2, shuffle=mode == "train", rank=-1, **kw)
+
+
+def _check(G, tag, batch):
+    assert [os.path.basename(f) for f in batch["im_file"]] == list(G[f"{tag}/files"]), tag
+    assert torch.equal(batch["img"], torch.from_numpy(G[f"{tag}/img"])), tag
+    for k in ("cls", "bboxes", "batch_idx"):
+        ref = torch.from_numpy(G[f"{tag}/{k}"])
+        assert batch[k].shape == ref.shape and torch.equal(batch[k], ref), (tag, k, batch[k], ref)
+    assert np.array_equal(np.array(batch["ori_shape"]), G[f"{tag}/ori_shape"])
+    assert np.array_equal(np.array(batch["resized_shape"]), G[f"{tag}/resized_shape"])
+    if f"{tag}/ratio_pad" in G:
+        rp = np.array([[r[0][0], r[0][1], r[1][0], r[1][1]] for r in batch["ratio_pad"]], dtype=np.float64)
+        assert np.array_equal(rp, G[f"{tag}/ratio_pad"])
+
+
+def test_train_batches_identical_to_reference_over_two_epochs(root):
+    G = np.load(GOLD)
+    loader = _loader(root, "train")
+    assert len(loader) == int(G["train/nb"])
+    assert len(loader.dataset) == 9  # 13 files, 4 dropped as corrupt
+    for ep in range(2):
+        for i, batch in enumerate(loader):
+            _check(G, f"train/e{ep}/b{i}", batch)
+
+
+def test_val_rect_batches_identical_to_reference(root):
+    G = np.load(GOLD)
+    loader = _loader(root, "val")
+    assert len(loader) == int(G["val/nb"])
+    for i, batch in enumerate(loader):
+        _check(G, f"val/b{i}", batch)
+
+
+def test_nhwc_layout_and_png_decoding_agree_with_the_cached_arrays(root, tmp_path):
+    a = [b for b in _loader(root, "val")]
+    nhwc = [b for b in _loader(root, "val", layout="nhwc")]
+    bare = str(tmp_path / "bare")
+    shutil.copytree(root, bare)
+    for split in ("train", "val"):
+        for f in os.listdir(os.path.join(bare, "images", split)):
+            if f.endswith(".npy"):
+                os.remove(os.path.join(bare, "images", split, f))
+    png = [b for b in _loader(bare, "val")]
+    for x, y, z in zip(a, nhwc, png):
+        assert torch.equal(x["img"], y["img"].permute(0, 3, 1, 2)) and torch.equal(x["img"], z["img"])
+        assert torch.equal(x["bboxes"], z["bboxes"])
+
+
+def test_interpolated_sizes_keep_geometry(tmp_path):
+    """Long side != imgsz: load_image resizes (bilinear; the reference's cv2 fixed-point INTER_LINEAR is not pinned) -- shapes,
+    padding and label geometry still follow the reference's formulas."""
+    from PIL import Image
+    from ultralytics.data import YOLODataset
+    r = tmp_path / "ds"
+    (r / "images" / "train").mkdir(parents=True)
+    (r / "labels" / "train").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 256, (30, 100, 3), dtype=np.uint8)).save(r / "images" / "train" / "a.png")
+    (r / "labels" / "train" / "a.txt").write_text("1 0.5 0.5 0.4 0.6\n")
+    s = YOLODataset(str(r / "images" / "train"), imgsz=64, augment=True, data={"nc": 2})[0]
+    assert tuple(s["img"].shape) == (64, 64, 3) and s["ori_shape"] == (30, 100)
+    # resized to 20x64 (ceil(30*0.64) = 20), centred: rows 22..41 hold the image, the rest is the 114 border
+    assert (s["img"][:22] == 114).all() and (s["img"][42:] == 114).all() and not (s["img"][22:42] == 114).all()
+    np.testing.assert_allclose(s["bboxes"].numpy(), [[0.5, 0.5, 0.4, 0.6 * 20 / 64]], rtol=1e-6)
+
+
+def test_ddp_sharding_matches_torch_distributed_sampler(root):
+    from torch.utils.data.distributed import DistributedSampler
+    full = _loader(root, "train")
+    n = len(full.dataset)
+    for epoch in (0, 3):
+        for rank in range(2):
+            ld = _loader(root, "train", world_size=2)
+            ld.rank = rank
+            ld.set_epoch(epoch)
+            ref = DistributedSampler(range(n), num_replicas=2, rank=rank, shuffle=True)
+            ref.set_epoch(epoch)
+            assert ld._indices() == list(ref)
+
+
+def test_data_yaml_errors(tmp_path):
+    from ultralytics.data import check_det_dataset
+    p = tmp_path / "d.yaml"
+    p.write_text("train: images/train\nnc: 2\n")
+    with pytest.raises(SyntaxError):
+        check_det_dataset(str(p))
+    p.write_text("train: images/train\nval: images/val\nnc: 2\nnames: [a]\n")
+    with pytest.raises(SyntaxError):
+        check_det_dataset(str(p))
+    p.write_text("train: images/train\nval: images/val\nnc: 2\n")
+    with pytest.raises(FileNotFoundError):
+        check_det_dataset(str(p))
+    with pytest.raises(FileNotFoundError):
+        check_det_dataset(str(tmp_path / "missing.yaml"))
