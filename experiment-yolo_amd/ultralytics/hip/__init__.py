@@ -62,6 +62,9 @@ SIGNATURES = {
     "dy_bn_bwd_finalize": (i32, [vp, i32, vp, vp, vp, i32, f32, i32, vp]),
     "dy_bn_act_bwd_apply": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, i64, i32, i32, i32, vp]),
     "dy_import_image": (i32, [vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "dy_crop_letterbox_u8": (i32, [vp, i32, i32, vp, vp, i32, i32, vp, vp]),
+    "dy_refine_select": (i32, [vp, vp, vp, vp, vp, i32, C.c_float, C.c_float, vp, vp, vp]),
+    "dy_nms_hard": (i32, [vp, vp, vp, i32, C.c_float, vp, vp]),
     "dy_import_image_u8": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "dy_add": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]),
     "dy_upsample2x": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -223,6 +223,20 @@ int dy_match_predictions(const float* preds, const int* pred_off, const float* t
 /* utils/metrics.py:53-73 box_iou: (n,4) x (m,4) xyxy fp32 -> (n,m) */
 int dy_box_iou(const float* box1, int n, const float* box2, int m, float* out, hipStream_t stream);
 
+/* ---- two-stage ("double") inference, double_inference.py:98-305 ----------------------------------------------------
+ * crop + resize + letterbox of K rectangles of one HBM-resident uint8 HWC image into a (K,S,S,3) batch
+ * (prepare_cropped_image_cv2 :129-149; rects x1,y1,x2,y2 with exclusive x2/y2; geom new_w,new_h,pad_x,pad_y per crop). */
+int dy_crop_letterbox_u8(const void* img, int H, int W, const int* rects, const int* geom, int K, int S, void* out,
+                         hipStream_t stream);
+/* per first-stage detection: map its crop's second-stage rows back (scale_boxes_vectorized :152-161) and pick the
+ * replacement of process_refined_boxes_optimized :263-303.  dets: packed (x1,y1,x2,y2,conf,cls) rows, offsets (K+1),
+ * orig (K,6), scale (K,3) ratio,pad_x,pad_y; out (K,6), found (K). */
+int dy_refine_select(const float* dets, const int* offsets, const float* orig, const int* rects, const float* scale, int K,
+                     float img_w, float img_h, float* out, int* found, hipStream_t stream);
+/* greedy per-class NMS in descending score order, suppress IoU > iou_thr (torchvision_nms :164-203); n <= 2048; keep: n bytes */
+int dy_nms_hard(const float* boxes, const float* scores, const float* labels, int n, float iou_thr, void* keep,
+                hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

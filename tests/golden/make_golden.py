@@ -617,6 +617,85 @@ def gen_data():
     shutil.rmtree(root)
 
 
+def gen_two_stage():
+    """Two-stage inference: outputs of the reference script's OWN functions.  double_inference.py is
+    a Kaggle script whose import has side effects (creates /kaggle/... folders, opens a log file), so only its function
+    definitions are compiled -- read from the reference tree at generation time, nothing is copied -- and called on seeded
+    inputs.  torchvision is absent here, so torchvision_nms takes its built-in fallback branch."""
+    import ast
+    src = open(os.path.join(_refimport.REF, "double_inference.py")).read()
+    tree = ast.parse(src)
+    want = {"calculate_iou_tensor", "calculate_iou", "calculate_optimal_crop_batch", "scale_boxes_vectorized", "torchvision_nms",
+            "process_refined_boxes_optimized"}
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    for f in fns:
+        f.decorator_list = []  # @torch.jit.script: same arithmetic, eager
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "double_inference.py", "exec"), ns)
+    rng = np.random.default_rng(11)
+    arrs = {}
+    # crops
+    W, H = 900, 600
+    n = 64
+    c = np.stack([rng.uniform(0, W, n), rng.uniform(0, H, n)], 1)
+    wh = np.exp(rng.uniform(np.log(2), np.log(300), (n, 2)))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], 1)
+    boxes[:4] = [[0, 0, 5, 5], [W - 6, H - 6, W, H], [10.5, 20.25, 14.75, 300.5], [-20, -30, 50, 40]]
+    dets = [{"bbox": [float(v) for v in b], "score": 0.5, "category_id": 0} for b in boxes]
+    crops = ns["calculate_optimal_crop_batch"](dets, W, H)
+    arrs["crop/boxes"], arrs["crop/wh"] = boxes, np.array([W, H])
+    arrs["crop/rects"] = np.array([[c["x1"], c["y1"], c["x2"], c["y2"]] for c in crops])
+    # scale + refine: per case one original detection and a candidate set around it
+    K = 40
+    for k in range(K):
+        ob = boxes[k % n].clip(0, [W, H, W, H]).astype(np.float32)
+        if ob[2] - ob[0] < 2 or ob[3] - ob[1] < 2:
+            ob = np.array([100, 100, 160, 150], np.float32)
+        rect = arrs["crop/rects"][k % n]
+        cw, ch = int(rect[2] - rect[0]), int(rect[3] - rect[1])  # Python ints, as crop.shape gives the script
+        ratio = min(640 / cw, 640 / ch)
+        nw, nh = int(cw * ratio), int(ch * ratio)
+        px, py = (640 - nw) // 2, (640 - nh) // 2
+        m = int(rng.integers(0, 12))
+        # candidates in crop-canvas coordinates: jittered copies of the original box mapped into the canvas, plus strays
+        base = (ob - np.array([rect[0], rect[1], rect[0], rect[1]])) * ratio + np.array([px, py, px, py])
+        cand = (base[None] + rng.normal(0, 25, (m, 4))).astype(np.float32)
+        if m > 2:
+            cand[0] = rng.uniform(0, 640, 4)
+            cand[1] = base  # exact hit
+        cand = cand.clip(0, 640).astype(np.float32)
+        labels = rng.integers(0, 3, m).astype(int)
+        confs = rng.uniform(0.25, 1.0, m).astype(np.float32)
+        if m > 4:
+            confs[3] = confs[2]  # a tie in confidence
+        odet = {"bbox": [float(v) for v in ob], "score": float(rng.uniform(0.25, 0.9)), "category_id": int(rng.integers(0, 3))}
+        crop_info = {"x1": int(rect[0]), "y1": int(rect[1]), "x2": int(rect[2]), "y2": int(rect[3])}
+        scaled = ns["scale_boxes_vectorized"](cand, px, py, crop_info, ratio)
+        res = ns["process_refined_boxes_optimized"](scaled, labels, confs, odet, W, H) if m else None
+        arrs[f"ref/{k}/cand"], arrs[f"ref/{k}/labels"], arrs[f"ref/{k}/confs"] = cand, labels, confs
+        arrs[f"ref/{k}/orig"] = np.array(odet["bbox"] + [odet["score"], odet["category_id"]], np.float64)
+        arrs[f"ref/{k}/rect"], arrs[f"ref/{k}/geom"] = rect, np.array([ratio, px, py], np.float64)
+        arrs[f"ref/{k}/scaled"] = np.asarray(scaled, np.float32).reshape(-1, 4)
+        arrs[f"ref/{k}/out"] = np.array(res["bbox"] + [res["score"], res["category_id"]], np.float64) if res else np.zeros(0)
+    arrs["ref/n"] = K
+    # per-class NMS
+    for k, m in enumerate((1, 2, 7, 40, 150)):
+        c = np.stack([rng.uniform(50, 400, m), rng.uniform(50, 300, m)], 1)
+        wh = rng.uniform(20, 120, (m, 2))
+        b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+        sc = rng.uniform(0.25, 1, m).astype(np.float32)
+        if m > 6:
+            sc[5] = sc[4]
+            b[6] = b[2]  # identical boxes
+        lab = rng.integers(0, 3, m)
+        kb, ks, kl = ns["torchvision_nms"](b.tolist(), sc.tolist(), lab.tolist(), 0.45)
+        arrs[f"nms/{k}/boxes"], arrs[f"nms/{k}/scores"], arrs[f"nms/{k}/labels"] = b, sc, lab
+        arrs[f"nms/{k}/kept_boxes"], arrs[f"nms/{k}/kept_scores"] = np.array(kb, np.float32).reshape(-1, 4), np.array(ks, np.float32)
+        arrs[f"nms/{k}/kept_labels"] = np.array(kl, np.int64)
+    arrs["nms/n"] = 5
+    npz("two_stage", **arrs)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["modules", "models", "loss", "nms", "trainer", "fullsize", "metrics"]
     for w in which:
