@@ -1161,7 +1161,10 @@ static int pick_cc(int cin_p, int ks, int stride) {
 }
 // cout rows per workgroup = 16*MT.  48 / 80 / 96-channel outputs take MT = 4 with a padded last group (zero weight rows, masked
 // stores): these layers are memory-bound, and MT = 1 would stream the whole input once per 16 output channels
-static int pick_mt(int cout16) { return cout16 >= 48 ? 4 : (cout16 == 32 ? 2 : 1); }
+static int pick_mt(int cout16) {
+  if (const char* e = getenv("DY_CONV_MT")) return atoi(e);  // measurement switch
+  return cout16 >= 48 ? 4 : (cout16 == 32 ? 2 : 1);
+}
 
 extern "C" int dy_conv_geometry(int cin, int cout, int ks, int stride, int* cin_p, int* cout_p, int* cc, int* nch,
                                 int* mt, int* ngroups, int* ksteps, int* packed_elems) {

@@ -28,6 +28,9 @@ for name, a, ms in prof:
         n, h, w, cin, cout, ks, s, dil = a[7:15]
         d = f"{cin}->{cout} k{ks} s{s} dil{dil} @{h}x{w} epi{a[17]}"
         by = plan.conv_algorithmic_bytes(a)
+        pp = ks // 2 * dil
+        fl = 2.0 * n * ((h + 2 * pp - dil * (ks - 1) - 1) // s + 1) * ((w + 2 * pp - dil * (ks - 1) - 1) // s + 1) * cin * cout * ks * ks
+        d += f" {fl / ms / 1e9:6.0f}TF"
     elif name == "dy_conv_wgrad":
         n, h, w, cin, cout, ks, s = a[6:13]
         d = f"{cin}->{cout} k{ks} s{s} @{h}x{w}"
@@ -53,5 +56,5 @@ for name, a, ms in prof:
     rows.append((ms, name, d, by))
 tot = sum(r[0] for r in rows)
 print(f"total device ms/step {tot:.2f}  ({len(rows)} calls)")
-for ms, name, d, by in sorted(rows, key=lambda r: -r[0])[:60]:
-    print(f"{ms*1e3:9.1f} us  {name:24s} {d:40s} {by/ms/1e6 if by else 0:8.0f} GB/s")
+for ms, name, d, by in sorted(rows, key=lambda r: -r[0])[:int(os.environ.get('TOP', '60'))]:
+    print(f"{ms*1e3:9.1f} us  {name:24s} {d:48s} {by/ms/1e6 if by else 0:8.0f} GB/s")
