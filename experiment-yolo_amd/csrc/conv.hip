@@ -30,6 +30,7 @@ struct ConvArgs {
   int dil;        // 1, or 2 = zero-dilated virtual input (stride-2 dgrad)
   int tiles_x, tiles_y;
   int npix;       // FLAT (1x1) only: N*Ho*Wo
+  int xcd_map;    // 1: workgroups of one XCD (blockIdx.x % 8) own a contiguous band of tiles, so halo rows meet in one L2
 };
 
 template <int CC, int MT, int KS, int STRIDE, int TROWS>
@@ -711,10 +712,14 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
   };
 
   const int gstride = 2 * gridDim.x;
-  const int gt0 = blockIdx.x * 2 + g;
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  With the identity map the tiles of one period are
+  // spread over all XCDs and every halo row is fetched into two L2s; mapping XCD x to the x-th eighth of the period's tiles
+  // keeps vertical neighbours on one XCD (only the band edges still meet a second L2).
+  const int vb = (a.xcd_map && !(gridDim.x & 7)) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int gt0 = vb * 2 + g;
   const int ntg = gt0 < ntiles ? (ntiles - gt0 + gstride - 1) / gstride : 0;
   const int J = ntg * a.nch;
-  const int Jmax = ((ntiles - (int)blockIdx.x * 2 + gstride - 1) / gstride) * a.nch;  // group 0 has the most tiles
+  const int Jmax = ((ntiles - vb * 2 + gstride - 1) / gstride) * a.nch;  // group 0 has the most tiles
   // tile coordinates advance by a fixed (dx, dy, dn) per period: no integer division inside the loop
   const int sdx = FLAT ? gstride : gstride % a.tiles_x;
   const int sdy = FLAT ? 0 : (gstride / a.tiles_x) % a.tiles_y;
@@ -1379,10 +1384,11 @@ __global__ __launch_bounds__(512) void conv_mfma_dg2_kernel(ConvArgs a, int ntil
   };
 
   const int gstride = 2 * gridDim.x;
-  const int gt0 = blockIdx.x * 2 + g;
+  const int vb = (a.xcd_map && !(gridDim.x & 7)) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int gt0 = vb * 2 + g;
   const int ntg = gt0 < ntiles ? (ntiles - gt0 + gstride - 1) / gstride : 0;
   const int J = ntg * a.nch;
-  const int Jmax = ((ntiles - (int)blockIdx.x * 2 + gstride - 1) / gstride) * a.nch;
+  const int Jmax = ((ntiles - vb * 2 + gstride - 1) / gstride) * a.nch;
   const int sdx = gstride % a.tiles_x, sdy = (gstride / a.tiles_x) % a.tiles_y, sdn = (gstride / a.tiles_x) / a.tiles_y;
   auto tile_next = [&](TileCur& c) {
     c.bx += sdx;
@@ -1557,7 +1563,9 @@ static int pp_trows(int cc, int mt, int ks, int stride, int nch) {
 // two tiles per period; this is also the number of BN partial rows the launch writes
 static int pp_grid(int cc, int mt, int ks, int stride, int nch, int trows, int ntiles) {
   const int per_cu = 2 * pp_lds_bytes(cc, mt, ks, stride, nch, trows) <= 160 * 1024 ? 2 : 1;
-  const int want = cdiv(ntiles, 2), cap = DY_NUM_CUS * per_cu;
+  int want = cdiv(ntiles, 2);
+  const int cap = DY_NUM_CUS * per_cu;
+  if (want >= 8) want = (want + 7) & ~7;  // a multiple of the XCD count, so that the XCD-aware tile map applies
   return want < cap ? want : cap;
 }
 
@@ -1662,6 +1670,8 @@ extern "C" int dy_conv_forward(const void* x, int ldx, const void* w_packed, con
     a.Wo = out_w;
   }
   a.cout = cout; a.nch = nch; a.epi = epi; a.dil = dil;
+  static const bool xcd_map = getenv("DY_CONV_NO_XCDMAP") == nullptr;
+  a.xcd_map = xcd_map && ks == 3;  // 1x1 tiles have no halo to share
   int gx;
   if (ks == 1) {
     a.npix = n * a.Ho * a.Wo;
