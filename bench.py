@@ -188,6 +188,7 @@ def main():
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # rank 0 may still be probing / printing: leave together
         dist.destroy_process_group()
 
 

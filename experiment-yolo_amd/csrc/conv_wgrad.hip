@@ -371,6 +371,10 @@ extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks
   const int per_cu = (ks == 3 && nci * mtc >= 16) ? 1 : 2;
   int gx = (256 * per_cu) / gy;
   if (gx < 32) gx = 32;
+  // every workgroup ends by writing a full fp32 weight slab (147 KB for 64x64x3x3) that the reduce kernel reads back: on small
+  // maps a workgroup with one or two tiles moves more slab bytes than activation bytes, so keep at least TPB tiles per slab
+  static const int tpb = getenv("DY_WGRAD_TPB") ? atoi(getenv("DY_WGRAD_TPB")) : 1;
+  if (tpb > 1 && gx > ntiles / tpb) gx = ntiles / tpb > 32 ? ntiles / tpb : (ntiles < 32 ? ntiles : 32);
   if (gx > ntiles) gx = ntiles;
   if (gx < 1) gx = 1;
   *nslabs = gx;
