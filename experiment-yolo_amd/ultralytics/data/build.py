@@ -155,7 +155,11 @@ class HipDataLoader:
                     raise b
                 ev = b.pop("_ready", None)
                 if ev is not None:
-                    torch.cuda.current_stream(self.device).wait_event(ev)
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    # the device batch was allocated under the copy stream: tell the caching allocator that the consumer's
+                    # stream reads it, or the block could be handed to a later copy while queued kernels still need it
+                    b["img"].record_stream(cur)
                 yield b
         finally:
             stop.set()
