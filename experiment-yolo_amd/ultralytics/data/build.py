@@ -25,8 +25,9 @@ AUGMENT_KEYS = ("mosaic", "mixup", "copy_paste", "hsv_h", "hsv_s", "hsv_v", "deg
                 "flipud", "fliplr")
 
 
-def build_yolo_dataset(cfg, img_path, batch, data, mode="train", rect=False, stride=32, layout="nhwc"):
-    return YOLODataset(img_path=img_path, imgsz=cfg.imgsz, batch_size=batch, augment=mode == "train",
+def build_yolo_dataset(cfg, img_path, batch, data, mode="train", rect=False, stride=32, layout="nhwc", flip_on_device=False):
+    flips = dict(flipud=float(getattr(cfg, "flipud", 0.0) or 0.0), fliplr=float(getattr(cfg, "fliplr", 0.0) or 0.0)) if mode == "train" else {}
+    return YOLODataset(img_path=img_path, imgsz=cfg.imgsz, batch_size=batch, augment=mode == "train", flip_on_device=flip_on_device, **flips,
                        rect=bool(getattr(cfg, "rect", False)) or rect, stride=int(stride), pad=0.0 if mode == "train" else 0.5,
                        data=data, fraction=getattr(cfg, "fraction", 1.0) if mode == "train" else 1.0,
                        cache=bool(getattr(cfg, "cache", False)), layout=layout, prefix=f"{mode}: ")
@@ -84,7 +85,8 @@ class HipDataLoader:
         (memcpy, GIL released) -- a pinned ring slot when a device is set, fresh host memory otherwise; only the label tensors
         go through collate_fn."""
         n, W = len(idx), min(self.workers, len(idx))
-        first = self.dataset[idx[0]]
+        flips = [self.dataset.draw_augment() for _ in idx]  # RNG consumed here, in sample order, whatever the worker schedule
+        first = self.dataset.get(idx[0], flips[0])
         shape = tuple(first["img"].shape)
         if self.device is not None:
             key = (slot, n, shape)
@@ -101,7 +103,7 @@ class HipDataLoader:
 
         def work(lo, hi):
             for j in range(lo, hi):
-                s = first if j == 0 else self.dataset[idx[j]]
+                s = first if j == 0 else self.dataset.get(idx[j], flips[j])
                 if tuple(s["img"].shape) != shape:
                     raise ValueError(f"images of one batch differ in shape: {tuple(s['img'].shape)} vs {shape} ({s['im_file']})")
                 np.copyto(buf_np[j], s["img"].numpy())
@@ -115,6 +117,8 @@ class HipDataLoader:
             s["img"] = v[:0]
         batch = self.dataset.collate_fn(samples)
         batch["img"] = buf
+        if "flip" in batch and self.device is not None:
+            batch["flip"] = batch["flip"].to(self.device, non_blocking=True)
         if self.device is not None:
             with torch.cuda.stream(self._copy_stream):
                 batch["img"] = buf.to(self.device, non_blocking=True)

@@ -13,12 +13,17 @@ reference's CHW tensor.  Geometry and label arithmetic follow the reference oper
   RandomPerspective.box_candidates (:562-581) drops boxes under 2 px, with aspect ratio >= 100 or that lost 90 % of their area;
 * val mode: rectangular batches (base.py:224-246: aspect-sorted, per-batch shape ceil(shape*imgsz/stride + 0.5)*stride) and
   LetterBox(scaleup=False) to the batch shape; ``ratio_pad`` kept for the validator's box rescaling.
-Augmentations themselves (mosaic, HSV, affine, flips: cv2 + Python RNG) are not on this path."""
+Of the augmentations, the two flips are on this path (``flipud`` / ``fliplr`` probabilities): the decisions come from
+Python's ``random`` in the reference's per-sample draw order (Mosaic's probability draw, the eight RandomPerspective draws and
+MixUp's draw are consumed even at zero gain, augment.py:105, :406-425), so a run seeded like the reference flips the same
+images; labels flip on the host, pixels either on the host or -- ``flip_on_device`` -- inside the import kernel.  Mosaic, HSV
+and the affine warp (cv2 + numpy RNG) are not on this path."""
 from __future__ import annotations
 
 import glob
 import math
 import os
+import random
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
@@ -48,8 +53,9 @@ def letterbox_geometry(shape, new_shape, scaleup):
 
 class YOLODataset:
     def __init__(self, img_path, imgsz=640, batch_size=16, augment=False, rect=False, stride=32, pad=0.0, data=None, fraction=1.0,
-                 cache=False, layout="nhwc", prefix=""):
+                 cache=False, layout="nhwc", prefix="", flipud=0.0, fliplr=0.0, flip_on_device=False):
         self.img_path, self.imgsz, self.batch_size, self.augment, self.rect = img_path, int(imgsz), batch_size, augment, rect
+        self.flipud, self.fliplr, self.flip_on_device = float(flipud), float(fliplr), flip_on_device
         self.stride, self.pad, self.data, self.fraction, self.layout, self.prefix = stride, pad, data or {}, fraction, layout, prefix
         self.im_files = self.get_img_files(img_path)
         self.labels = self.get_labels()
@@ -142,7 +148,23 @@ class YOLODataset:
     def __len__(self):
         return self.ni
 
+    def draw_augment(self):
+        """The random decisions of one training sample, drawn from Python's ``random`` in the reference's order (call this in
+        sample order from ONE thread; the pixels can then be produced by any worker).  -> flip bits: 1 = left-right, 2 = up-down."""
+        if not self.augment:
+            return 0
+        random.uniform(0, 1)                                  # Mosaic.__call__ probability check   augment.py:105
+        for _ in range(8):                                    # RandomPerspective.affine_transform  :406-425
+            random.uniform(0, 0)
+        random.uniform(0, 1)                                  # MixUp.__call__ probability check    :105
+        ud = random.random() < self.flipud                    # RandomFlip(vertical)                :670
+        lr = random.random() < self.fliplr                    # RandomFlip(horizontal)              :674
+        return (1 if lr else 0) | (2 if ud else 0)
+
     def __getitem__(self, index):
+        return self.get(index, self.draw_augment())
+
+    def get(self, index, flip=0):
         lab = self.labels[index]
         im, ori_shape, resized = self.load_image(index)
         h, w = resized
@@ -178,9 +200,15 @@ class YOLODataset:
             ar = np.maximum(w2 / (h2 + eps), h2 / (w2 + eps))
             keep = (w2 > 2) & (h2 > 2) & (w2 * h2 / (w1 * h1 + eps) > np.float32(0.1)) & (ar < 100)
             xy, cls = xy[keep], cls[keep]
-        out = np.empty_like(xy)  # Format (:912-945): xyxy -> xywh, normalise by the canvas
+        out = np.empty_like(xy)  # RandomFlip / Format (:664, :918): xyxy -> xywh; flips mirror the centre; normalise by the canvas
         out[:, 0], out[:, 1] = (xy[:, 0] + xy[:, 2]) / 2, (xy[:, 1] + xy[:, 3]) / 2
         out[:, 2], out[:, 3] = xy[:, 2] - xy[:, 0], xy[:, 3] - xy[:, 1]
+        if flip & 2:
+            out[:, 1] = H - out[:, 1]
+        if flip & 1:
+            out[:, 0] = W - out[:, 0]
+        if flip and not self.flip_on_device:
+            canvas = np.ascontiguousarray(canvas[::-1 if flip & 2 else 1, ::-1 if flip & 1 else 1])
         for j, sc in enumerate((1 / W, 1 / H, 1 / W, 1 / H)):
             out[:, j] *= sc
         nl = len(out)
@@ -191,6 +219,8 @@ class YOLODataset:
         s["cls"] = torch.from_numpy(cls) if nl else torch.zeros(nl)
         s["bboxes"] = torch.from_numpy(out) if nl else torch.zeros((nl, 4))
         s["batch_idx"] = torch.zeros(nl)
+        if self.flip_on_device:
+            s["flip"] = flip  # pixels are delivered unflipped: dy_import_image_u8 mirrors them while converting
         return s
 
     @staticmethod
@@ -201,6 +231,8 @@ class YOLODataset:
             value = [b[k] for b in batch]
             if k == "img":
                 value = torch.stack(value, 0)
+            if k == "flip":
+                value = torch.tensor(value, dtype=torch.uint8)
             if k in ("bboxes", "cls"):
                 value = torch.cat([v.reshape(-1, 4 if k == "bboxes" else 1) if v.numel() == 0 else v for v in value], 0)
             new[k] = value

@@ -126,11 +126,11 @@ class DetectionTrainer:
         a = self.args
         if mode == "train":
             on = [k for k in ("mosaic", "mixup", "copy_paste", "hsv_h", "hsv_s", "hsv_v", "degrees", "translate", "scale", "shear",
-                              "perspective", "flipud", "fliplr") if getattr(a, k, 0)]
+                              "perspective") if getattr(a, k, 0)]  # flipud / fliplr ARE applied (inside the import kernel)
             if on:
                 LOGGER.warning(f"WARNING augmentations {on} are not on this path (cv2 pipeline): training without them")
         ds = build_yolo_dataset(a, dataset_path, batch_size, data, mode=mode, rect=mode == "val", stride=32,
-                                layout="nhwc" if mode == "train" else "nchw")
+                                layout="nhwc" if mode == "train" else "nchw", flip_on_device=mode == "train")
         return build_dataloader(ds, batch_size, a.workers, shuffle=mode == "train", rank=rank if self.world_size > 1 else -1,
                                 world_size=self.world_size, device=self.device if mode == "train" else None, drop_last=mode == "train")
 

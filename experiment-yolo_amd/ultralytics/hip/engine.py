@@ -303,13 +303,14 @@ class Engine:
         self.call("dy_import_image", img.data_ptr(), out.ptr, N, Cc, H, W, cp, float(mul))
         return out
 
-    def import_image_u8(self, img, cp=8):
-        """NHWC uint8 RGB image batch (the loader's format) -> NHWC fp16 Act, value/255, channels zero-padded to ``cp``."""
+    def import_image_u8(self, img, cp=8, flip=None):
+        """NHWC uint8 RGB image batch (the loader's format) -> NHWC fp16 Act, value/255, channels zero-padded to ``cp``;
+        ``flip``: (N,) uint8 device tensor of flip bits (1 = left-right, 2 = up-down) applied while converting."""
         N, H, W, Cc = img.shape
         assert img.dtype == torch.uint8 and img.is_contiguous() and Cc == 3
         out = self.new_act(N, H, W, cp)
         out.needs_grad = False
-        self.call("dy_import_image_u8", img.data_ptr(), out.ptr, N, H, W, cp)
+        self.call("dy_import_image_u8", img.data_ptr(), out.ptr, N, H, W, cp, 0 if flip is None else flip.data_ptr())
         return out
 
     def _conv_raw(self, spec, x, y_ptr, ldy, epi, partials_ptr=0, bias=None):

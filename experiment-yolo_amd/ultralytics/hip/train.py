@@ -48,6 +48,7 @@ class StepPlan:
         self.partials = torch.zeros(4096, dtype=torch.float32, device=dev)
         self.img = torch.zeros((batch_size, 3, *self.imgsz), dtype=torch.float32, device=dev)
         self.input_u8 = False  # decided by the first batch: uint8 NHWC (the loader's format) or float NCHW (the public tensor API)
+        self.flip = None       # (B,) uint8 flip bits when the first loader batch carries them (flips folded into the import kernel)
         self.rec_fb = None
         self.rec_opt, self.graph_opt = {}, {}
         self.graph_fb = None
@@ -74,7 +75,7 @@ class StepPlan:
         eng.training = True
         try:
             rt.pack_all(transposed=True)
-            x = eng.import_image_u8(self.img, 8) if self.input_u8 else eng.import_image(self.img, 8)
+            x = eng.import_image_u8(self.img, 8, self.flip) if self.input_u8 else eng.import_image(self.img, 8)
             ho = model.forward_act(x)
             crit.bind(ho, self.nmax, gscale=self.state[0:1])
             crit.sync_modes()
@@ -98,6 +99,14 @@ class StepPlan:
         if self.rec_fb is None and u8:
             self.input_u8 = True
             self.img = torch.zeros((self.B, *self.imgsz, 3), dtype=torch.uint8, device=self.img.device)
+        if self.rec_fb is None and u8 and "flip" in batch:
+            self.flip = torch.zeros(self.B, dtype=torch.uint8, device=self.img.device)
+        if self.flip is not None:
+            if "flip" not in batch:
+                raise KeyError("this plan was recorded for batches carrying 'flip' bits (loader with flip_on_device)")
+            self.flip.copy_(batch["flip"], non_blocking=True)
+        elif "flip" in batch and bool(batch["flip"].any()):
+            raise KeyError("the batch carries pending flips but this plan was recorded without them")
         if self.input_u8 and not u8:
             raise TypeError("this plan was recorded for uint8 NHWC batches (the loader's format); got "
                             f"{img.dtype} {tuple(img.shape)}")

@@ -608,6 +608,15 @@ def gen_data():
     for ep in range(2):
         for i, batch in enumerate(loader):
             put(f"train/e{ep}/b{i}", batch)
+    # the same training set with the two flips switched on: decisions come from Python's random in the pipeline's draw order
+    import random
+    cfg_f = get_cfg(DEFAULT_CFG, overrides=dict(imgsz=DATASET_IMGSZ, task="detect", **{**zero, "fliplr": 0.5, "flipud": 0.25}))
+    ds = build_yolo_dataset(cfg_f, os.path.join(root, "images", "train"), 4, data, mode="train")
+    loader = build_dataloader(ds, 4, 0, shuffle=True, rank=-1)
+    random.seed(7)
+    for ep in range(2):
+        for i, batch in enumerate(loader):
+            put(f"flip/e{ep}/b{i}", batch)
     ds = build_yolo_dataset(cfg, os.path.join(root, "images", "val"), 4, data, mode="val", rect=True, stride=32)
     loader = build_dataloader(ds, 4, 0, shuffle=False, rank=-1)
     arrs["val/nb"] = len(loader)

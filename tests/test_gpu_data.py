@@ -16,11 +16,21 @@ def test_import_u8_matches_float_division():
     for n, h, w in ((2, 5, 7), (1, 64, 64), (3, 33, 31)):
         x = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda")
         y = torch.full((n, h, w, 8), 7.0, dtype=torch.float16, device="cuda")
-        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, None), "dy_import_image_u8")
+        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, None, None), "dy_import_image_u8")
         torch.cuda.synchronize()
         ref = torch.zeros((n, h, w, 8), dtype=torch.float16, device="cuda")
         ref[..., :3] = (x.float() / 255).half()
         assert torch.equal(y, ref)
+        # flips folded into the conversion: bit 0 = left-right, bit 1 = up-down, per image
+        flip = torch.tensor([(i * 3 + 1) % 4 for i in range(n)], dtype=torch.uint8, device="cuda")
+        y.fill_(7.0)
+        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, flip.data_ptr(), None), "dy_import_image_u8")
+        torch.cuda.synchronize()
+        for i in range(n):
+            f = int(flip[i])
+            r = ref[i].flip(1) if f & 1 else ref[i]
+            r = r.flip(0) if f & 2 else r
+            assert torch.equal(y[i], r), (i, f)
 
 
 def test_plan_recorded_for_u8_batches_equals_the_float_plan():
@@ -50,6 +60,32 @@ def test_plan_recorded_for_u8_batches_equals_the_float_plan():
         plan_u8.forward_backward({**lab_d, "img": torch.rand(B, 3, S, S).cuda()})
 
 
+def test_device_flips_equal_host_flips(tmp_path):
+    """A loader that leaves the flips to the import kernel feeds the network the same pixels as one that flips on the host."""
+    import random
+    from types import SimpleNamespace
+    from ultralytics.data import build_dataloader, build_yolo_dataset, check_det_dataset
+    from ultralytics.hip.engine import Engine
+    root = str(tmp_path / "ds")
+    write_dataset(root)
+    data = check_det_dataset(os.path.join(root, "data.yaml"))
+    cfg = SimpleNamespace(imgsz=64, rect=False, cache=False, fraction=1.0, fliplr=0.5, flipud=0.5)
+    eng = Engine("cuda:0")
+    outs = []
+    for on_dev in (False, True):
+        ds = build_yolo_dataset(cfg, data["train"], 4, data, mode="train", flip_on_device=on_dev)
+        random.seed(3)
+        acts, labs = [], []
+        for b in build_dataloader(ds, 4, 2, shuffle=True, device="cuda:0", drop_last=True):
+            a = eng.import_image_u8(b["img"].contiguous(), 8, b.get("flip"))
+            acts.append(a.st.buf.clone())
+            labs.append(b["bboxes"].clone())
+        outs.append((acts, labs))
+    assert len(outs[0][0]) == 2
+    for (a0, l0), (a1, l1) in zip(zip(*outs[0]), zip(*outs[1])):
+        assert torch.equal(a0, a1) and torch.equal(l0, l1)
+
+
 def test_train_and_val_from_a_dataset_yaml(tmp_path):
     from ultralytics import YOLO
     root = str(tmp_path / "ds")
@@ -57,10 +93,12 @@ def test_train_and_val_from_a_dataset_yaml(tmp_path):
     zero = dict(mosaic=0.0, mixup=0.0, copy_paste=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, degrees=0.0, translate=0.0, scale=0.0, shear=0.0,
                 perspective=0.0, flipud=0.0, fliplr=0.0)
     y = YOLO("yolov8n-ASF-P2P2.yaml")
-    hist = y.train(data=os.path.join(root, "data.yaml"), batch=4, imgsz=64, epochs=3, optimizer="SGD", workers=2, hipgraph=True, **zero)
+    hist = y.train(data=os.path.join(root, "data.yaml"), batch=4, imgsz=64, epochs=3, optimizer="SGD", workers=2, hipgraph=True,
+                   **{**zero, "fliplr": 0.5, "flipud": 0.25})
     assert y.model.model[-1].nc == 4  # rebuilt for the dataset's class count
     assert len(hist) == 3 and all(np.isfinite(np.asarray(h, dtype=np.float64)).all() for h in hist)
     assert y.trainer.plan.input_u8  # the loader's uint8 NHWC batches went through dy_import_image_u8
+    assert y.trainer.plan.flip is not None  # ... which also applied the flips
     m = y.trainer.metrics
     assert set(m) >= {"metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)", "fitness"}
     assert y.trainer.validator.seen == 7

@@ -23,10 +23,10 @@ def root(tmp_path_factory):
     return r
 
 
-def _loader(root, mode, layout="nchw", **kw):
+def _loader(root, mode, layout="nchw", fliplr=0.0, flipud=0.0, **kw):
     from ultralytics.data import build_dataloader, build_yolo_dataset, check_det_dataset
     data = check_det_dataset(os.path.join(root, "data.yaml"))
-    cfg = SimpleNamespace(imgsz=DATASET_IMGSZ, rect=False, cache=False, fraction=1.0)
+    cfg = SimpleNamespace(imgsz=DATASET_IMGSZ, rect=False, cache=False, fraction=1.0, fliplr=fliplr, flipud=flipud)
     ds = build_yolo_dataset(cfg, data[mode], 4, data, mode=mode, rect=mode == "val", stride=32, layout=layout)
     return build_dataloader(ds, 4, 2, shuffle=mode == "train", rank=-1, **kw)
 
@@ -52,6 +52,21 @@ def test_train_batches_identical_to_reference_over_two_epochs(root):
     for ep in range(2):
         for i, batch in enumerate(loader):
             _check(G, f"train/e{ep}/b{i}", batch)
+
+
+def test_flipped_batches_identical_to_reference(root):
+    """fliplr 0.5 / flipud 0.25: same images flipped as in the reference run (Python ``random`` seeded alike and consumed in the
+    pipeline's order), pixels and labels identical."""
+    import random
+    G = np.load(GOLD)
+    loader = _loader(root, "train", fliplr=0.5, flipud=0.25)
+    random.seed(7)
+    flipped = 0
+    for ep in range(2):
+        for i, batch in enumerate(loader):
+            _check(G, f"flip/e{ep}/b{i}", batch)
+            flipped += int(not torch.equal(batch["img"], torch.from_numpy(G[f"train/e{ep}/b{i}/img"])))
+    assert flipped >= 3  # the fixture does contain flipped batches
 
 
 def test_val_rect_batches_identical_to_reference(root):
