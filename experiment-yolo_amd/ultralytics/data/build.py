@@ -6,7 +6,11 @@ buffers (78.6 MB for 64x640x640x3, a quarter of the fp32 NCHW batch the referenc
 issued on its own HIP stream one batch ahead so that it overlaps the previous step's kernels, and an event the consumer's
 stream waits on.  Epoch order reproduces the reference's: torch's RandomSampler drawing from a generator seeded
 6148914691236517205 + RANK (build.py:110-111) after the DataLoader iterator's one base-seed draw, or DistributedSampler's
-``randperm(seed = epoch)`` strided by rank when world_size > 1."""
+``randperm(seed = epoch)`` strided by rank when world_size > 1.
+
+``cache='hbm'`` (training, fixed canvas size): the decoded, letterboxed dataset is uploaded ONCE into one device tensor -- a
+100k-image 640x640 set is 123 GB of the MI355X's 288 GB -- and a batch is just (pool, int32 slot indices, flip bits): the import
+kernel gathers straight from the pool, so steady-state training moves no pixel over PCIe and the host only builds labels."""
 from __future__ import annotations
 
 import math
@@ -30,7 +34,8 @@ def build_yolo_dataset(cfg, img_path, batch, data, mode="train", rect=False, str
     return YOLODataset(img_path=img_path, imgsz=cfg.imgsz, batch_size=batch, augment=mode == "train", flip_on_device=flip_on_device, **flips,
                        rect=bool(getattr(cfg, "rect", False)) or rect, stride=int(stride), pad=0.0 if mode == "train" else 0.5,
                        data=data, fraction=getattr(cfg, "fraction", 1.0) if mode == "train" else 1.0,
-                       cache=bool(getattr(cfg, "cache", False)), layout=layout, prefix=f"{mode}: ")
+                       cache=(getattr(cfg, "cache", False) or False) if mode == "train" or getattr(cfg, "cache", False) != "hbm" else False,
+                       layout=layout, prefix=f"{mode}: ")
 
 
 def build_dataloader(dataset, batch, workers, shuffle=True, rank=-1, world_size=1, device=None, drop_last=False):
@@ -80,6 +85,35 @@ class HipDataLoader:
         return n // self.batch_size if self.drop_last else math.ceil(n / self.batch_size)
 
     # ---- batches -------------------------------------------------------------------------------------------------
+    # ---- HBM-resident dataset ------------------------------------------------------------------------------------
+    def _build_pool(self, workers):
+        ds = self.dataset
+        if not (ds.augment and ds.flip_on_device and ds.layout == "nhwc" and not ds.rect):
+            raise ValueError("cache='hbm' needs the training dataset in NHWC layout with flip_on_device=True")
+        shape = tuple(ds.get(0, 0)["img"].shape)
+        n, chunk = len(ds), 256
+        self._pool = torch.empty((n, *shape), dtype=torch.uint8, device=self.device)
+        stage = torch.empty((min(chunk, n), *shape), dtype=torch.uint8).pin_memory()
+        stage_np = stage.numpy()
+
+        def load(j, i):
+            np.copyto(stage_np[j], ds.get(i, 0)["img"].numpy())
+
+        for lo in range(0, n, chunk):
+            hi = min(lo + chunk, n)
+            list(workers.map(lambda j: load(j - lo, j), range(lo, hi)))
+            self._pool[lo:hi].copy_(stage[:hi - lo], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()  # the staging buffer is reused by the next chunk
+
+    def _assemble_pool(self, idx):
+        flips = [self.dataset.draw_augment() for _ in idx]
+        samples = [self.dataset.get(i, f, pixels=False) for i, f in zip(idx, flips)]
+        batch = self.dataset.collate_fn(samples)
+        batch["img"] = self._pool
+        batch["index"] = torch.tensor(idx, dtype=torch.int32).to(self.device, non_blocking=True)
+        batch["flip"] = batch["flip"].to(self.device, non_blocking=True)
+        return batch
+
     def _assemble(self, pool, idx, slot):
         """One batch.  Each worker decodes a contiguous chunk of samples and copies the pixels straight into the batch buffer
         (memcpy, GIL released) -- a pinned ring slot when a device is set, fresh host memory otherwise; only the label tensors
@@ -137,13 +171,18 @@ class HipDataLoader:
         q: queue.Queue = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
 
+        hbm = self.device is not None and getattr(self.dataset, "cache_mode", False) == "hbm"
+        if hbm and getattr(self, "_pool", None) is None:
+            with ThreadPoolExecutor(self.workers) as pool:
+                self._build_pool(pool)
+
         def produce():
             try:
                 with ThreadPoolExecutor(self.workers) as pool:
                     for k, c in enumerate(chunks):
                         if stop.is_set():
                             return
-                        q.put(self._assemble(pool, c, k % (self.prefetch + 2)))
+                        q.put(self._assemble_pool(c) if hbm else self._assemble(pool, c, k % (self.prefetch + 2)))
                 q.put(None)
             except BaseException as e:  # surfaced in the consumer
                 q.put(e)

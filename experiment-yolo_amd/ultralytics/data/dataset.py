@@ -64,7 +64,9 @@ class YOLODataset:
             self.set_rectangle()
         self.npy_files = [Path(f).with_suffix(".npy") for f in self.im_files]
         self.ims = [None] * self.ni
-        if cache:
+        self.im_hw0, self.im_hw = [None] * self.ni, [None] * self.ni  # shapes seen by load_image (label-only sample building)
+        self.cache_mode = cache  # False | True/'ram' (decoded images in host RAM) | 'hbm' (the loader keeps them on the device)
+        if cache and cache != "hbm":
             with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as pool:
                 self.ims = list(pool.map(self.load_image, range(self.ni)))
 
@@ -164,16 +166,23 @@ class YOLODataset:
     def __getitem__(self, index):
         return self.get(index, self.draw_augment())
 
-    def get(self, index, flip=0):
+    def get(self, index, flip=0, pixels=True):
+        """One sample; ``pixels=False`` builds the labels only (the image already sits in the loader's HBM pool)."""
         lab = self.labels[index]
-        im, ori_shape, resized = self.load_image(index)
+        if pixels or self.im_hw[index] is None:
+            im, ori_shape, resized = self.load_image(index)
+            self.im_hw0[index], self.im_hw[index] = ori_shape, resized
+        else:
+            im, ori_shape, resized = None, self.im_hw0[index], self.im_hw[index]
         h, w = resized
         new_shape = tuple(int(v) for v in self.batch_shapes[self.batch[index]]) if self.rect else (self.imgsz, self.imgsz)
         r, new_unpad, (dw, dh), (top, bottom, left, right) = letterbox_geometry((h, w), new_shape, scaleup=self.augment)
-        if (w, h) != new_unpad:
+        if im is not None and (w, h) != new_unpad:
             im = _resize_bilinear(im, *new_unpad)
-        H, W = im.shape[0] + top + bottom, im.shape[1] + left + right
-        if top or bottom or left or right:
+        H, W = new_unpad[1] + top + bottom, new_unpad[0] + left + right
+        if im is None:
+            canvas = None
+        elif top or bottom or left or right:
             canvas = np.full((H, W, 3), 114, dtype=np.uint8)
             canvas[top:top + im.shape[0], left:left + im.shape[1]] = im
         else:
@@ -207,7 +216,7 @@ class YOLODataset:
             out[:, 1] = H - out[:, 1]
         if flip & 1:
             out[:, 0] = W - out[:, 0]
-        if flip and not self.flip_on_device:
+        if flip and not self.flip_on_device and canvas is not None:
             canvas = np.ascontiguousarray(canvas[::-1 if flip & 2 else 1, ::-1 if flip & 1 else 1])
         for j, sc in enumerate((1 / W, 1 / H, 1 / W, 1 / H)):
             out[:, j] *= sc
@@ -215,7 +224,8 @@ class YOLODataset:
         s = dict(im_file=lab["im_file"], ori_shape=ori_shape, resized_shape=(H, W) if self.augment else new_shape)
         if not self.augment:
             s["ratio_pad"] = ((h / ori_shape[0], w / ori_shape[1]), (left, top))
-        s["img"] = torch.from_numpy(canvas if self.layout == "nhwc" else np.ascontiguousarray(canvas.transpose(2, 0, 1)))
+        if canvas is not None:
+            s["img"] = torch.from_numpy(canvas if self.layout == "nhwc" else np.ascontiguousarray(canvas.transpose(2, 0, 1)))
         s["cls"] = torch.from_numpy(cls) if nl else torch.zeros(nl)
         s["bboxes"] = torch.from_numpy(out) if nl else torch.zeros((nl, 4))
         s["batch_idx"] = torch.zeros(nl)

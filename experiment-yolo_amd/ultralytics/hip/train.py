@@ -49,6 +49,7 @@ class StepPlan:
         self.img = torch.zeros((batch_size, 3, *self.imgsz), dtype=torch.float32, device=dev)
         self.input_u8 = False  # decided by the first batch: uint8 NHWC (the loader's format) or float NCHW (the public tensor API)
         self.flip = None       # (B,) uint8 flip bits when the first loader batch carries them (flips folded into the import kernel)
+        self.pool = self.index = None  # HBM-resident image pool + (B,) int32 slots when the loader keeps the dataset on the device
         self.rec_fb = None
         self.rec_opt, self.graph_opt = {}, {}
         self.graph_fb = None
@@ -75,7 +76,10 @@ class StepPlan:
         eng.training = True
         try:
             rt.pack_all(transposed=True)
-            x = eng.import_image_u8(self.img, 8, self.flip) if self.input_u8 else eng.import_image(self.img, 8)
+            if self.pool is not None:
+                x = eng.import_image_u8(self.pool, 8, self.flip, self.index)
+            else:
+                x = eng.import_image_u8(self.img, 8, self.flip) if self.input_u8 else eng.import_image(self.img, 8)
             ho = model.forward_act(x)
             crit.bind(ho, self.nmax, gscale=self.state[0:1])
             crit.sync_modes()
@@ -96,7 +100,15 @@ class StepPlan:
         """Stage the batch, run fwd+loss+bwd; gradients (scaled by the loss scale) land in rt.flat_g."""
         img = batch["img"]
         u8 = img.dtype == torch.uint8 and img.dim() == 4 and img.shape[-1] == 3 and img.shape[1] != 3  # (B,H,W,3)
-        if self.rec_fb is None and u8:
+        if self.rec_fb is None and u8 and "index" in batch:  # img is the loader's HBM-resident pool: recorded by pointer
+            self.pool, self.input_u8 = img, True
+            self.index = torch.zeros(self.B, dtype=torch.int32, device=img.device)
+        if self.pool is not None:
+            if "index" not in batch or img.data_ptr() != self.pool.data_ptr():
+                raise KeyError("this plan was recorded for batches indexing one HBM-resident image pool")
+            self.index.copy_(batch["index"], non_blocking=True)
+            img = self.img  # nothing to stage
+        if self.rec_fb is None and u8 and self.pool is None:
             self.input_u8 = True
             self.img = torch.zeros((self.B, *self.imgsz, 3), dtype=torch.uint8, device=self.img.device)
         if self.rec_fb is None and u8 and "flip" in batch:
@@ -107,7 +119,7 @@ class StepPlan:
             self.flip.copy_(batch["flip"], non_blocking=True)
         elif "flip" in batch and bool(batch["flip"].any()):
             raise KeyError("the batch carries pending flips but this plan was recorded without them")
-        if self.input_u8 and not u8:
+        if self.input_u8 and not u8 and self.pool is None:
             raise TypeError("this plan was recorded for uint8 NHWC batches (the loader's format); got "
                             f"{img.dtype} {tuple(img.shape)}")
         if img.data_ptr() != self.img.data_ptr():  # a producer that writes straight into ``plan.img`` (the static input of the

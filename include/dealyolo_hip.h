@@ -132,8 +132,10 @@ int dy_bn_act_bwd_apply(const void* dy, int lddy, const void* x, int ldx, void* 
 int dy_import_image(const float* x_nchw, void* y, int n, int c, int h, int w, int cp, float mul, hipStream_t stream);
 /* The loader's batch: uint8 NHWC RGB (n,h,w,3), 4-byte aligned -> fp16 NHWC with channels zero-padded to cp, value u8/255
  * (models/yolo/detect/train.py:59 `batch["img"].float() / 255`).  flip: NULL, or n bytes -- bit 0 mirrors image i left-right,
- * bit 1 up-down while converting (RandomFlip, data/augment.py:651-683; the loader then ships unflipped pixels). */
-int dy_import_image_u8(const void* x, void* y, int n, int h, int w, int cp, const void* flip, hipStream_t stream);
+ * bit 1 up-down while converting (RandomFlip, data/augment.py:651-683; the loader then ships unflipped pixels).  index: NULL,
+ * or n ints -- batch slot i reads image index[i] of x, a pool of decoded images resident in HBM (no per-step host copy). */
+int dy_import_image_u8(const void* x, void* y, int n, int h, int w, int cp, const void* flip, const int* index,
+                       hipStream_t stream);
 int dy_add(const void* a, int lda, const void* b, int ldb, const void* c, int ldc, void* y, int ldy, long npix, int C,
            hipStream_t stream);
 int dy_upsample2x(const void* x, int ldx, void* y, int ldy, int n, int h, int w, int C, int backward, int accumulate,

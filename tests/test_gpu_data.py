@@ -16,7 +16,7 @@ def test_import_u8_matches_float_division():
     for n, h, w in ((2, 5, 7), (1, 64, 64), (3, 33, 31)):
         x = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda")
         y = torch.full((n, h, w, 8), 7.0, dtype=torch.float16, device="cuda")
-        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, None, None), "dy_import_image_u8")
+        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, None, None, None), "dy_import_image_u8")
         torch.cuda.synchronize()
         ref = torch.zeros((n, h, w, 8), dtype=torch.float16, device="cuda")
         ref[..., :3] = (x.float() / 255).half()
@@ -24,7 +24,7 @@ def test_import_u8_matches_float_division():
         # flips folded into the conversion: bit 0 = left-right, bit 1 = up-down, per image
         flip = torch.tensor([(i * 3 + 1) % 4 for i in range(n)], dtype=torch.uint8, device="cuda")
         y.fill_(7.0)
-        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, flip.data_ptr(), None), "dy_import_image_u8")
+        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, flip.data_ptr(), None, None), "dy_import_image_u8")
         torch.cuda.synchronize()
         for i in range(n):
             f = int(flip[i])
@@ -72,18 +72,21 @@ def test_device_flips_equal_host_flips(tmp_path):
     cfg = SimpleNamespace(imgsz=64, rect=False, cache=False, fraction=1.0, fliplr=0.5, flipud=0.5)
     eng = Engine("cuda:0")
     outs = []
-    for on_dev in (False, True):
+    for on_dev, cache in ((False, False), (True, False), (True, "hbm")):  # host flips | kernel flips | kernel flips + HBM pool
+        cfg.cache = cache
         ds = build_yolo_dataset(cfg, data["train"], 4, data, mode="train", flip_on_device=on_dev)
         random.seed(3)
         acts, labs = [], []
         for b in build_dataloader(ds, 4, 2, shuffle=True, device="cuda:0", drop_last=True):
-            a = eng.import_image_u8(b["img"].contiguous(), 8, b.get("flip"))
+            assert ("index" in b) == (cache == "hbm")
+            a = eng.import_image_u8(b["img"].contiguous(), 8, b.get("flip"), b.get("index"))
             acts.append(a.st.buf.clone())
             labs.append(b["bboxes"].clone())
         outs.append((acts, labs))
     assert len(outs[0][0]) == 2
-    for (a0, l0), (a1, l1) in zip(zip(*outs[0]), zip(*outs[1])):
-        assert torch.equal(a0, a1) and torch.equal(l0, l1)
+    for other in outs[1:]:
+        for (a0, l0), (a1, l1) in zip(zip(*outs[0]), zip(*other)):
+            assert torch.equal(a0, a1) and torch.equal(l0, l1)
 
 
 def test_train_and_val_from_a_dataset_yaml(tmp_path):
@@ -104,3 +107,12 @@ def test_train_and_val_from_a_dataset_yaml(tmp_path):
     assert y.trainer.validator.seen == 7
     m2 = y.val(data=os.path.join(root, "data.yaml"), batch=4)
     assert set(m2) == set(m)
+    # the same run with the dataset resident in HBM: identical batches (same seeds) -> identical loss history
+    hists = []
+    for cache in (False, "hbm"):
+        y2 = YOLO("yolov8n-ASF-P2P2.yaml")
+        torch.manual_seed(0)  # the model is rebuilt for the dataset's 4 classes inside train(): same initial weights both times
+        hists.append(y2.train(data=os.path.join(root, "data.yaml"), batch=4, imgsz=64, epochs=2, optimizer="SGD", workers=2, hipgraph=False,
+                              val=False, cache=cache, **{**zero, "fliplr": 0.5}))
+        assert (y2.trainer.plan.pool is not None) == (cache == "hbm")
+    np.testing.assert_array_equal(np.asarray(hists[0], dtype=np.float64), np.asarray(hists[1], dtype=np.float64))

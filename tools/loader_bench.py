@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive training rate: DEAL-YOLO-N 640x640 bs=64 fed by ultralytics.data.HipDataLoader from a YOLO-format dataset
 on local disk (uint8 NHWC pinned batches, H2D on a copy stream one batch ahead) next to the same step with the batch
-resident in HBM.  Usage: loader_bench.py [n_images=512] [steps=60] [cache=ram|disk]"""
+resident in HBM.  Usage: loader_bench.py [n_images=512] [steps=60] [cache=ram|disk|hbm]"""
 import os
 import sys
 import tempfile
@@ -19,7 +19,8 @@ from ultralytics.nn.tasks import DetectionModel  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-CACHE = (sys.argv[3] if len(sys.argv) > 3 else "ram") == "ram"
+MODE = sys.argv[3] if len(sys.argv) > 3 else "ram"
+CACHE = {"ram": True, "disk": False, "hbm": "hbm"}[MODE]
 B, S = 64, 640
 root = tempfile.mkdtemp(prefix="dy_loader_bench_")
 os.makedirs(os.path.join(root, "images", "train"))
@@ -43,7 +44,7 @@ print(f"dataset: {N} images written in {time.time() - t0:.1f} s", flush=True)
 data = check_det_dataset(os.path.join(root, "data.yaml"))
 dev = torch.device("cuda", 0)
 cfg = SimpleNamespace(imgsz=S, cache=CACHE, fraction=1.0, rect=False)
-ds = build_yolo_dataset(cfg, data["train"], B, data, mode="train")
+ds = build_yolo_dataset(cfg, data["train"], B, data, mode="train", flip_on_device=True)
 loader = build_dataloader(ds, B, 14, shuffle=True, device=dev, drop_last=True)
 
 t0 = time.time()
@@ -53,7 +54,7 @@ for ep in range(max(1, STEPS // len(loader))):
         nb += 1
 torch.cuda.synchronize()
 dt = time.time() - t0
-print(f"loader alone ({'RAM-cached' if CACHE else 'from *.npy files'}): {nb * B / dt:.0f} images/s ({dt / nb * 1e3:.2f} ms/batch, 14 threads)", flush=True)
+print(f"loader alone ({MODE}): {nb * B / dt:.0f} images/s ({dt / nb * 1e3:.2f} ms/batch, 14 threads)", flush=True)
 
 torch.manual_seed(0)
 model = DetectionModel("yolov8n-ASF-P2P2.yaml", verbose=False).to(dev).train()
@@ -68,6 +69,10 @@ def step(batch):
 
 first = next(iter(loader))
 first = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in first.items()}
+if MODE != "hbm":
+    first.pop("flip", None)  # resident reference: the plain uint8 import
+if MODE == "hbm":
+    plan.forward_backward(first)  # record for the pool
 for _ in range(5):
     step(first)
 torch.cuda.synchronize()
