@@ -210,16 +210,84 @@ __global__ __launch_bounds__(256) void ldconv_doff_kernel(LdArgs a, int LG, unsi
 // one row), the same for columns, and the sum of the scatter's four corner products factorises into row*col.  Over-wide
 // candidate ranges only cost time.  fp32 accumulation in a fixed order: run-to-run deterministic (the far side pass, when a
 // layer has far samples at all, is not).
+// accumulate, for input pixel (img, r, c) and channel granules [part*GP, part*GP+GP), every near sample that touches it --
+// candidates re-derived from the offsets in global memory (the path for geometries whose candidate table does not fit in LDS)
+template <int GP>
+static __device__ __forceinline__ void ld_gather_direct(const LdArgs& a, int R, bool has_far, float thr, long img, int r, int c, int part,
+                                                        float (&acc)[GP][8]) {
+  const int Np = a.Np, s = a.stride, C = a.C;
+  const float Hm = (float)(a.H - 1), Wm = (float)(a.W - 1);
+  for (int n = 0; n < Np; ++n) {
+    const int pnr = a.pn[n], pnc = a.pn[Np + n];
+    const int nr = r - 1 - R - pnr, nc_ = c - 1 - R - pnc;
+    const int oy_lo = nr > 0 ? (nr + s - 1) / s : 0;
+    const int ox_lo = nc_ > 0 ? (nc_ + s - 1) / s : 0;
+    int oy_hi = (r + R - pnr) / s, ox_hi = (c + R - pnc) / s;
+    if (r == a.H - 1 || oy_hi > a.h - 1) oy_hi = a.h - 1;
+    if (c == a.W - 1 || ox_hi > a.w - 1) ox_hi = a.w - 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const long prow = (img * a.h + oy) * a.w;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const long pix = prow + ox;
+        const float* o = a.off + pix * a.ldoff_in;
+        if (has_far && ld_is_far(o[n], o[Np + n], thr)) continue;  // the side pass owns it
+        const float ur = (float)(oy * s) + (float)pnr + o[n];  // identical to ld_coords
+        const float fr = floorf(ur);
+        const int r0 = (int)fminf(fmaxf(fr, 0.f), Hm), r1 = (int)fminf(fmaxf(fr + 1.f, 0.f), Hm);
+        if (r0 != r && r1 != r) continue;
+        const float uc = (float)(ox * s) + (float)pnc + o[Np + n];
+        const float fc = floorf(uc);
+        const int c0 = (int)fminf(fmaxf(fc, 0.f), Wm), c1 = (int)fminf(fmaxf(fc + 1.f, 0.f), Wm);
+        if (c0 != c && c1 != c) continue;
+        const float pr = fminf(fmaxf(ur, 0.f), Hm), pc = fminf(fmaxf(uc, 0.f), Wm);
+        const float wr = (r0 == r ? 1.f + ((float)r0 - pr) : 0.f) + (r1 == r ? 1.f - ((float)r1 - pr) : 0.f);
+        const float wc = (c0 == c ? 1.f + ((float)c0 - pc) : 0.f) + (c1 == c ? 1.f - ((float)c1 - pc) : 0.f);
+        const float wgt = wr * wc;
+        const f16* gp = a.dxo + pix * a.lddxo + n * C + part * (GP * 8);
+#pragma unroll
+        for (int g = 0; g < GP; ++g) {
+          const half8 g8 = *reinterpret_cast<const half8*>(gp + g * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[g][j] += wgt * (float)g8[j];
+        }
+      }
+    }
+  }
+}
+
+template <int GP>
+static __device__ __forceinline__ void ld_gather_store(const LdArgs& a, f16* dx, int lddx, int accumulate, bool has_far, long img, int r, int c,
+                                                       int part, float (&acc)[GP][8]) {
+  const int C = a.C;
+  const long ipix = (img * a.H + r) * a.W + c;
+  if (has_far) {
+    const float4* f = reinterpret_cast<const float4*>(a.dx32 + ipix * C + part * (GP * 8));
+#pragma unroll
+    for (int g = 0; g < GP; ++g) {
+      const float4 f0 = f[2 * g], f1 = f[2 * g + 1];
+      acc[g][0] += f0.x; acc[g][1] += f0.y; acc[g][2] += f0.z; acc[g][3] += f0.w;
+      acc[g][4] += f1.x; acc[g][5] += f1.y; acc[g][6] += f1.z; acc[g][7] += f1.w;
+    }
+  }
+  f16* d = dx + ipix * lddx + part * (GP * 8);
+#pragma unroll
+  for (int g = 0; g < GP; ++g) {
+    half8 o8;
+    if (accumulate) o8 = *reinterpret_cast<const half8*>(d + g * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o8[j] = (f16)(acc[g][j] + (accumulate ? (float)o8[j] : 0.f));
+    *reinterpret_cast<half8*>(d + g * 8) = o8;
+  }
+}
+
 template <int GP>
 __global__ __launch_bounds__(256) void ldconv_gather_bwd_kernel(LdArgs a, f16* dx, int lddx, int accumulate, const unsigned* maxabs, int rmax) {
   const unsigned mb = *maxabs;
   const bool has_far = ld_has_far(mb, rmax);
   const int R = has_far ? rmax : (int)ceilf(__uint_as_float(mb) + 0.01f);  // >= 1
   const float thr = (float)rmax - 0.01f;
-  const int Np = a.Np, s = a.stride, C = a.C;
-  const int tpp = (C >> 3) / GP;
+  const int tpp = (a.C >> 3) / GP;
   const long total = (long)a.N * a.H * a.W * tpp;
-  const float Hm = (float)(a.H - 1), Wm = (float)(a.W - 1);
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int part = (int)(idx % tpp);
     long t = idx / tpp;
@@ -232,6 +300,85 @@ __global__ __launch_bounds__(256) void ldconv_gather_bwd_kernel(LdArgs a, f16* d
     for (int g = 0; g < GP; ++g)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+    ld_gather_direct<GP>(a, R, has_far, thr, img, r, c, part, acc);
+    ld_gather_store<GP>(a, dx, lddx, accumulate, has_far, img, r, c, part, acc);
+  }
+}
+
+// Tiled form of the gather: a workgroup owns a (TH x 32)-pixel tile of one image.  The samples that can reach the tile form a
+// compact block of output pixels; their landing geometry (two clamped rows, two clamped columns, the clamped coordinates) is
+// derived ONCE, by the whole workgroup, into an LDS table, and every (pixel, candidate) test then is one 16-byte LDS read and a
+// dozen VALU ops instead of two strided global loads and the full floor/clamp arithmetic.  Far samples are marked in the table.
+// A tile whose candidate block exceeds the table (very wide sample patterns) takes the direct path above.
+#define LD_TAB_CAP 1536
+struct __attribute__((aligned(16))) LdTab { short r0, r1, c0, c1; float pr, pc; };
+
+template <int GP>
+__global__ __launch_bounds__(256) void ldconv_gather_tile_kernel(LdArgs a, f16* dx, int lddx, int accumulate, const unsigned* maxabs, int rmax,
+                                                                 int TH, int tiles_x, int tiles_y) {
+  __shared__ LdTab tab[LD_TAB_CAP];
+  const unsigned mb = *maxabs;
+  const bool has_far = ld_has_far(mb, rmax);
+  const int R = has_far ? rmax : (int)ceilf(__uint_as_float(mb) + 0.01f);
+  const float thr = (float)rmax - 0.01f;
+  const int Np = a.Np, s = a.stride, C = a.C;
+  const int tpp = (C >> 3) / GP;
+  const float Hm = (float)(a.H - 1), Wm = (float)(a.W - 1);
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % tiles_x;
+  const int t2 = blockIdx.x / tiles_x;
+  const int ty = t2 % tiles_y;
+  const long img = t2 / tiles_y;
+  int pr_min = 1 << 20, pr_max = -(1 << 20), pc_min = 1 << 20, pc_max = -(1 << 20);
+  for (int n = 0; n < Np; ++n) {
+    pr_min = min(pr_min, a.pn[n]); pr_max = max(pr_max, a.pn[n]);
+    pc_min = min(pc_min, a.pn[Np + n]); pc_max = max(pc_max, a.pn[Np + n]);
+  }
+  const int r_first = ty * TH, r_last = min(r_first + TH - 1, a.H - 1);
+  const int c_first = tx * 32, c_last = min(c_first + 31, a.W - 1);
+  int v = r_first - 1 - R - pr_max;
+  const int oy_base = v > 0 ? (v + s - 1) / s : 0;
+  v = c_first - 1 - R - pc_max;
+  const int ox_base = v > 0 ? (v + s - 1) / s : 0;
+  int oy_top = (r_last + R - pr_min) / s, ox_top = (c_last + R - pc_min) / s;
+  if (r_last == a.H - 1 || oy_top > a.h - 1) oy_top = a.h - 1;
+  if (c_last == a.W - 1 || ox_top > a.w - 1) ox_top = a.w - 1;
+  const int noy = oy_top - oy_base + 1, nox = ox_top - ox_base + 1;
+  const int per_n = noy > 0 && nox > 0 ? noy * nox : 0;
+  const bool use_tab = per_n * Np <= LD_TAB_CAP;
+  if (use_tab) {
+    for (int k = tid; k < per_n * Np; k += 256) {
+      const int n = k / per_n, rem = k - n * per_n;
+      const int oy = oy_base + rem / nox, ox = ox_base + rem % nox;
+      const float* o = a.off + ((img * a.h + oy) * a.w + ox) * a.ldoff_in;
+      const float o_r = o[n], o_c = o[Np + n];
+      LdTab e;
+      if (has_far && ld_is_far(o_r, o_c, thr)) {
+        e.r0 = e.r1 = e.c0 = e.c1 = -1;  // never equals a pixel coordinate
+        e.pr = e.pc = 0.f;
+      } else {
+        const float ur = (float)(oy * s) + (float)a.pn[n] + o_r;  // identical to ld_coords
+        const float uc = (float)(ox * s) + (float)a.pn[Np + n] + o_c;
+        const float fr = floorf(ur), fc = floorf(uc);
+        e.r0 = (short)fminf(fmaxf(fr, 0.f), Hm); e.r1 = (short)fminf(fmaxf(fr + 1.f, 0.f), Hm);
+        e.c0 = (short)fminf(fmaxf(fc, 0.f), Wm); e.c1 = (short)fminf(fmaxf(fc + 1.f, 0.f), Wm);
+        e.pr = fminf(fmaxf(ur, 0.f), Hm); e.pc = fminf(fmaxf(uc, 0.f), Wm);
+      }
+      tab[k] = e;
+    }
+    __syncthreads();
+  }
+  const int ps = tid / tpp, part = tid - ps * tpp;
+  const int r = r_first + (ps >> 5), c = c_first + (ps & 31);
+  if (ps >= TH * 32 || r > r_last || c > c_last) return;
+  float acc[GP][8];
+#pragma unroll
+  for (int g = 0; g < GP; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+  if (!use_tab) {
+    ld_gather_direct<GP>(a, R, has_far, thr, img, r, c, part, acc);
+  } else {
     for (int n = 0; n < Np; ++n) {
       const int pnr = a.pn[n], pnc = a.pn[Np + n];
       const int nr = r - 1 - R - pnr, nc_ = c - 1 - R - pnc;
@@ -241,24 +388,15 @@ __global__ __launch_bounds__(256) void ldconv_gather_bwd_kernel(LdArgs a, f16* d
       if (r == a.H - 1 || oy_hi > a.h - 1) oy_hi = a.h - 1;
       if (c == a.W - 1 || ox_hi > a.w - 1) ox_hi = a.w - 1;
       for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const LdTab* row = tab + n * per_n + (oy - oy_base) * nox - ox_base;
         const long prow = (img * a.h + oy) * a.w;
         for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-          const long pix = prow + ox;
-          const float* o = a.off + pix * a.ldoff_in;
-          if (has_far && ld_is_far(o[n], o[Np + n], thr)) continue;  // the side pass owns it
-          const float ur = (float)(oy * s) + (float)pnr + o[n];  // identical to ld_coords
-          const float fr = floorf(ur);
-          const int r0 = (int)fminf(fmaxf(fr, 0.f), Hm), r1 = (int)fminf(fmaxf(fr + 1.f, 0.f), Hm);
-          if (r0 != r && r1 != r) continue;
-          const float uc = (float)(ox * s) + (float)pnc + o[Np + n];
-          const float fc = floorf(uc);
-          const int c0 = (int)fminf(fmaxf(fc, 0.f), Wm), c1 = (int)fminf(fmaxf(fc + 1.f, 0.f), Wm);
-          if (c0 != c && c1 != c) continue;
-          const float pr = fminf(fmaxf(ur, 0.f), Hm), pc = fminf(fmaxf(uc, 0.f), Wm);
-          const float wr = (r0 == r ? 1.f + ((float)r0 - pr) : 0.f) + (r1 == r ? 1.f - ((float)r1 - pr) : 0.f);
-          const float wc = (c0 == c ? 1.f + ((float)c0 - pc) : 0.f) + (c1 == c ? 1.f - ((float)c1 - pc) : 0.f);
+          const LdTab e = row[ox];
+          if ((e.r0 != r && e.r1 != r) || (e.c0 != c && e.c1 != c)) continue;
+          const float wr = (e.r0 == r ? 1.f + ((float)e.r0 - e.pr) : 0.f) + (e.r1 == r ? 1.f - ((float)e.r1 - e.pr) : 0.f);
+          const float wc = (e.c0 == c ? 1.f + ((float)e.c0 - e.pc) : 0.f) + (e.c1 == c ? 1.f - ((float)e.c1 - e.pc) : 0.f);
           const float wgt = wr * wc;
-          const f16* gp = a.dxo + pix * a.lddxo + n * C + part * (GP * 8);
+          const f16* gp = a.dxo + (prow + ox) * a.lddxo + n * C + part * (GP * 8);
 #pragma unroll
           for (int g = 0; g < GP; ++g) {
             const half8 g8 = *reinterpret_cast<const half8*>(gp + g * 8);
@@ -268,26 +406,8 @@ __global__ __launch_bounds__(256) void ldconv_gather_bwd_kernel(LdArgs a, f16* d
         }
       }
     }
-    const long ipix = (img * a.H + r) * a.W + c;
-    if (has_far) {
-      const float4* f = reinterpret_cast<const float4*>(a.dx32 + ipix * C + part * (GP * 8));
-#pragma unroll
-      for (int g = 0; g < GP; ++g) {
-        const float4 f0 = f[2 * g], f1 = f[2 * g + 1];
-        acc[g][0] += f0.x; acc[g][1] += f0.y; acc[g][2] += f0.z; acc[g][3] += f0.w;
-        acc[g][4] += f1.x; acc[g][5] += f1.y; acc[g][6] += f1.z; acc[g][7] += f1.w;
-      }
-    }
-    f16* d = dx + ipix * lddx + part * (GP * 8);
-#pragma unroll
-    for (int g = 0; g < GP; ++g) {
-      half8 o8;
-      if (accumulate) o8 = *reinterpret_cast<const half8*>(d + g * 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o8[j] = (f16)(acc[g][j] + (accumulate ? (float)o8[j] : 0.f));
-      *reinterpret_cast<half8*>(d + g * 8) = o8;
-    }
   }
+  ld_gather_store<GP>(a, dx, lddx, accumulate, has_far, img, r, c, part, acc);
 }
 
 extern "C" int dy_ldconv_sample(const void* x, int ldx, const float* off, int ldoff, const int* pn, void* xo, int ldxo,
@@ -423,7 +543,16 @@ extern "C" int dy_ldconv_sample_backward_gather(const void* x, int ldx, const fl
   const int GP = (cpp % 4 == 0 && cpp >= 8) ? 4 : (cpp % 2 == 0 ? 2 : 1);
   long gb = ((long)n * H * W * (cpp / GP) + 255) / 256;
   if (gb > 65536) gb = 65536;
-  if (GP == 4) hipLaunchKernelGGL(ldconv_gather_bwd_kernel<4>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, rmax);
+  const int tpp = cpp / GP;
+  static const bool no_tile = getenv("DY_LD_NO_TILE") != nullptr;  // measurement switch: the untiled gather
+  const int TH = tpp <= 8 ? (256 / tpp) / 32 : 0;
+  const long ntile = TH ? (long)n * ((H + TH - 1) / TH) * ((W + 31) / 32) : 0;
+  if (TH && !no_tile && H < 32768 && W < 32768 && ntile < 2147483647L) {
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH;
+    if (GP == 4) hipLaunchKernelGGL(ldconv_gather_tile_kernel<4>, dim3((int)ntile), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, rmax, TH, tiles_x, tiles_y);
+    else if (GP == 2) hipLaunchKernelGGL(ldconv_gather_tile_kernel<2>, dim3((int)ntile), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, rmax, TH, tiles_x, tiles_y);
+    else hipLaunchKernelGGL(ldconv_gather_tile_kernel<1>, dim3((int)ntile), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, rmax, TH, tiles_x, tiles_y);
+  } else if (GP == 4) hipLaunchKernelGGL(ldconv_gather_bwd_kernel<4>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, rmax);
   else if (GP == 2) hipLaunchKernelGGL(ldconv_gather_bwd_kernel<2>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, rmax);
   else hipLaunchKernelGGL(ldconv_gather_bwd_kernel<1>, dim3((int)gb), dim3(256), 0, stream, a, (f16*)dx, lddx, accumulate, maxabs, rmax);
   DY_CHECK_LAUNCH();
