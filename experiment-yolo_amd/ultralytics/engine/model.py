@@ -46,8 +46,9 @@ class YOLO:
                 if self.ckpt_path is not None:
                     raise ValueError(f"checkpoint has {self.model.model[-1].nc} classes, dataset has {nc}")
                 self.model = DetectionModel(self.model.yaml, nc=nc, verbose=False)
+            log_every = kw.pop("log_every", 0)
             self.trainer = DetectionTrainer(self.model, overrides=dict(batch=batch, imgsz=imgsz, data=str(data), **kw))
-            return self.trainer.train_on_dataset(data, batch, imgsz)
+            return self.trainer.train_on_dataset(data, batch, imgsz, log_every=log_every)
         self.trainer = DetectionTrainer(self.model, overrides=dict(batch=batch, imgsz=imgsz, **kw))
         return self.trainer.train(data, batch, imgsz)
 

@@ -134,7 +134,7 @@ class DetectionTrainer:
         return build_dataloader(ds, batch_size, a.workers, shuffle=mode == "train", rank=rank if self.world_size > 1 else -1,
                                 world_size=self.world_size, device=self.device if mode == "train" else None, drop_last=mode == "train")
 
-    def train_on_dataset(self, data_yaml, batch_size, imgsz):
+    def train_on_dataset(self, data_yaml, batch_size, imgsz, log_every=0):
         """``YOLO.train(data=<yaml>)``: check the dataset YAML, build the loaders, train, validate the EMA model on 'val'."""
         from ..data import check_det_dataset
         from ..models.yolo.detect import DetectionValidator
@@ -146,7 +146,7 @@ class DetectionTrainer:
         self._epoch_hook = loader.set_epoch
         most = max((len(lb["cls"]) for lb in loader.dataset.labels), default=1)
         self.args.nmax = max(8, (most + 7) // 8 * 8)  # per-image label capacity of the recorded loss kernels
-        hist = self.train(loader, batch_size, imgsz)
+        hist = self.train(loader, batch_size, imgsz, log_every=log_every)  # log_every=1: per-epoch MEAN loss items, as results.csv
         self.metrics = None
         if self.args.val and self.rank == 0:
             vloader = self.get_dataloader(self.data["val"], batch_size * 2, 0, "val", self.data)

@@ -200,3 +200,36 @@ def write_dataset(root):
                     f.write(txt)
     with open(os.path.join(root, "data.yaml"), "w") as f:
         f.write("path: .\ntrain: images/train\nval: images/val\nnc: 4\nnames: [a, b, c, d]\n")
+
+
+# ----------------------------------------------------------------------------- end-to-end trainer protocol
+E2E = dict(imgsz=640, nc=6, n_train=16, n_val=16, boxes=8, epochs=40, batch=2)
+E2E_COLOURS = [(220, 40, 40), (40, 200, 60), (50, 80, 230), (230, 210, 40), (200, 60, 210), (40, 210, 220)]
+
+
+def write_e2e_dataset(root):
+    """The synthetic set of SURVEY.md section 8(c): 640x640 images, grey 114 + U{0..19} noise, eight solid class-coloured
+    rectangles per image with w, h in [0.03, 0.09]; PNG + BGR *.npy siblings + YOLO labels + data.yaml."""
+    from PIL import Image
+    s = E2E["imgsz"]
+    for split, n, seed in (("train", E2E["n_train"], 100), ("val", E2E["n_val"], 200)):
+        os.makedirs(os.path.join(root, "images", split), exist_ok=True)
+        os.makedirs(os.path.join(root, "labels", split), exist_ok=True)
+        for i in range(n):
+            rng = np.random.default_rng(seed + i)
+            img = (114 + rng.integers(0, 20, (s, s, 3))).astype(np.uint8)
+            rows = []
+            for _ in range(E2E["boxes"]):
+                c = int(rng.integers(0, E2E["nc"]))
+                w, h = rng.uniform(0.03, 0.09, 2)
+                cx, cy = rng.uniform(0.06, 0.94, 2)
+                x1, y1, x2, y2 = [int(round(v * s)) for v in (cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2)]
+                img[y1:y2, x1:x2] = E2E_COLOURS[c]
+                rows.append(f"{c} {cx:.6f} {cy:.6f} {w:.6f} {h:.6f}")
+            name = f"{split}_{i:03d}"
+            Image.fromarray(img).save(os.path.join(root, "images", split, name + ".png"))
+            np.save(os.path.join(root, "images", split, name + ".npy"), img[..., ::-1].copy())
+            with open(os.path.join(root, "labels", split, name + ".txt"), "w") as f:
+                f.write("\n".join(rows) + "\n")
+    with open(os.path.join(root, "data.yaml"), "w") as f:
+        f.write(f"path: {os.path.abspath(root)}\ntrain: images/train\nval: images/val\nnc: 6\nnames: [c0, c1, c2, c3, c4, c5]\n")

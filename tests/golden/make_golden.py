@@ -39,7 +39,7 @@ from ultralytics.utils.metrics import WiseIouLoss  # noqa: E402
 from ultralytics.utils.torch_utils import ModelEMA, initialize_weights  # noqa: E402
 
 from oracle import graph as og  # noqa: E402
-from cases import DATASET_IMGSZ, write_dataset, MODES, loss_cases, metric_cases, metric_geometry, module_cases, planted_batches, module_shapes, rnd, synth_batch, synth_detections  # noqa: E402
+from cases import DATASET_IMGSZ, E2E, write_dataset, write_e2e_dataset, MODES, loss_cases, metric_cases, metric_geometry, module_cases, planted_batches, module_shapes, rnd, synth_batch, synth_detections  # noqa: E402
 
 CFG_DIR = os.path.join(_refimport.REF, "ultralytics/cfg/models")
 torch.set_num_threads(8)
@@ -703,6 +703,69 @@ def gen_two_stage():
         arrs[f"nms/{k}/kept_labels"] = np.array(kl, np.int64)
     arrs["nms/n"] = 5
     npz("two_stage", **arrs)
+
+
+def gen_e2e():
+    """End-to-end protocol of SURVEY section 8(c): the reference's UNMODIFIED trainer (DetectionTrainer(overrides).train():
+    its dataset reader, loader, loss, optimizer, warm-up, EMA, validator, soft-NMS) on the synthetic set of
+    cases.write_e2e_dataset, CPU, fp32, batch 2, all augmentation gains zero.  The fixture keeps its results.csv (per-epoch
+    train losses, val metrics) -- the mAP-parity target for `YOLO.train(data=...)` of this package on the GPU."""
+    import csv
+    import glob
+    import math
+    import shutil
+    import tempfile
+    import cv2
+    import cpuinfo
+
+    def copy_make_border(img, top, bottom, left, right, border_type, value=(0, 0, 0)):
+        out = np.empty((img.shape[0] + top + bottom, img.shape[1] + left + right, img.shape[2]), img.dtype)
+        out[...] = np.asarray(value, img.dtype)
+        out[top:top + img.shape[0], left:left + img.shape[1]] = img
+        return out
+
+    def rotation_matrix(angle, center, scale):
+        a, b = scale * math.cos(math.radians(angle)), scale * math.sin(math.radians(angle))
+        return np.array([[a, b, (1 - a) * center[0] - b * center[1]], [-b, a, b * center[0] + (1 - a) * center[1]]])
+
+    def no_interp(*a, **k):
+        raise RuntimeError("interpolation is outside the pinned subset")
+
+    cv2.copyMakeBorder, cv2.getRotationMatrix2D, cv2.resize, cv2.warpAffine = copy_make_border, rotation_matrix, no_interp, no_interp
+    cv2.BORDER_CONSTANT, cv2.INTER_LINEAR, cv2.INTER_AREA = 0, 1, 3
+    cv2.setNumThreads = lambda n: None
+    cpuinfo.get_cpu_info = lambda: {"brand_raw": "cpu"}
+    os.environ["TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD"] = "1"
+    from ultralytics.utils import USER_CONFIG_DIR
+    import matplotlib
+    ttf = glob.glob(os.path.join(os.path.dirname(matplotlib.__file__), "mpl-data", "fonts", "ttf", "DejaVuSans.ttf"))[0]
+    for name in ("Arial.ttf", "Arial.Unicode.ttf"):
+        shutil.copy(ttf, os.path.join(str(USER_CONFIG_DIR), name))  # check_font would otherwise try to download it
+    from ultralytics.models.yolo.detect import DetectionTrainer
+    from ultralytics.utils import callbacks as cb_mod
+    import ultralytics.engine.trainer as trainer_mod
+    # experiment-tracker integrations (neptune, wandb, ...) see this harness's permissive import stubs as installed packages
+    cb_mod.add_integration_callbacks = lambda trainer: None
+    trainer_mod.callbacks.add_integration_callbacks = cb_mod.add_integration_callbacks
+    root = tempfile.mkdtemp(prefix="dy_e2e_")
+    write_e2e_dataset(root)
+    zero = dict(mosaic=0.0, mixup=0.0, copy_paste=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, degrees=0.0, translate=0.0, scale=0.0, shear=0.0,
+                perspective=0.0, flipud=0.0, fliplr=0.0)
+    ov = dict(model=os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"), data=os.path.join(root, "data.yaml"), epochs=E2E["epochs"], batch=E2E["batch"],
+              imgsz=E2E["imgsz"], device="cpu", workers=0, optimizer="SGD", amp=False, plots=False, val=True, close_mosaic=0, seed=0,
+              deterministic=True, project=os.path.join(root, "runs"), name="e2e", exist_ok=True, **zero)
+    import time
+    t0 = time.time()
+    tr = DetectionTrainer(overrides=ov)
+    tr.train()
+    print(f"reference trainer: {time.time() - t0:.0f} s")
+    rows = list(csv.reader(open(os.path.join(root, "runs", "e2e", "results.csv"))))
+    head = [h.strip() for h in rows[0]]
+    vals = np.array([[float(v) for v in r] for r in rows[1:]], dtype=np.float64)
+    print(head)
+    print(vals[[0, len(vals) // 2, -1]])
+    npz("e2e_trainer", header=np.array(head), results=vals, protocol=np.array(sorted(f"{k}={v}" for k, v in E2E.items())))
+    shutil.rmtree(root)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,44 @@
+"""-m gpu: the end-to-end protocol of SURVEY.md section 8(c).  tests/golden/e2e_trainer.npz holds the results.csv of the
+reference's UNMODIFIED trainer (its own dataset reader, loader, loss, optimizer, warm-up, EMA, validator; CPU, fp32) on the
+synthetic set of golden.cases.write_e2e_dataset: 16 + 16 images of 640x640, 40 epochs, batch 2, no augmentation.  Here the
+same files and overrides go through this package's public API -- YOLO(yaml).train(data=...) -- on the GPU, and the north-star
+clause is checked: mAP50 on the held-out images within 0.2 of the reference (weights are initialised from different random
+streams, so trajectories are compared statistically, not step by step)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden.cases import E2E, write_e2e_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def test_public_api_training_reaches_the_reference_trainers_map(tmp_path):
+    from ultralytics import YOLO
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_trainer.npz"))
+    head = [str(h) for h in G["header"]]
+    ref = {h: G["results"][:, j] for j, h in enumerate(head)}
+    root = str(tmp_path / "e2e")
+    write_e2e_dataset(root)
+    zero = dict(mosaic=0.0, mixup=0.0, copy_paste=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, degrees=0.0, translate=0.0, scale=0.0, shear=0.0,
+                perspective=0.0, flipud=0.0, fliplr=0.0)
+    torch.manual_seed(0)
+    y = YOLO("yolov8n-ASF-P2P2.yaml")
+    hist = y.train(data=os.path.join(root, "data.yaml"), epochs=E2E["epochs"], batch=E2E["batch"], imgsz=E2E["imgsz"], workers=2,
+                   optimizer="SGD", val=True, close_mosaic=0, seed=0, deterministic=True, log_every=1, **zero)
+    hist = np.asarray(hist, dtype=np.float64)
+    m = y.trainer.metrics
+    for e in (0, 9, 19, 29, 39):
+        print(f"epoch {e + 1:2d}  ours box/cls/dfl {np.round(hist[e], 3)}   reference "
+              f"{[round(float(ref[k][e]), 3) for k in ('train/box_loss', 'train/cls_loss', 'train/dfl_loss')]}")
+    print(f"held-out: ours P {m['metrics/precision(B)']:.3f} R {m['metrics/recall(B)']:.3f} mAP50 {m['metrics/mAP50(B)']:.3f} "
+          f"mAP50-95 {m['metrics/mAP50-95(B)']:.3f}   reference P {ref['metrics/precision(B)'][-1]:.3f} R {ref['metrics/recall(B)'][-1]:.3f} "
+          f"mAP50 {ref['metrics/mAP50(B)'][-1]:.3f} mAP50-95 {ref['metrics/mAP50-95(B)'][-1]:.3f}")
+    assert hist.shape == (E2E["epochs"], 3) and np.isfinite(hist).all()
+    r1 = np.array([ref[k][0] for k in ("train/box_loss", "train/cls_loss", "train/dfl_loss")])
+    assert np.all(np.abs(hist[0] - r1) / r1 < 0.15), "first-epoch mean losses (different random initial weights: 15 %)"
+    rl = np.array([ref[k][-1] for k in ("train/box_loss", "train/cls_loss", "train/dfl_loss")])
+    assert np.all(np.abs(hist[-1] - rl) / rl < 0.25), "last-epoch mean losses"
+    assert abs(m["metrics/mAP50(B)"] - ref["metrics/mAP50(B)"][-1]) < 0.2  # the north-star bound
