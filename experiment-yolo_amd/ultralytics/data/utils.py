@@ -32,48 +32,59 @@ def exif_size(img: Image.Image):
     return s
 
 
+class _Reject(Exception):
+    """A pair the reference would drop as corrupt."""
+
+
+def _read_labels(lb_file, num_cls):
+    """Label text -> (n,5) float32 rows [cls, x, y, w, h] and a note; raises _Reject on the reference's rejection rules."""
+    rows = [ln.split() for ln in Path(lb_file).read_text().strip().splitlines() if ln]
+    if not rows:
+        return np.zeros((0, 5), dtype=np.float32), ""
+    if max(len(r) for r in rows) > 6:
+        raise _Reject("segment labels are not on the detect path")
+    try:
+        lb = np.array(rows, dtype=np.float32)
+    except ValueError as e:
+        raise _Reject(str(e))
+    if lb.ndim != 2 or lb.shape[1] != 5:
+        raise _Reject(f"labels require 5 columns, {lb.shape[-1] if lb.ndim == 2 else 'ragged'} columns detected")
+    if lb[:, 1:].max() > 1:
+        raise _Reject(f"non-normalized or out of bounds coordinates {lb[:, 1:][lb[:, 1:] > 1]}")
+    if lb.min() < 0:
+        raise _Reject(f"negative label values {lb[lb < 0]}")
+    if lb[:, 0].max() > num_cls:
+        raise _Reject(f"Label class {int(lb[:, 0].max())} exceeds dataset class count {num_cls}")
+    first = np.unique(lb, axis=0, return_index=True)[1]  # first occurrence of every distinct row, rows come back SORTED
+    note = f"{len(lb) - len(first)} duplicate labels removed" if len(first) < len(lb) else ""
+    return (lb[first] if note else lb), note
+
+
 def verify_image_label(im_file, lb_file, num_cls):
     """One image/label pair -> (im_file | None, labels (n,5) float32 [cls, x, y, w, h], (h, w), n_missing, n_found, n_empty,
-    n_corrupt, message).  Same acceptance rules as the reference: image at least 10x10 and of a known format; five columns;
-    coordinates normalised (<= 1) and non-negative; class ids within the dataset's count; duplicate rows removed (np.unique,
-    i.e. the kept rows come back sorted); any violation drops the whole image as corrupt."""
-    nm = nf = ne = nc = 0
-    msg = ""
+    n_corrupt, message).  Same acceptance rules as the reference (data/utils.py:96-165): image at least 10x10 and of a known
+    format; five columns; coordinates normalised (<= 1) and non-negative; class ids within the dataset's count; duplicate rows
+    removed (np.unique, i.e. the kept rows come back sorted); any violation drops the whole image as corrupt."""
+    missing = found = empty = 0
     try:
-        im = Image.open(im_file)
-        im.verify()
-        shape = exif_size(im)
-        shape = (shape[1], shape[0])  # hw
-        assert (shape[0] > 9) & (shape[1] > 9), f"image size {shape} <10 pixels"
-        assert im.format.lower() in IMG_FORMATS, f"invalid image format {im.format}"
+        with Image.open(im_file) as im:
+            im.verify()
+            w, h = exif_size(im)
+            fmt = (im.format or "").lower()
+        if min(h, w) < 10:
+            raise _Reject(f"image size {(h, w)} <10 pixels")
+        if fmt not in IMG_FORMATS:
+            raise _Reject(f"invalid image format {fmt}")
+        note = ""
         if os.path.isfile(lb_file):
-            nf = 1
-            with open(lb_file) as f:
-                lb = [x.split() for x in f.read().strip().splitlines() if len(x)]
-            if any(len(x) > 6 for x in lb):
-                raise AssertionError("segment labels are not on the detect path")
-            lb = np.array(lb, dtype=np.float32)
-            nl = len(lb)
-            if nl:
-                assert lb.shape[1] == 5, f"labels require 5 columns, {lb.shape[1]} columns detected"
-                points = lb[:, 1:]
-                assert points.max() <= 1, f"non-normalized or out of bounds coordinates {points[points > 1]}"
-                assert lb.min() >= 0, f"negative label values {lb[lb < 0]}"
-                max_cls = lb[:, 0].max()
-                assert max_cls <= num_cls, f"Label class {int(max_cls)} exceeds dataset class count {num_cls}"
-                _, i = np.unique(lb, axis=0, return_index=True)
-                if len(i) < nl:
-                    lb = lb[i]
-                    msg = f"WARNING {im_file}: {nl - len(i)} duplicate labels removed"
-            else:
-                ne = 1
-                lb = np.zeros((0, 5), dtype=np.float32)
+            found = 1
+            lb, note = _read_labels(lb_file, num_cls)
+            empty = int(len(lb) == 0)
         else:
-            nm = 1
-            lb = np.zeros((0, 5), dtype=np.float32)
-        return im_file, lb[:, :5], shape, nm, nf, ne, nc, msg
-    except Exception as e:
-        return None, None, None, nm, nf, ne, 1, f"WARNING {im_file}: ignoring corrupt image/label: {e}"
+            missing, lb = 1, np.zeros((0, 5), dtype=np.float32)
+        return im_file, lb, (h, w), missing, found, empty, 0, f"WARNING {im_file}: {note}" if note else ""
+    except Exception as e:  # noqa: BLE001 -- the reference catches everything here too
+        return None, None, None, missing, found, empty, 1, f"WARNING {im_file}: ignoring corrupt image/label: {e}"
 
 
 def check_det_dataset(dataset):

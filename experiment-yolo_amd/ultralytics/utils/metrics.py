@@ -36,12 +36,11 @@ def smooth(y, f=0.05):
 
 def compute_ap(recall, precision):
     """AP by 101-point interpolation of the precision envelope (reference :1109-1139).  Returns (ap, mpre, mrec)."""
-    mrec = np.concatenate(([0.0], recall, [1.0]))
-    mpre = np.concatenate(([1.0], precision, [0.0]))
-    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
+    mrec = np.r_[0.0, recall, 1.0]
+    envelope = np.maximum.accumulate(np.r_[1.0, precision, 0.0][::-1])[::-1]  # right-to-left running maximum
     grid = np.linspace(0, 1, 101)
     integrate = getattr(np, "trapezoid", None) or np.trapz
-    return integrate(np.interp(grid, mrec, mpre), grid), mpre, mrec
+    return integrate(np.interp(grid, mrec, envelope), grid), envelope, mrec
 
 
 def ap_per_class(tp, conf, pred_cls, target_cls, plot=False, on_plot=None, save_dir=None, names=(), eps=1e-16, prefix=""):
@@ -50,63 +49,59 @@ def ap_per_class(tp, conf, pred_cls, target_cls, plot=False, on_plot=None, save_
         raise NotImplementedError("PR-curve plotting is control plane (SURVEY.md section 8: out of scope)")
     order = np.argsort(-conf)
     tp, conf, pred_cls = tp[order], conf[order], pred_cls[order]
-    unique_classes, nt = np.unique(target_cls, return_counts=True)
-    nc = unique_classes.shape[0]
-    x, prec_values = np.linspace(0, 1, 1000), []
-    ap, p_curve, r_curve = np.zeros((nc, tp.shape[1])), np.zeros((nc, 1000)), np.zeros((nc, 1000))
-    for ci, c in enumerate(unique_classes):
+    classes, n_labels = np.unique(target_cls, return_counts=True)
+    n_cls, n_thr, n_grid = classes.shape[0], tp.shape[1], 1000
+    x = np.linspace(0, 1, n_grid)
+    ap = np.zeros((n_cls, n_thr))
+    p_curve, r_curve = np.zeros((n_cls, n_grid)), np.zeros((n_cls, n_grid))
+    for ci, (c, n_l) in enumerate(zip(classes, n_labels)):
         sel = pred_cls == c
-        n_l, n_p = nt[ci], sel.sum()
-        if n_p == 0 or n_l == 0:
+        if not sel.any() or n_l == 0:
             continue
-        fpc, tpc = (1 - tp[sel]).cumsum(0), tp[sel].cumsum(0)
-        recall = tpc / (n_l + eps)
+        hits = tp[sel].cumsum(0)
+        misses = (1 - tp[sel]).cumsum(0)
+        recall, precision = hits / (n_l + eps), hits / (hits + misses)
         r_curve[ci] = np.interp(-x, -conf[sel], recall[:, 0], left=0)  # negated: xp must increase
-        precision = tpc / (tpc + fpc)
         p_curve[ci] = np.interp(-x, -conf[sel], precision[:, 0], left=1)
-        for j in range(tp.shape[1]):
-            ap[ci, j] = compute_ap(recall[:, j], precision[:, j])[0]
+        ap[ci] = [compute_ap(recall[:, j], precision[:, j])[0] for j in range(n_thr)]
     f1_curve = 2 * p_curve * r_curve / (p_curve + r_curve + eps)
     k = smooth(f1_curve.mean(0), 0.1).argmax()
     p, r, f1 = p_curve[:, k], r_curve[:, k], f1_curve[:, k]
-    tpn = (r * nt).round()
+    tpn = (r * n_labels).round()
     fpn = (tpn / (p + eps) - tpn).round()
-    return tpn, fpn, p, r, f1, ap, unique_classes.astype(int), p_curve, r_curve, f1_curve, x, np.array(prec_values)
+    return tpn, fpn, p, r, f1, ap, classes.astype(int), p_curve, r_curve, f1_curve, x, np.array([])
+
+
+def _avg(a, empty=0.0):
+    return a.mean() if len(a) else empty
 
 
 class Metric:
-    """Per-class results container (reference :1233-1402)."""
+    """Per-class results container with the reference's attribute names (reference :1233-1402): ``p, r, f1, all_ap
+    (classes x 10 IoU thresholds), ap_class_index, nc`` and the derived ``ap50, ap, mp, mr, map50, map75, map, maps``."""
 
     def __init__(self):
         self.p, self.r, self.f1, self.all_ap, self.ap_class_index, self.nc = [], [], [], [], [], 0
 
-    @property
-    def ap50(self):
-        return self.all_ap[:, 0] if len(self.all_ap) else []
+    def update(self, results):
+        self.p, self.r, self.f1, self.all_ap, self.ap_class_index = results[:5]
+
+    def _ap_at(self, col):
+        return self.all_ap[:, col] if len(self.all_ap) else []
+
+    ap50 = property(lambda self: self._ap_at(0))
+    ap = property(lambda self: self.all_ap.mean(1) if len(self.all_ap) else [])
+    mp = property(lambda self: _avg(self.p))
+    mr = property(lambda self: _avg(self.r))
+    map50 = property(lambda self: _avg(self._ap_at(0)))
+    map75 = property(lambda self: _avg(self._ap_at(5)))
+    map = property(lambda self: _avg(self.all_ap) if len(self.all_ap) else 0.0)
 
     @property
-    def ap(self):
-        return self.all_ap.mean(1) if len(self.all_ap) else []
-
-    @property
-    def mp(self):
-        return self.p.mean() if len(self.p) else 0.0
-
-    @property
-    def mr(self):
-        return self.r.mean() if len(self.r) else 0.0
-
-    @property
-    def map50(self):
-        return self.all_ap[:, 0].mean() if len(self.all_ap) else 0.0
-
-    @property
-    def map75(self):
-        return self.all_ap[:, 5].mean() if len(self.all_ap) else 0.0
-
-    @property
-    def map(self):
-        return self.all_ap.mean() if len(self.all_ap) else 0.0
+    def maps(self):
+        out = np.full(self.nc, self.map, dtype=np.float64)
+        out[np.asarray(self.ap_class_index, dtype=int)] = self.ap
+        return out
 
     def mean_results(self):
         return [self.mp, self.mr, self.map50, self.map]
@@ -114,56 +109,34 @@ class Metric:
     def class_result(self, i):
         return self.p[i], self.r[i], self.ap50[i], self.ap[i]
 
-    @property
-    def maps(self):
-        maps = np.zeros(self.nc) + self.map
-        for i, c in enumerate(self.ap_class_index):
-            maps[c] = self.ap[i]
-        return maps
-
     def fitness(self):
-        return (np.array(self.mean_results()) * [0.0, 0.0, 0.1, 0.9]).sum()
-
-    def update(self, results):
-        self.p, self.r, self.f1, self.all_ap, self.ap_class_index = results[:5]
+        mp, mr, m50, m = self.mean_results()
+        return 0.1 * m50 + 0.9 * m  # weights [0, 0, 0.1, 0.9] over (P, R, mAP50, mAP50-95)
 
 
 class DetMetrics:
     """Reference :1405-1480: ``process`` the concatenated statistics, then read ``results_dict`` / ``mean_results``."""
+    keys = ["metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)"]
+    task = "detect"
 
     def __init__(self, save_dir=None, plot=False, on_plot=None, names=()):
         self.save_dir, self.plot, self.on_plot, self.names = save_dir, plot, on_plot, names
         self.box = Metric()
-        self.speed = {"preprocess": 0.0, "inference": 0.0, "loss": 0.0, "postprocess": 0.0}
-        self.task = "detect"
+        self.speed = dict.fromkeys(("preprocess", "inference", "loss", "postprocess"), 0.0)
 
     def process(self, tp, conf, pred_cls, target_cls):
-        results = ap_per_class(tp, conf, pred_cls, target_cls, plot=False, names=self.names)[2:]
         self.box.nc = len(self.names)
-        self.box.update(results)
+        self.box.update(ap_per_class(tp, conf, pred_cls, target_cls, plot=False, names=self.names)[2:])
 
-    @property
-    def keys(self):
-        return ["metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)"]
-
-    def mean_results(self):
-        return self.box.mean_results()
-
-    def class_result(self, i):
-        return self.box.class_result(i)
-
-    @property
-    def maps(self):
-        return self.box.maps
+    def __getattr__(self, name):  # mean_results / class_result / maps / ap_class_index are the box metric's
+        if name in ("mean_results", "class_result", "maps", "ap_class_index"):
+            return getattr(self.box, name)
+        raise AttributeError(name)
 
     @property
     def fitness(self):
         return self.box.fitness()
 
     @property
-    def ap_class_index(self):
-        return self.box.ap_class_index
-
-    @property
     def results_dict(self):
-        return dict(zip(self.keys + ["fitness"], self.mean_results() + [self.fitness]))
+        return dict(zip(self.keys + ["fitness"], [*self.box.mean_results(), self.fitness]))

@@ -705,7 +705,12 @@ def gen_two_stage():
     npz("two_stage", **arrs)
 
 
-def gen_e2e():
+def gen_e2e_ld():
+    """The same protocol for the LDConv model (BASELINE configs[3] oracle): yolov8n-LD-P2.yaml, p_conv zero-initialised."""
+    gen_e2e("yolov8n-LD-P2", "e2e_trainer_ld")
+
+
+def gen_e2e(model_name="yolov8n-ASF-P2P2", out_name="e2e_trainer"):
     """End-to-end protocol of SURVEY section 8(c): the reference's UNMODIFIED trainer (DetectionTrainer(overrides).train():
     its dataset reader, loader, loss, optimizer, warm-up, EMA, validator, soft-NMS) on the synthetic set of
     cases.write_e2e_dataset, CPU, fp32, batch 2, all augmentation gains zero.  The fixture keeps its results.csv (per-epoch
@@ -751,7 +756,7 @@ def gen_e2e():
     write_e2e_dataset(root)
     zero = dict(mosaic=0.0, mixup=0.0, copy_paste=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, degrees=0.0, translate=0.0, scale=0.0, shear=0.0,
                 perspective=0.0, flipud=0.0, fliplr=0.0)
-    ov = dict(model=os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"), data=os.path.join(root, "data.yaml"), epochs=E2E["epochs"], batch=E2E["batch"],
+    ov = dict(model=os.path.join(CFG_DIR, model_name + ".yaml"), data=os.path.join(root, "data.yaml"), epochs=E2E["epochs"], batch=E2E["batch"],
               imgsz=E2E["imgsz"], device="cpu", workers=0, optimizer="SGD", amp=False, plots=False, val=True, close_mosaic=0, seed=0,
               deterministic=True, project=os.path.join(root, "runs"), name="e2e", exist_ok=True, **zero)
     import time
@@ -764,7 +769,7 @@ def gen_e2e():
     vals = np.array([[float(v) for v in r] for r in rows[1:]], dtype=np.float64)
     print(head)
     print(vals[[0, len(vals) // 2, -1]])
-    npz("e2e_trainer", header=np.array(head), results=vals, protocol=np.array(sorted(f"{k}={v}" for k, v in E2E.items())))
+    npz(out_name, header=np.array(head), results=vals, protocol=np.array(sorted(f"{k}={v}" for k, v in E2E.items())))
     shutil.rmtree(root)
 
 
