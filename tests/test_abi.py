@@ -64,3 +64,27 @@ def test_conv_kernel_name_helper():
     assert L.dy_conv_kernel_name(64, 64, 1, 1, buf, 128) == 0 and buf.value.startswith(b"conv_mfma_pp_kernel<64, 4, 1, 1,")
     assert L.dy_conv_kernel_name(64, 64, 5, 1, buf, 128) != 0
     assert L.dy_wgrad_reduce_desc_bytes() >= 64
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 without HIP (what cgo / bindgen / cffi would feed a C compiler),
+    and a C translation unit that takes the address of every declared function must link against the library."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "dealyolo_hip.h")
+    names = sorted(set(re.findall(r"^\s*(?:int|long|void|const char\s*\*)\s+(dy_\w+)\s*\(", open(hdr).read(), flags=re.M)))
+    assert len(names) > 40
+    src = tmp_path / "abi.c"
+    src.write_text('#include "dealyolo_hip.h"\n#include <stdio.h>\nint main(void) {\n  void* f[] = {' + ", ".join(f"(void*){n}" for n in names) +
+                   '};\n  printf("%d %d\\n", (int)(sizeof f / sizeof f[0]), dy_abi_version());\n  return 0;\n}\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-Wno-pedantic", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
+                   check=True, capture_output=True)
+    lib = os.path.join(root, "experiment-yolo_amd", "csrc", "libdealyolo_hip.so")
+    exe = tmp_path / "abi"
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), lib, "-Wl,-rpath," + os.path.dirname(lib),
+                        "-Wl,--unresolved-symbols=ignore-in-shared-libs", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

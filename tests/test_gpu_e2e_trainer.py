@@ -15,9 +15,11 @@ from golden.cases import E2E, write_e2e_dataset
 pytestmark = pytest.mark.gpu
 
 
-def test_public_api_training_reaches_the_reference_trainers_map(tmp_path):
+@pytest.mark.parametrize("model,fixture", [("yolov8n-ASF-P2P2.yaml", "e2e_trainer.npz"), ("yolov8n-LD-P2.yaml", "e2e_trainer_ld.npz")],
+                         ids=["DEAL-YOLO-N", "LD"])
+def test_public_api_training_reaches_the_reference_trainers_map(tmp_path, model, fixture):
     from ultralytics import YOLO
-    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_trainer.npz"))
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
     head = [str(h) for h in G["header"]]
     ref = {h: G["results"][:, j] for j, h in enumerate(head)}
     root = str(tmp_path / "e2e")
@@ -25,7 +27,7 @@ def test_public_api_training_reaches_the_reference_trainers_map(tmp_path):
     zero = dict(mosaic=0.0, mixup=0.0, copy_paste=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, degrees=0.0, translate=0.0, scale=0.0, shear=0.0,
                 perspective=0.0, flipud=0.0, fliplr=0.0)
     torch.manual_seed(0)
-    y = YOLO("yolov8n-ASF-P2P2.yaml")
+    y = YOLO(model)
     hist = y.train(data=os.path.join(root, "data.yaml"), epochs=E2E["epochs"], batch=E2E["batch"], imgsz=E2E["imgsz"], workers=2,
                    optimizer="SGD", val=True, close_mosaic=0, seed=0, deterministic=True, log_every=1, **zero)
     hist = np.asarray(hist, dtype=np.float64)
