@@ -69,9 +69,8 @@ def test_conv_kernel_name_helper():
 def test_header_is_plain_c(tmp_path):
     """The boundary is a C ABI: the header must compile as C99 without HIP (what cgo / bindgen / cffi would feed a C compiler),
     and a C translation unit that takes the address of every declared function must link against the library."""
-    import re
     import shutil
-    import subprocess
+    import pytest
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
