@@ -78,7 +78,7 @@ struct StepArgs {
   float* state;
   long n, g0_end, g1_end;  // group boundaries: [0,g0_end) bias, [g0_end,g1_end) decayed weights, rest norm weights
   const uint8_t* frozen;   // optional per-element mask (1 = requires_grad False)
-  int adam;                // 0 SGD-nesterov, 1 Adam (L2 decay), 2 AdamW (decoupled)
+  int adam;                // 0 SGD-nesterov, 1 Adam (L2 decay), 2 AdamW (decoupled), 3 RMSprop(alpha .99, momentum), 4 RAdam, 5 Adamax
 };
 
 __global__ __launch_bounds__(256) void optim_step_kernel(StepArgs a) {
@@ -97,6 +97,34 @@ __global__ __launch_bounds__(256) void optim_step_kernel(StepArgs a) {
         float buf = first ? g : mom * a.m[i] + g;
         a.m[i] = buf;
         p -= lr * (g + mom * buf);
+      } else if (a.adam == 3) {  // torch.optim.RMSprop(lr, alpha=0.99, eps=1e-8, momentum): engine/trainer.py:1161-1162
+        if (wd != 0.f) g += wd * p;
+        const float sq = 0.99f * (first ? 0.f : a.v[i]) + 0.01f * g * g;
+        a.v[i] = sq;
+        const float step = g / (sqrtf(sq) + 1e-8f);
+        const float buf = mom * (first ? 0.f : a.m[i]) + step;
+        a.m[i] = buf;
+        p -= lr * (mom > 0.f ? buf : step);
+      } else if (a.adam == 4 || a.adam == 5) {  // torch.optim.RAdam / Adamax (betas = (momentum, 0.999), eps 1e-8, L2 decay)
+        if (wd != 0.f) g += wd * p;
+        const float b2 = a.hyper[9], t = a.state[5] + 1.f;
+        const float m = mom * (first ? 0.f : a.m[i]) + (1.f - mom) * g;
+        a.m[i] = m;
+        const float bc1 = 1.f - powf(mom, t);
+        if (a.adam == 5) {
+          const float u = fmaxf(b2 * (first ? 0.f : a.v[i]), fabsf(g) + 1e-8f);
+          a.v[i] = u;
+          p -= lr / bc1 * m / u;
+        } else {
+          const float v = b2 * (first ? 0.f : a.v[i]) + (1.f - b2) * g * g;
+          a.v[i] = v;
+          const float b2t = powf(b2, t), bc2 = 1.f - b2t;
+          const float rho_inf = 2.f / (1.f - b2) - 1.f, rho = rho_inf - 2.f * t * b2t / bc2;
+          float upd = m / bc1;
+          if (rho > 5.f)
+            upd *= sqrtf((rho - 4.f) * (rho - 2.f) * rho_inf / ((rho_inf - 4.f) * (rho_inf - 2.f) * rho)) * (sqrtf(bc2) / (sqrtf(v) + 1e-8f));
+          p -= lr * upd;
+        }
       } else {
         if (a.adam == 2) p *= 1.f - lr * wd;
         else if (wd != 0.f) g += wd * p;
@@ -142,7 +170,7 @@ extern "C" int dy_optimizer_step(float* params, const float* grads, float* mom, 
                                  long g0_end, long g1_end, const unsigned char* frozen, const float* buffers,
                                  float* ema_buffers, long n_buffers, const float* hyper, float* state,
                                  float* partials, int mode, hipStream_t stream) {
-  if (n <= 0 || mode < 0 || mode > 2 || (mode > 0 && !adam_v)) return DY_ERR_ARG;
+  if (n <= 0 || mode < 0 || mode > 5 || (mode > 0 && !adam_v)) return DY_ERR_ARG;
   int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(grad_sumsq_kernel, dim3(blocks), dim3(256), 0, stream, grads, n, partials);
   hipLaunchKernelGGL(grad_norm_final_kernel, dim3(1), dim3(256), 0, stream, partials, blocks, hyper, state);

@@ -241,3 +241,47 @@ def test_scalseq_backward_all_levels_matches_per_level():
     torch.cuda.synchronize()
     for l in range(3):
         assert relerr(outs[l].float(), refs[l].float()) < 2e-3, l
+
+
+@pytest.mark.parametrize("name", ["SGD", "Adam", "AdamW", "RMSProp", "RAdam", "Adamax"])
+def test_flat_optimizer_step_matches_torch_optim(name):
+    """dy_optimizer_step (unscale, global-norm clip, step per parameter group) against torch.optim on the CPU, built like the
+    reference's build_optimizer (engine/trainer.py:1146-1180): betas = (momentum, 0.999), weight decay on the middle group."""
+    import ctypes as C
+    from ultralytics.hip import check, lib
+    g = torch.Generator().manual_seed(5)
+    n, g0, g1 = 3000, 500, 2200  # [0,g0) bias group, [g0,g1) decayed weights, rest norm weights
+    p0 = torch.randn(n, generator=g)
+    lr, mom, wd, scale, max_norm = 0.01, 0.9, 0.05, 8.0, 10.0
+    ref_p = [p0[:g0].clone().requires_grad_(True), p0[g0:g1].clone().requires_grad_(True), p0[g1:].clone().requires_grad_(True)]
+    groups = [dict(params=[ref_p[0]], weight_decay=0.0), dict(params=[ref_p[1]], weight_decay=wd), dict(params=[ref_p[2]], weight_decay=0.0)]
+    opt = {"SGD": lambda: torch.optim.SGD(groups, lr=lr, momentum=mom, nesterov=True),
+           "Adam": lambda: torch.optim.Adam(groups, lr=lr, betas=(mom, 0.999)),
+           "AdamW": lambda: torch.optim.AdamW(groups, lr=lr, betas=(mom, 0.999)),
+           "RMSProp": lambda: torch.optim.RMSprop(groups, lr=lr, momentum=mom),
+           "RAdam": lambda: torch.optim.RAdam(groups, lr=lr, betas=(mom, 0.999)),
+           "Adamax": lambda: torch.optim.Adamax(groups, lr=lr, betas=(mom, 0.999))}[name]()
+    mode = {"SGD": 0, "Adam": 1, "AdamW": 2, "RMSProp": 3, "RAdam": 4, "Adamax": 5}[name]
+    dev = "cuda:0"
+    p = p0.clone().to(dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    hyper = torch.zeros(16, device=dev)
+    hyper[0:3] = lr
+    hyper[3], hyper[5], hyper[7], hyper[8], hyper[9], hyper[10] = mom, wd, 0.0, max_norm, 0.999, 1e-8
+    state = torch.zeros(8, device=dev)
+    state[0] = scale
+    partials = torch.zeros(4096, device=dev)
+    buf = torch.zeros(8, device=dev)
+    for step in range(8):  # RAdam switches to the rectified update at step 6
+        grad = torch.randn(n, generator=g) * (3.0 if step == 2 else 0.5)  # step 2 exceeds the clip norm
+        for q, sl in zip(ref_p, (slice(0, g0), slice(g0, g1), slice(g1, n))):
+            q.grad = grad[sl].clone()
+        torch.nn.utils.clip_grad_norm_(ref_p, max_norm)
+        opt.step()
+        gd = (grad * scale).to(dev)
+        check(lib().dy_optimizer_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), None, n, g0, g1, None, buf.data_ptr(), None, 0,
+                                      hyper.data_ptr(), state.data_ptr(), partials.data_ptr(), mode, None), "dy_optimizer_step")
+        torch.cuda.synchronize()
+        ref = torch.cat([q.detach() for q in ref_p])
+        assert relerr(p, ref) < 2e-5, (name, step)
+    assert float(state[5]) == 8 and float(state[6]) == 0
