@@ -105,9 +105,9 @@ class HipDataLoader:
             self._pool[lo:hi].copy_(stage[:hi - lo], non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()  # the staging buffer is reused by the next chunk
 
-    def _assemble_pool(self, idx):
+    def _assemble_pool(self, workers, idx):
         flips = [self.dataset.draw_augment() for _ in idx]
-        samples = [self.dataset.get(i, f, pixels=False) for i, f in zip(idx, flips)]
+        samples = list(workers.map(lambda t: self.dataset.get(t[0], t[1], pixels=False), zip(idx, flips)))
         batch = self.dataset.collate_fn(samples)
         batch["img"] = self._pool
         batch["index"] = torch.tensor(idx, dtype=torch.int32).to(self.device, non_blocking=True)
@@ -182,7 +182,7 @@ class HipDataLoader:
                     for k, c in enumerate(chunks):
                         if stop.is_set():
                             return
-                        q.put(self._assemble_pool(c) if hbm else self._assemble(pool, c, k % (self.prefetch + 2)))
+                        q.put(self._assemble_pool(pool, c) if hbm else self._assemble(pool, c, k % (self.prefetch + 2)))
                 q.put(None)
             except BaseException as e:  # surfaced in the consumer
                 q.put(e)
