@@ -103,6 +103,74 @@ extern "C" int dy_import_image_u8(const void* x, void* y, int n, int h, int w, i
   return DY_OK;
 }
 
+// Mosaic + random affine + flips composed ON THE DEVICE, straight into the fp16 stem input (Mosaic._mosaic4, data/augment.py:208-
+// 241; RandomPerspective.affine_transform / cv2.warpAffine :384-435; RandomFlip :651-683).  The decoded training set lives in HBM
+// (x = pool of letterboxed S x S uint8 images); the host only draws the random decisions and transforms the labels.  Per batch
+// slot one WarpSlot: the inverse affine map (output pixel -> canvas), the canvas (2S x 2S mosaic of up to four pool images, each
+// a destination rectangle + source offset, or the S x S letterbox of one image), the flip bits.  Every output pixel is one
+// bilinear sample of that virtual canvas -- grey 114 outside the rectangles and outside the canvas (np.full / borderValue) --
+// so the mosaic canvas, the warped image and the uint8 batch are never materialised.  Sampling is float bilinear with
+// round-to-nearest; cv2's fixed-point INTER_LINEAR (5 fractional bits) is not reproduced.
+struct WarpSlot {
+  float minv[6];                   // u = minv[0]*x + minv[1]*y + minv[2];  v = minv[3]*x + minv[4]*y + minv[5]
+  int canvas_w, canvas_h, xc, yc;  // mosaic centre: patch k = (u >= xc) + 2*(v >= yc); single image: xc = yc = canvas size
+  int flip, npatch;
+  int patch[4][7];                 // pool index, x1a, y1a, x2a, y2a (destination, exclusive ends), source x, y of the rectangle's corner
+};
+
+static __device__ __forceinline__ void warp_fetch(const unsigned char* pool, const WarpSlot& w, int S, int cx, int cy, float (&v)[3]) {
+  v[0] = v[1] = v[2] = 114.f;
+  if ((unsigned)cx >= (unsigned)w.canvas_w || (unsigned)cy >= (unsigned)w.canvas_h) return;
+  const int k = w.npatch == 1 ? 0 : (cx >= w.xc ? 1 : 0) + (cy >= w.yc ? 2 : 0);
+  const int* p = w.patch[k];
+  if (cx < p[1] || cx >= p[3] || cy < p[2] || cy >= p[4]) return;
+  const int sx = cx - p[1] + p[5], sy = cy - p[2] + p[6];
+  if ((unsigned)sx >= (unsigned)S || (unsigned)sy >= (unsigned)S) return;
+  const unsigned char* q = pool + (((long)p[0] * S + sy) * S + sx) * 3;
+  v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2];
+}
+
+__global__ __launch_bounds__(256) void warp_import_kernel(const unsigned char* pool, const WarpSlot* slots, f16* y, int N, int S, int Cp) {
+  const long per = (long)S * S, total = per * N;
+  for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long)gridDim.x * 256) {
+    const int n = (int)(pix / per);
+    const int r = (int)(pix - (long)n * per);
+    int oy = r / S, ox = r - oy * S;
+    const WarpSlot& w = slots[n];
+    if (w.flip & 1) ox = S - 1 - ox;
+    if (w.flip & 2) oy = S - 1 - oy;
+    const float u = w.minv[0] * (float)ox + w.minv[1] * (float)oy + w.minv[2];
+    const float vv = w.minv[3] * (float)ox + w.minv[4] * (float)oy + w.minv[5];
+    const float fu = floorf(u), fv = floorf(vv);
+    const int x0 = (int)fu, y0 = (int)fv;
+    const float ax = u - fu, ay = vv - fv;
+    float c00[3], c01[3], c10[3], c11[3];
+    warp_fetch(pool, w, S, x0, y0, c00);
+    warp_fetch(pool, w, S, x0 + 1, y0, c01);
+    warp_fetch(pool, w, S, x0, y0 + 1, c10);
+    warp_fetch(pool, w, S, x0 + 1, y0 + 1, c11);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float top = c00[c] * (1.f - ax) + c01[c] * ax, bot = c10[c] * (1.f - ax) + c11[c] * ax;
+      o[c] = (f16)(fminf(fmaxf(rintf(top * (1.f - ay) + bot * ay), 0.f), 255.f) / 255.f);
+    }
+    *reinterpret_cast<half8*>(y + pix * Cp) = o;
+    for (int c0 = 8; c0 < Cp; c0 += 8) *reinterpret_cast<half8*>(y + pix * Cp + c0) = half8{};
+  }
+}
+extern "C" int dy_warp_import_u8(const void* pool, const void* slots, void* y, int n, int s, int cp, hipStream_t stream) {
+  if ((cp & 7) || cp < 8) return DY_ERR_ALIGN;
+  if (!pool || !slots || n <= 0) return DY_ERR_ARG;
+  hipLaunchKernelGGL(warp_import_kernel, dim3(grid_for((long)n * s * s)), dim3(256), 0, stream, (const unsigned char*)pool, (const WarpSlot*)slots,
+                     (f16*)y, n, s, cp);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+extern "C" int dy_warp_slot_bytes(void) { return (int)sizeof(WarpSlot); }
+
 // ---- generic 8-channel-granule element-wise kernels
 struct EwArgs {
   const f16* a;

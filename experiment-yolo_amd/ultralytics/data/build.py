@@ -30,7 +30,7 @@ AUGMENT_KEYS = ("mosaic", "mixup", "copy_paste", "hsv_h", "hsv_s", "hsv_v", "deg
 
 
 def build_yolo_dataset(cfg, img_path, batch, data, mode="train", rect=False, stride=32, layout="nhwc", flip_on_device=False):
-    flips = dict(flipud=float(getattr(cfg, "flipud", 0.0) or 0.0), fliplr=float(getattr(cfg, "fliplr", 0.0) or 0.0)) if mode == "train" else {}
+    flips = {k: float(getattr(cfg, k, 0.0) or 0.0) for k in ("flipud", "fliplr", "mosaic", "degrees", "translate", "scale", "shear")} if mode == "train" else {}
     return YOLODataset(img_path=img_path, imgsz=cfg.imgsz, batch_size=batch, augment=mode == "train", flip_on_device=flip_on_device, **flips,
                        rect=bool(getattr(cfg, "rect", False)) or rect, stride=int(stride), pad=0.0 if mode == "train" else 0.5,
                        data=data, fraction=getattr(cfg, "fraction", 1.0) if mode == "train" else 1.0,
@@ -91,6 +91,8 @@ class HipDataLoader:
         if not (ds.augment and ds.flip_on_device and ds.layout == "nhwc" and not ds.rect):
             raise ValueError("cache='hbm' needs the training dataset in NHWC layout with flip_on_device=True")
         shape = tuple(ds.get(0, 0)["img"].shape)
+        if ds.geometric and shape[0] != shape[1]:
+            raise ValueError("mosaic / affine need square training canvases")
         n, chunk = len(ds), 256
         self._pool = torch.empty((n, *shape), dtype=torch.uint8, device=self.device)
         stage = torch.empty((min(chunk, n), *shape), dtype=torch.uint8).pin_memory()
@@ -106,12 +108,16 @@ class HipDataLoader:
             torch.cuda.current_stream(self.device).synchronize()  # the staging buffer is reused by the next chunk
 
     def _assemble_pool(self, workers, idx):
-        flips = [self.dataset.draw_augment() for _ in idx]
-        samples = list(workers.map(lambda t: self.dataset.get(t[0], t[1], pixels=False), zip(idx, flips)))
+        flips = [self.dataset.draw_augment(i) for i in idx]
+        # label arithmetic is a few dozen tiny numpy calls per sample: GIL-bound, so worker threads only add contention
+        samples = [self.dataset.get(i, f, pixels=False) for i, f in zip(idx, flips)]
         batch = self.dataset.collate_fn(samples)
         batch["img"] = self._pool
-        batch["index"] = torch.tensor(idx, dtype=torch.int32).to(self.device, non_blocking=True)
-        batch["flip"] = batch["flip"].to(self.device, non_blocking=True)
+        if "warp" in batch:  # mosaic / affine: the device composes the pixels from per-slot records (flips included)
+            batch["warp"] = batch["warp"].to(self.device, non_blocking=True)
+        else:
+            batch["index"] = torch.tensor(idx, dtype=torch.int32).to(self.device, non_blocking=True)
+            batch["flip"] = batch["flip"].to(self.device, non_blocking=True)
         return batch
 
     def _assemble(self, pool, idx, slot):
@@ -119,7 +125,7 @@ class HipDataLoader:
         (memcpy, GIL released) -- a pinned ring slot when a device is set, fresh host memory otherwise; only the label tensors
         go through collate_fn."""
         n, W = len(idx), min(self.workers, len(idx))
-        flips = [self.dataset.draw_augment() for _ in idx]  # RNG consumed here, in sample order, whatever the worker schedule
+        flips = [self.dataset.draw_augment(i) for i in idx]  # RNG consumed here, in sample order, whatever the worker schedule
         first = self.dataset.get(idx[0], flips[0])
         shape = tuple(first["img"].shape)
         if self.device is not None:

@@ -53,13 +53,18 @@ def letterbox_geometry(shape, new_shape, scaleup):
 
 class YOLODataset:
     def __init__(self, img_path, imgsz=640, batch_size=16, augment=False, rect=False, stride=32, pad=0.0, data=None, fraction=1.0,
-                 cache=False, layout="nhwc", prefix="", flipud=0.0, fliplr=0.0, flip_on_device=False):
+                 cache=False, layout="nhwc", prefix="", flipud=0.0, fliplr=0.0, flip_on_device=False, mosaic=0.0, degrees=0.0,
+                 translate=0.0, scale=0.0, shear=0.0):
         self.img_path, self.imgsz, self.batch_size, self.augment, self.rect = img_path, int(imgsz), batch_size, augment, rect
         self.flipud, self.fliplr, self.flip_on_device = float(flipud), float(fliplr), flip_on_device
+        self.mosaic, self.degrees, self.translate, self.scale, self.shear = (float(v) for v in (mosaic, degrees, translate, scale, shear))
+        self.geometric = augment and any((self.mosaic, self.degrees, self.translate, self.scale, self.shear))
+        self.buffer, self._in_buffer = [], set()  # BaseDataset.buffer (base.py:86-87, :170-176): what Mosaic draws its partners from
         self.stride, self.pad, self.data, self.fraction, self.layout, self.prefix = stride, pad, data or {}, fraction, layout, prefix
         self.im_files = self.get_img_files(img_path)
         self.labels = self.get_labels()
         self.ni = len(self.labels)
+        self.max_buffer_length = min(self.ni, self.batch_size * 8, 1000) if augment else 0
         if rect:
             self.set_rectangle()
         self.npy_files = [Path(f).with_suffix(".npy") for f in self.im_files]
@@ -150,24 +155,165 @@ class YOLODataset:
     def __len__(self):
         return self.ni
 
-    def draw_augment(self):
+    def _touch(self, i):
+        """The bookkeeping side of the reference's load_image under augmentation (base.py:170-176): an image that is not in the
+        RAM buffer enters it, and the oldest one leaves when the buffer is full."""
+        if i in self._in_buffer:
+            return
+        self._in_buffer.add(i)
+        self.buffer.append(i)
+        if len(self.buffer) >= self.max_buffer_length:
+            self._in_buffer.discard(self.buffer.pop(0))
+
+    def draw_augment(self, index=None):
         """The random decisions of one training sample, drawn from Python's ``random`` in the reference's order (call this in
-        sample order from ONE thread; the pixels can then be produced by any worker).  -> flip bits: 1 = left-right, 2 = up-down."""
+        sample order from ONE thread; pixels and labels can then be produced by any worker).  Returns the flip bits (1 = left-
+        right, 2 = up-down) or, when a geometric augmentation is on, a dict with them plus the mosaic partners / centre and the
+        affine parameters."""
         if not self.augment:
             return 0
-        random.uniform(0, 1)                                  # Mosaic.__call__ probability check   augment.py:105
-        for _ in range(8):                                    # RandomPerspective.affine_transform  :406-425
-            random.uniform(0, 0)
+        aug = None
+        if self.geometric:
+            self._touch(index)                                # get_image_and_label(index) ran before the transforms
+            aug = {"mosaic": None}
+        if random.uniform(0, 1) <= self.mosaic and self.geometric:   # Mosaic.__call__ (augment.py:105): skipped when u > p
+            partners = random.choices(list(self.buffer), k=3)        # get_indexes(buffer=True) :159-162
+            for i in partners:
+                self._touch(i)
+            b = -self.imgsz // 2
+            yc = int(random.uniform(-b, 2 * self.imgsz + b))          # _mosaic4 :212 (y first)
+            xc = int(random.uniform(-b, 2 * self.imgsz + b))
+            aug["mosaic"] = (partners, yc, xc)
+        random.uniform(0, 0), random.uniform(0, 0)            # RandomPerspective.affine_transform :406-407 (perspective = 0)
+        a = random.uniform(-self.degrees, self.degrees)       # :411
+        sc = random.uniform(1 - self.scale, 1 + self.scale)   # :413
+        shx = math.tan(random.uniform(-self.shear, self.shear) * math.pi / 180)   # :419-420
+        shy = math.tan(random.uniform(-self.shear, self.shear) * math.pi / 180)
+        tx = random.uniform(0.5 - self.translate, 0.5 + self.translate)           # :424-425
+        ty = random.uniform(0.5 - self.translate, 0.5 + self.translate)
         random.uniform(0, 1)                                  # MixUp.__call__ probability check    :105
         ud = random.random() < self.flipud                    # RandomFlip(vertical)                :670
         lr = random.random() < self.fliplr                    # RandomFlip(horizontal)              :674
-        return (1 if lr else 0) | (2 if ud else 0)
+        flip = (1 if lr else 0) | (2 if ud else 0)
+        if aug is None:
+            return flip
+        aug.update(flip=flip, affine=(a, sc, shx, shy, tx, ty))
+        return aug
 
     def __getitem__(self, index):
-        return self.get(index, self.draw_augment())
+        return self.get(index, self.draw_augment(index))
+
+    def _hw(self, i):
+        if self.im_hw[i] is None:
+            _, self.im_hw0[i], self.im_hw[i] = self.load_image(i)
+        return self.im_hw[i]
+
+    @staticmethod
+    def _pixel_boxes(lab, w, h, padw, padh):
+        """normalised xywh -> xyxy -> * (w, h) -> + pad, column by column in float32 (Mosaic._update_labels :292-299)."""
+        b = lab["bboxes"].astype(np.float32, copy=True)
+        xy = np.empty_like(b)
+        hw_, hh_ = b[:, 2] / 2, b[:, 3] / 2
+        xy[:, 0], xy[:, 1], xy[:, 2], xy[:, 3] = b[:, 0] - hw_, b[:, 1] - hh_, b[:, 0] + hw_, b[:, 1] + hh_
+        for j, sc in enumerate((w, h, w, h)):
+            xy[:, j] *= sc
+        for j, off in enumerate((padw, padh, padw, padh)):
+            xy[:, j] += off
+        return xy
+
+    def mosaic_layout(self, index, aug):
+        """The four placements of Mosaic._mosaic4 (:208-241) on the (2s x 2s) canvas: per patch (image index, destination
+        x1a, y1a, x2a, y2a, source x1b, y1b)."""
+        partners, yc, xc = aug["mosaic"]
+        s2 = self.imgsz * 2
+        out = []
+        for k, i in enumerate([index, *partners]):
+            h, w = self._hw(i)
+            if k == 0:
+                x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
+                x1b, y1b = w - (x2a - x1a), h - (y2a - y1a)
+            elif k == 1:
+                x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, s2), yc
+                x1b, y1b = 0, h - (y2a - y1a)
+            elif k == 2:
+                x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(s2, yc + h)
+                x1b, y1b = w - (x2a - x1a), 0
+            else:
+                x1a, y1a, x2a, y2a = xc, yc, min(xc + w, s2), min(s2, yc + h)
+                x1b, y1b = 0, 0
+            out.append((i, x1a, y1a, x2a, y2a, x1b, y1b))
+        return out
+
+    def affine_matrix(self, aug, img_w, img_h, size):
+        """RandomPerspective.affine_transform (:384-435) with perspective 0: M = T @ S @ R @ P @ C in float32."""
+        a, sc, shx, shy, tx, ty = aug["affine"]
+        Cm = np.eye(3, dtype=np.float32)
+        Cm[0, 2], Cm[1, 2] = -img_w / 2, -img_h / 2
+        P = np.eye(3, dtype=np.float32)
+        R = np.eye(3, dtype=np.float32)
+        al, be = sc * math.cos(math.radians(a)), sc * math.sin(math.radians(a))  # cv2.getRotationMatrix2D(angle, (0, 0), scale)
+        R[:2] = np.array([[al, be, 0.0], [-be, al, 0.0]])
+        S = np.eye(3, dtype=np.float32)
+        S[0, 1], S[1, 0] = shx, shy
+        T = np.eye(3, dtype=np.float32)
+        T[0, 2], T[1, 2] = tx * size[0], ty * size[1]
+        return T @ S @ R @ P @ Cm
+
+    def _geo_labels(self, index, aug):
+        """Labels through Mosaic / LetterBox and RandomPerspective (:512-560) -> (xyxy in canvas pixels, cls, (W, H), M)."""
+        s = self.imgsz
+        if aug["mosaic"] is not None:
+            parts, clss = [], []
+            for i, x1a, y1a, x2a, y2a, x1b, y1b in self.mosaic_layout(index, aug):
+                h, w = self._hw(i)
+                parts.append(self._pixel_boxes(self.labels[i], w, h, x1a - x1b, y1a - y1b))
+                clss.append(self.labels[i]["cls"])
+            xy, cls = np.concatenate(parts, 0), np.concatenate(clss, 0)
+            xy[:, [0, 2]] = xy[:, [0, 2]].clip(0, 2 * s)       # _cat_labels :318-319: clip to the mosaic, drop empty boxes
+            xy[:, [1, 3]] = xy[:, [1, 3]].clip(0, 2 * s)
+            good = (xy[:, 2] - xy[:, 0]) * (xy[:, 3] - xy[:, 1]) > 0
+            xy, cls = xy[good], cls[good]
+            img_w = img_h = 2 * s
+            border = (-s // 2, -s // 2)
+        else:
+            h, w = self._hw(index)
+            r, new_unpad, (dw, dh), (top, bottom, left, right) = letterbox_geometry((h, w), (s, s), scaleup=True)
+            xy = self._pixel_boxes(self.labels[index], w, h, 0, 0)
+            for j in range(4):
+                xy[:, j] *= r
+            for j, off in enumerate((dw, dh, dw, dh)):
+                xy[:, j] += off
+            cls = self.labels[index]["cls"].copy()
+            img_w, img_h = new_unpad[0] + left + right, new_unpad[1] + top + bottom
+            border = (0, 0)
+        size = (img_w + border[1] * 2, img_h + border[0] * 2)
+        M = self.affine_matrix(aug, img_w, img_h, size)
+        n = len(xy)
+        if n:
+            pts = np.ones((n * 4, 3), dtype=xy.dtype)
+            pts[:, :2] = xy[:, [0, 1, 2, 3, 0, 3, 2, 1]].reshape(n * 4, 2)  # x1y1, x2y2, x1y2, x2y1
+            pts = (pts @ M.T)[:, :2].reshape(n, 8)
+            px, py = pts[:, [0, 2, 4, 6]], pts[:, [1, 3, 5, 7]]
+            new = np.concatenate((px.min(1), py.min(1), px.max(1), py.max(1)), dtype=xy.dtype).reshape(4, n).T
+        else:
+            new = xy
+        new[:, [0, 2]] = new[:, [0, 2]].clip(0, size[0])
+        new[:, [1, 3]] = new[:, [1, 3]].clip(0, size[1])
+        sc = aug["affine"][1]
+        for j in range(4):
+            xy[:, j] *= sc                                       # instances.scale(scale, scale, bbox_only=True) :551
+        w1, h1 = xy[:, 2] - xy[:, 0], xy[:, 3] - xy[:, 1]
+        w2, h2 = new[:, 2] - new[:, 0], new[:, 3] - new[:, 1]
+        eps = np.float32(1e-16)
+        ar = np.maximum(w2 / (h2 + eps), h2 / (w2 + eps))
+        keep = (w2 > 2) & (h2 > 2) & (w2 * h2 / (w1 * h1 + eps) > np.float32(0.1)) & (ar < 100)
+        return new[keep], cls[keep], size, M
 
     def get(self, index, flip=0, pixels=True):
-        """One sample; ``pixels=False`` builds the labels only (the image already sits in the loader's HBM pool)."""
+        """One sample; ``pixels=False`` builds the labels only (the image already sits in the loader's HBM pool).  ``flip``: the
+        value ``draw_augment`` returned (flip bits, or the dict of a geometric augmentation)."""
+        if isinstance(flip, dict):
+            return self._get_geometric(index, flip, pixels)
         lab = self.labels[index]
         if pixels or self.im_hw[index] is None:
             im, ori_shape, resized = self.load_image(index)
@@ -233,6 +379,56 @@ class YOLODataset:
             s["flip"] = flip  # pixels are delivered unflipped: dy_import_image_u8 mirrors them while converting
         return s
 
+    def warp_slot(self, index, aug, M):
+        """The 40-word record dy_warp_import_u8 reads for this sample (see include/dealyolo_hip.h): inverse affine map, canvas,
+        mosaic centre, flip bits, up to four (pool image, destination rectangle, source corner) patches.  Pool images are the
+        letterboxed s x s canvases the loader uploaded, so a patch's source corner is shifted by that image's letterbox pad."""
+        s = self.imgsz
+        rec = np.zeros(40, dtype=np.int32)
+        minv = np.linalg.inv(M.astype(np.float64))[:2].astype(np.float32)  # cv2.warpAffine inverts the forward map
+        rec[:6] = minv.reshape(-1).view(np.int32)
+
+        def pad_of(i):
+            h, w = self._hw(i)
+            _, _, _, (top, _, left, _) = letterbox_geometry((h, w), (s, s), scaleup=True)
+            return left, top
+
+        if aug["mosaic"] is not None:
+            _, yc, xc = aug["mosaic"]
+            rec[6:12] = (2 * s, 2 * s, xc, yc, aug["flip"], 4)
+            for k, (i, x1a, y1a, x2a, y2a, x1b, y1b) in enumerate(self.mosaic_layout(index, aug)):
+                left, top = pad_of(i)
+                rec[12 + 7 * k:19 + 7 * k] = (i, x1a, y1a, x2a, y2a, x1b + left, y1b + top)
+        else:
+            rec[6:12] = (s, s, s, s, aug["flip"], 1)
+            rec[12:19] = (index, 0, 0, s, s, 0, 0)
+        return rec
+
+    def _get_geometric(self, index, aug, pixels):
+        """Mosaic / affine sample: labels on the host; the pixels of this path are composed on the device from the loader's HBM
+        pool (the reference warps with cv2), so only ``pixels=False`` is served here."""
+        if pixels:
+            raise NotImplementedError("mosaic / affine pixels are composed on the device from the HBM image pool (cache='hbm')")
+        lab = self.labels[index]
+        xy, cls, (W, H), M = self._geo_labels(index, aug)
+        flip = aug["flip"]
+        out = np.empty_like(xy)
+        out[:, 0], out[:, 1] = (xy[:, 0] + xy[:, 2]) / 2, (xy[:, 1] + xy[:, 3]) / 2
+        out[:, 2], out[:, 3] = xy[:, 2] - xy[:, 0], xy[:, 3] - xy[:, 1]
+        if flip & 2:
+            out[:, 1] = H - out[:, 1]
+        if flip & 1:
+            out[:, 0] = W - out[:, 0]
+        for j, sc in enumerate((1 / W, 1 / H, 1 / W, 1 / H)):
+            out[:, j] *= sc
+        nl = len(out)
+        s = dict(im_file=lab["im_file"], ori_shape=self.im_hw0[index], resized_shape=(H, W))
+        s["cls"] = torch.from_numpy(cls) if nl else torch.zeros(nl)
+        s["bboxes"] = torch.from_numpy(out) if nl else torch.zeros((nl, 4))
+        s["batch_idx"] = torch.zeros(nl)
+        s["warp"] = torch.from_numpy(self.warp_slot(index, aug, M))
+        return s
+
     @staticmethod
     def collate_fn(batch):
         """dataset.py:207-224."""
@@ -243,6 +439,8 @@ class YOLODataset:
                 value = torch.stack(value, 0)
             if k == "flip":
                 value = torch.tensor(value, dtype=torch.uint8)
+            if k == "warp":
+                value = torch.stack(value, 0)
             if k in ("bboxes", "cls"):
                 value = torch.cat([v.reshape(-1, 4 if k == "bboxes" else 1) if v.numel() == 0 else v for v in value], 0)
             new[k] = value

@@ -316,6 +316,17 @@ class Engine:
                   0 if index is None else index.data_ptr())
         return out
 
+    def import_warp(self, pool, slots, cp=8):
+        """Mosaic + affine + flips composed from the HBM image pool into the fp16 NHWC stem input (dy_warp_import_u8);
+        ``slots``: (N, 40) int32 device tensor of per-sample records (YOLODataset.warp_slot)."""
+        assert pool.dtype == torch.uint8 and pool.is_contiguous() and pool.shape[1] == pool.shape[2] and pool.shape[3] == 3
+        assert slots.dtype == torch.int32 and slots.is_contiguous() and slots.shape[1] * 4 == lib().dy_warp_slot_bytes()
+        N, S = slots.shape[0], pool.shape[1]
+        out = self.new_act(N, S, S, cp)
+        out.needs_grad = False
+        self.call("dy_warp_import_u8", pool.data_ptr(), slots.data_ptr(), out.ptr, N, S, cp)
+        return out
+
     def _conv_raw(self, spec, x, y_ptr, ldy, epi, partials_ptr=0, bias=None):
         self.call("dy_conv_forward", x.ptr, x.ld, spec.wpack.data_ptr(), _ptr(bias), y_ptr, ldy, partials_ptr, x.N, x.H, x.W,
                   x.C, spec.cout, spec.ks, spec.stride, 1, 0, 0, epi, None)

@@ -50,6 +50,7 @@ class StepPlan:
         self.input_u8 = False  # decided by the first batch: uint8 NHWC (the loader's format) or float NCHW (the public tensor API)
         self.flip = None       # (B,) uint8 flip bits when the first loader batch carries them (flips folded into the import kernel)
         self.pool = self.index = None  # HBM-resident image pool + (B,) int32 slots when the loader keeps the dataset on the device
+        self.warp = None               # (B,40) int32 mosaic/affine records: the pool is then read through dy_warp_import_u8
         self.rec_fb = None
         self.rec_opt, self.graph_opt = {}, {}
         self.graph_fb = None
@@ -76,7 +77,9 @@ class StepPlan:
         eng.training = True
         try:
             rt.pack_all(transposed=True)
-            if self.pool is not None:
+            if self.warp is not None:
+                x = eng.import_warp(self.pool, self.warp, 8)
+            elif self.pool is not None:
                 x = eng.import_image_u8(self.pool, 8, self.flip, self.index)
             else:
                 x = eng.import_image_u8(self.img, 8, self.flip) if self.input_u8 else eng.import_image(self.img, 8)
@@ -100,13 +103,17 @@ class StepPlan:
         """Stage the batch, run fwd+loss+bwd; gradients (scaled by the loss scale) land in rt.flat_g."""
         img = batch["img"]
         u8 = img.dtype == torch.uint8 and img.dim() == 4 and img.shape[-1] == 3 and img.shape[1] != 3  # (B,H,W,3)
-        if self.rec_fb is None and u8 and "index" in batch:  # img is the loader's HBM-resident pool: recorded by pointer
+        if self.rec_fb is None and u8 and ("index" in batch or "warp" in batch):  # img is the loader's HBM pool: recorded by pointer
             self.pool, self.input_u8 = img, True
-            self.index = torch.zeros(self.B, dtype=torch.int32, device=img.device)
+            if "warp" in batch:
+                self.warp = torch.zeros((self.B, batch["warp"].shape[1]), dtype=torch.int32, device=img.device)
+            else:
+                self.index = torch.zeros(self.B, dtype=torch.int32, device=img.device)
         if self.pool is not None:
-            if "index" not in batch or img.data_ptr() != self.pool.data_ptr():
-                raise KeyError("this plan was recorded for batches indexing one HBM-resident image pool")
-            self.index.copy_(batch["index"], non_blocking=True)
+            key = "warp" if self.warp is not None else "index"
+            if key not in batch or img.data_ptr() != self.pool.data_ptr():
+                raise KeyError(f"this plan was recorded for batches carrying '{key}' records over one HBM-resident image pool")
+            (self.warp if self.warp is not None else self.index).copy_(batch[key], non_blocking=True)
             img = self.img  # nothing to stage
         if self.rec_fb is None and u8 and self.pool is None:
             self.input_u8 = True

@@ -136,6 +136,12 @@ int dy_import_image(const float* x_nchw, void* y, int n, int c, int h, int w, in
  * or n ints -- batch slot i reads image index[i] of x, a pool of decoded images resident in HBM (no per-step host copy). */
 int dy_import_image_u8(const void* x, void* y, int n, int h, int w, int cp, const void* flip, const int* index,
                        hipStream_t stream);
+/* Mosaic (data/augment.py:208-241) + random affine (cv2.warpAffine of RandomPerspective :384-435, border 114) + flips, composed
+ * from an HBM-resident pool of letterboxed s x s uint8 images straight into the fp16 NHWC stem input.  slots: n records of
+ * dy_warp_slot_bytes() bytes = { float minv[6] (output pixel -> canvas); int canvas_w, canvas_h, xc, yc, flip, npatch;
+ * int patch[4][7] = pool index, destination x1,y1,x2,y2 on the canvas, source x,y } built on the host from the random draws. */
+int dy_warp_import_u8(const void* pool, const void* slots, void* y, int n, int s, int cp, hipStream_t stream);
+int dy_warp_slot_bytes(void);
 int dy_add(const void* a, int lda, const void* b, int ldb, const void* c, int ldc, void* y, int ldy, long npix, int C,
            hipStream_t stream);
 int dy_upsample2x(const void* x, int ldx, void* y, int ldy, int n, int h, int w, int C, int backward, int accumulate,

@@ -617,6 +617,21 @@ def gen_data():
     for ep in range(2):
         for i, batch in enumerate(loader):
             put(f"flip/e{ep}/b{i}", batch)
+    # the full geometric pipeline: mosaic + random affine + flips.  Labels only (cv2.warpAffine is absent: the stand-in returns a
+    # grey canvas of the requested size, so pixels of this section are not part of the fixture)
+    def grey_warp(img, M, dsize=None, borderValue=(114, 114, 114), **k):
+        return np.full((dsize[1], dsize[0], 3), 114, np.uint8)
+
+    cv2.warpAffine = grey_warp
+    geo = {**zero, "mosaic": 1.0, "degrees": 5.0, "translate": 0.1, "scale": 0.5, "shear": 2.0, "fliplr": 0.5, "flipud": 0.1}
+    cfg_g = get_cfg(DEFAULT_CFG, overrides=dict(imgsz=DATASET_IMGSZ, task="detect", **geo))
+    ds = build_yolo_dataset(cfg_g, os.path.join(root, "images", "train"), 4, data, mode="train")
+    loader = build_dataloader(ds, 4, 0, shuffle=True, rank=-1)
+    random.seed(11)
+    for ep in range(3):
+        for i, batch in enumerate(loader):
+            put(f"geo/e{ep}/b{i}", batch)
+            del arrs[f"geo/e{ep}/b{i}/img"]
     ds = build_yolo_dataset(cfg, os.path.join(root, "images", "val"), 4, data, mode="val", rect=True, stride=32)
     loader = build_dataloader(ds, 4, 0, shuffle=False, rank=-1)
     arrs["val/nb"] = len(loader)

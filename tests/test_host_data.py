@@ -23,10 +23,10 @@ def root(tmp_path_factory):
     return r
 
 
-def _loader(root, mode, layout="nchw", fliplr=0.0, flipud=0.0, **kw):
+def _loader(root, mode, layout="nchw", fliplr=0.0, flipud=0.0, geo=None, **kw):
     from ultralytics.data import build_dataloader, build_yolo_dataset, check_det_dataset
     data = check_det_dataset(os.path.join(root, "data.yaml"))
-    cfg = SimpleNamespace(imgsz=DATASET_IMGSZ, rect=False, cache=False, fraction=1.0, fliplr=fliplr, flipud=flipud)
+    cfg = SimpleNamespace(imgsz=DATASET_IMGSZ, rect=False, cache=False, fraction=1.0, fliplr=fliplr, flipud=flipud, **(geo or {}))
     ds = build_yolo_dataset(cfg, data[mode], 4, data, mode=mode, rect=mode == "val", stride=32, layout=layout)
     return build_dataloader(ds, 4, 2, shuffle=mode == "train", rank=-1, **kw)
 
@@ -67,6 +67,31 @@ def test_flipped_batches_identical_to_reference(root):
             _check(G, f"flip/e{ep}/b{i}", batch)
             flipped += int(not torch.equal(batch["img"], torch.from_numpy(G[f"train/e{ep}/b{i}/img"])))
     assert flipped >= 3  # the fixture does contain flipped batches
+
+
+def test_mosaic_affine_flip_labels_identical_to_reference(root):
+    """mosaic 1.0, degrees 5, translate 0.1, scale 0.5, shear 2, fliplr 0.5, flipud 0.1 -- the whole geometric pipeline of the
+    reference (Mosaic partners drawn from its image buffer, mosaic centre, affine matrix, box transform, clipping, candidate
+    filter, flips) reproduced label for label over three epochs; Python's ``random`` seeded as in the reference run."""
+    import random
+    G = np.load(GOLD)
+    loader = _loader(root, "train", geo=dict(mosaic=1.0, degrees=5.0, translate=0.1, scale=0.5, shear=2.0), fliplr=0.5, flipud=0.1)
+    ds = loader.dataset
+    random.seed(11)
+    n_boxes = 0
+    for ep in range(3):
+        idx = loader._indices()
+        for i in range(len(loader)):
+            chunk = idx[i * 4:(i + 1) * 4]
+            augs = [ds.draw_augment(j) for j in chunk]
+            batch = ds.collate_fn([ds.get(j, a, pixels=False) for j, a in zip(chunk, augs)])
+            tag = f"geo/e{ep}/b{i}"
+            assert [os.path.basename(f) for f in batch["im_file"]] == list(G[f"{tag}/files"]), tag
+            for k in ("cls", "bboxes", "batch_idx"):
+                ref = torch.from_numpy(G[f"{tag}/{k}"])
+                assert batch[k].shape == ref.shape and torch.equal(batch[k], ref), (tag, k, batch[k][:6], ref[:6])
+            n_boxes += len(batch["cls"])
+    assert n_boxes > 50
 
 
 def test_val_rect_batches_identical_to_reference(root):

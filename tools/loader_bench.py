@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """PCIe-inclusive training rate: DEAL-YOLO-N 640x640 bs=64 fed by ultralytics.data.HipDataLoader from a YOLO-format dataset
 on local disk (uint8 NHWC pinned batches, H2D on a copy stream one batch ahead) next to the same step with the batch
-resident in HBM.  Usage: loader_bench.py [n_images=512] [steps=60] [cache=ram|disk|hbm]"""
+resident in HBM.  Usage: loader_bench.py [n_images=512] [steps=60] [cache=ram|disk|hbm] [aug=0|1]   (aug=1 with hbm: mosaic 1.0,
+degrees 5, translate 0.1, scale 0.5, shear 2, fliplr 0.5 composed on the device)"""
 import os
 import sys
 import tempfile
@@ -21,6 +22,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 MODE = sys.argv[3] if len(sys.argv) > 3 else "ram"
 CACHE = {"ram": True, "disk": False, "hbm": "hbm"}[MODE]
+AUG = len(sys.argv) > 4 and sys.argv[4] == "1"
 B, S = 64, 640
 root = tempfile.mkdtemp(prefix="dy_loader_bench_")
 os.makedirs(os.path.join(root, "images", "train"))
@@ -43,7 +45,7 @@ print(f"dataset: {N} images written in {time.time() - t0:.1f} s", flush=True)
 
 data = check_det_dataset(os.path.join(root, "data.yaml"))
 dev = torch.device("cuda", 0)
-cfg = SimpleNamespace(imgsz=S, cache=CACHE, fraction=1.0, rect=False)
+cfg = SimpleNamespace(imgsz=S, cache=CACHE, fraction=1.0, rect=False, **(dict(mosaic=1.0, degrees=5.0, translate=0.1, scale=0.5, shear=2.0, fliplr=0.5) if AUG else {}))
 ds = build_yolo_dataset(cfg, data["train"], B, data, mode="train", flip_on_device=True)
 loader = build_dataloader(ds, B, 14, shuffle=True, device=dev, drop_last=True)
 
@@ -54,11 +56,12 @@ for ep in range(max(1, STEPS // len(loader))):
         nb += 1
 torch.cuda.synchronize()
 dt = time.time() - t0
-print(f"loader alone ({MODE}): {nb * B / dt:.0f} images/s ({dt / nb * 1e3:.2f} ms/batch, 14 threads)", flush=True)
+TAG = MODE + (", device-side mosaic + affine + flips" if AUG else "")
+print(f"loader alone ({TAG}): {nb * B / dt:.0f} images/s ({dt / nb * 1e3:.2f} ms/batch, 14 threads)", flush=True)
 
 torch.manual_seed(0)
 model = DetectionModel("yolov8n-ASF-P2P2.yaml", verbose=False).to(dev).train()
-plan = StepPlan(model, B, S, nmax=8, optimizer="SGD", use_graph=True)
+plan = StepPlan(model, B, S, nmax=64 if AUG else 8, optimizer="SGD", use_graph=True)  # a mosaic carries the boxes of four images
 
 
 def step(batch):
