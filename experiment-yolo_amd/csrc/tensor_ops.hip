@@ -66,13 +66,51 @@ __global__ __launch_bounds__(256) void import_image_u8_kernel(const unsigned cha
     for (int c0 = 8; c0 < Cp; c0 += 8) *reinterpret_cast<half8*>(y + pix * Cp + c0) = half8{};
   }
 }
+// RandomHSV (data/augment.py:605-624) on one 8-bit RGB pixel: to 8-bit HSV (H in [0,180), OpenCV's convention: V = max,
+// S = 255*(V-min)/V, H = 30*sector formula, each rounded to nearest), the three look-up tables hue' = (H*r0) mod 180,
+// sat' = min(S*r1, 255), val' = min(V*r2, 255) with numpy's truncating uint8 cast, and back.  OpenCV evaluates both conversions
+// in fixed point / float with its own rounding, so values can differ from the reference's by an LSB or two (not pinned).
+static __device__ __forceinline__ void hsv_jitter(float (&c)[3], float r0, float r1, float r2) {
+  const float R = c[0], G = c[1], B = c[2];
+  const float V = fmaxf(R, fmaxf(G, B)), mn = fminf(R, fminf(G, B)), d = V - mn;
+  float H = 0.f;
+  if (d > 0.f) {
+    if (V == R) H = (G - B) / d;
+    else if (V == G) H = 2.f + (B - R) / d;
+    else H = 4.f + (R - G) / d;
+    H *= 30.f;
+    if (H < 0.f) H += 180.f;
+  }
+  float h8 = rintf(H);
+  if (h8 >= 180.f) h8 -= 180.f;
+  const float s8 = V > 0.f ? rintf(255.f * d / V) : 0.f;
+  const float hh = floorf(fmodf(h8 * r0, 180.f)), ss = floorf(fminf(s8 * r1, 255.f)), vv = floorf(fminf(V * r2, 255.f));
+  // HSV -> RGB (sector form), hue in degrees = 2*hh
+  const float hs = hh / 30.f, sf = ss / 255.f;
+  const int sec = (int)floorf(hs) % 6;
+  const float f = hs - floorf(hs);
+  const float p = vv * (1.f - sf), q = vv * (1.f - sf * f), t = vv * (1.f - sf * (1.f - f));
+  float r, g, b;
+  switch (sec) {
+    case 0: r = vv; g = t; b = p; break;
+    case 1: r = q; g = vv; b = p; break;
+    case 2: r = p; g = vv; b = t; break;
+    case 3: r = p; g = q; b = vv; break;
+    case 4: r = t; g = p; b = vv; break;
+    default: r = vv; g = p; b = q; break;
+  }
+  c[0] = fminf(fmaxf(rintf(r), 0.f), 255.f);
+  c[1] = fminf(fmaxf(rintf(g), 0.f), 255.f);
+  c[2] = fminf(fmaxf(rintf(b), 0.f), 255.f);
+}
+
 // The same conversion with the two flip augmentations folded in (RandomFlip, data/augment.py:651-683): flip[n] bit 0 mirrors
 // image n left-right, bit 1 up-down -- the loader ships the pixels as decoded and this kernel reads them mirrored, so a flip
 // costs no pass over the image anywhere.  index (optional): batch slot n reads image index[n] of x, which then is a pool of
 // decoded images resident in HBM (a 100k-image 640x640 dataset is 123 GB of the 288): the step's input costs one gather-read.
 // One output pixel per thread (mirrored quads would straddle the 12-byte groups).
 __global__ __launch_bounds__(256) void import_image_u8_flip_kernel(const unsigned char* x, f16* y, int N, int H, int W, int Cp,
-                                                                   const unsigned char* flip, const int* index) {
+                                                                   const unsigned char* flip, const int* index, const float* hsv) {
   const long hw = (long)H * W, npix = hw * N;
   for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
     const int n = (int)(pix / hw);
@@ -83,21 +121,23 @@ __global__ __launch_bounds__(256) void import_image_u8_flip_kernel(const unsigne
     if (f & 2) yy = H - 1 - yy;
     const long src = index ? (long)index[n] : (long)n;
     const unsigned char* p = x + (src * hw + (long)yy * W + xx) * 3;
+    float c[3] = {(float)p[0], (float)p[1], (float)p[2]};
+    if (hsv) hsv_jitter(c, hsv[n * 3], hsv[n * 3 + 1], hsv[n * 3 + 2]);
     half8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = j < 3 ? (f16)((float)p[j] / 255.f) : (f16)0.f;
+    for (int j = 0; j < 8; ++j) v[j] = j < 3 ? (f16)(c[j] / 255.f) : (f16)0.f;
     *reinterpret_cast<half8*>(y + pix * Cp) = v;
     for (int c0 = 8; c0 < Cp; c0 += 8) *reinterpret_cast<half8*>(y + pix * Cp + c0) = half8{};
   }
 }
 extern "C" int dy_import_image_u8(const void* x, void* y, int n, int h, int w, int cp, const void* flip, const int* index,
-                                  hipStream_t stream) {
+                                  const float* hsv, hipStream_t stream) {
   if ((cp & 7) || cp < 8) return DY_ERR_ALIGN;
   if ((uintptr_t)x & 3) return DY_ERR_ALIGN;
   const long npix = (long)n * h * w;
-  if (flip || index)
+  if (flip || index || hsv)
     hipLaunchKernelGGL(import_image_u8_flip_kernel, dim3(grid_for(npix)), dim3(256), 0, stream, (const unsigned char*)x, (f16*)y, n, h, w, cp,
-                       (const unsigned char*)flip, index);
+                       (const unsigned char*)flip, index, hsv);
   else hipLaunchKernelGGL(import_image_u8_kernel, dim3(grid_for((npix + 3) / 4)), dim3(256), 0, stream, (const unsigned char*)x, (f16*)y, npix, cp);
   DY_CHECK_LAUNCH();
   return DY_OK;
@@ -116,6 +156,8 @@ struct WarpSlot {
   int canvas_w, canvas_h, xc, yc;  // mosaic centre: patch k = (u >= xc) + 2*(v >= yc); single image: xc = yc = canvas size
   int flip, npatch;
   int patch[4][7];                 // pool index, x1a, y1a, x2a, y2a (destination, exclusive ends), source x, y of the rectangle's corner
+  float hsv[3];                    // RandomHSV gains (hue, saturation, value multipliers); hsv[0] == 0: off
+  int pad_;
 };
 
 static __device__ __forceinline__ void warp_fetch(const unsigned char* pool, const WarpSlot& w, int S, int cx, int cy, float (&v)[3]) {
@@ -152,11 +194,15 @@ __global__ __launch_bounds__(256) void warp_import_kernel(const unsigned char* p
     half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+    float px[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float top = c00[c] * (1.f - ax) + c01[c] * ax, bot = c10[c] * (1.f - ax) + c11[c] * ax;
-      o[c] = (f16)(fminf(fmaxf(rintf(top * (1.f - ay) + bot * ay), 0.f), 255.f) / 255.f);
+      px[c] = fminf(fmaxf(rintf(top * (1.f - ay) + bot * ay), 0.f), 255.f);
     }
+    if (w.hsv[0] != 0.f) hsv_jitter(px, w.hsv[0], w.hsv[1], w.hsv[2]);  // RandomHSV follows the warp in the reference too
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (f16)(px[c] / 255.f);
     *reinterpret_cast<half8*>(y + pix * Cp) = o;
     for (int c0 = 8; c0 < Cp; c0 += 8) *reinterpret_cast<half8*>(y + pix * Cp + c0) = half8{};
   }

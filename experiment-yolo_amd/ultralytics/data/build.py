@@ -30,7 +30,7 @@ AUGMENT_KEYS = ("mosaic", "mixup", "copy_paste", "hsv_h", "hsv_s", "hsv_v", "deg
 
 
 def build_yolo_dataset(cfg, img_path, batch, data, mode="train", rect=False, stride=32, layout="nhwc", flip_on_device=False):
-    flips = {k: float(getattr(cfg, k, 0.0) or 0.0) for k in ("flipud", "fliplr", "mosaic", "degrees", "translate", "scale", "shear")} if mode == "train" else {}
+    flips = {k: float(getattr(cfg, k, 0.0) or 0.0) for k in ("flipud", "fliplr", "mosaic", "degrees", "translate", "scale", "shear", "hsv_h", "hsv_s", "hsv_v")} if mode == "train" else {}
     return YOLODataset(img_path=img_path, imgsz=cfg.imgsz, batch_size=batch, augment=mode == "train", flip_on_device=flip_on_device, **flips,
                        rect=bool(getattr(cfg, "rect", False)) or rect, stride=int(stride), pad=0.0 if mode == "train" else 0.5,
                        data=data, fraction=getattr(cfg, "fraction", 1.0) if mode == "train" else 1.0,
@@ -118,6 +118,8 @@ class HipDataLoader:
         else:
             batch["index"] = torch.tensor(idx, dtype=torch.int32).to(self.device, non_blocking=True)
             batch["flip"] = batch["flip"].to(self.device, non_blocking=True)
+            if "hsv" in batch:
+                batch["hsv"] = batch["hsv"].to(self.device, non_blocking=True)
         return batch
 
     def _assemble(self, pool, idx, slot):
@@ -159,6 +161,8 @@ class HipDataLoader:
         batch["img"] = buf
         if "flip" in batch and self.device is not None:
             batch["flip"] = batch["flip"].to(self.device, non_blocking=True)
+        if "hsv" in batch and self.device is not None:
+            batch["hsv"] = batch["hsv"].to(self.device, non_blocking=True)
         if self.device is not None:
             with torch.cuda.stream(self._copy_stream):
                 batch["img"] = buf.to(self.device, non_blocking=True)

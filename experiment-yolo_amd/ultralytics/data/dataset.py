@@ -54,11 +54,12 @@ def letterbox_geometry(shape, new_shape, scaleup):
 class YOLODataset:
     def __init__(self, img_path, imgsz=640, batch_size=16, augment=False, rect=False, stride=32, pad=0.0, data=None, fraction=1.0,
                  cache=False, layout="nhwc", prefix="", flipud=0.0, fliplr=0.0, flip_on_device=False, mosaic=0.0, degrees=0.0,
-                 translate=0.0, scale=0.0, shear=0.0):
+                 translate=0.0, scale=0.0, shear=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0):
         self.img_path, self.imgsz, self.batch_size, self.augment, self.rect = img_path, int(imgsz), batch_size, augment, rect
         self.flipud, self.fliplr, self.flip_on_device = float(flipud), float(fliplr), flip_on_device
         self.mosaic, self.degrees, self.translate, self.scale, self.shear = (float(v) for v in (mosaic, degrees, translate, scale, shear))
         self.geometric = augment and any((self.mosaic, self.degrees, self.translate, self.scale, self.shear))
+        self.hsv = (float(hsv_h), float(hsv_s), float(hsv_v)) if augment and any((hsv_h, hsv_s, hsv_v)) else None
         self.buffer, self._in_buffer = [], set()  # BaseDataset.buffer (base.py:86-87, :170-176): what Mosaic draws its partners from
         self.stride, self.pad, self.data, self.fraction, self.layout, self.prefix = stride, pad, data or {}, fraction, layout, prefix
         self.im_files = self.get_img_files(img_path)
@@ -192,12 +193,18 @@ class YOLODataset:
         tx = random.uniform(0.5 - self.translate, 0.5 + self.translate)           # :424-425
         ty = random.uniform(0.5 - self.translate, 0.5 + self.translate)
         random.uniform(0, 1)                                  # MixUp.__call__ probability check    :105
+        gains = None
+        if self.hsv is not None:                              # RandomHSV :613 -- numpy's global RNG, three draws per sample
+            gains = (np.random.uniform(-1, 1, 3) * self.hsv + 1).astype(np.float32)
         ud = random.random() < self.flipud                    # RandomFlip(vertical)                :670
         lr = random.random() < self.fliplr                    # RandomFlip(horizontal)              :674
         flip = (1 if lr else 0) | (2 if ud else 0)
-        if aug is None:
+        if aug is None and gains is None:
             return flip
-        aug.update(flip=flip, affine=(a, sc, shx, shy, tx, ty))
+        aug = aug if aug is not None else {}
+        aug.update(flip=flip, hsv=gains)
+        if self.geometric:
+            aug["affine"] = (a, sc, shx, shy, tx, ty)
         return aug
 
     def __getitem__(self, index):
@@ -312,8 +319,13 @@ class YOLODataset:
     def get(self, index, flip=0, pixels=True):
         """One sample; ``pixels=False`` builds the labels only (the image already sits in the loader's HBM pool).  ``flip``: the
         value ``draw_augment`` returned (flip bits, or the dict of a geometric augmentation)."""
+        gains = None
         if isinstance(flip, dict):
-            return self._get_geometric(index, flip, pixels)
+            if "affine" in flip:
+                return self._get_geometric(index, flip, pixels)
+            flip, gains = flip["flip"], flip["hsv"]  # colour jitter (+ flips) only
+            if gains is not None and not self.flip_on_device:
+                raise NotImplementedError("HSV jitter is applied inside the device import kernels (flip_on_device loaders)")
         lab = self.labels[index]
         if pixels or self.im_hw[index] is None:
             im, ori_shape, resized = self.load_image(index)
@@ -377,14 +389,18 @@ class YOLODataset:
         s["batch_idx"] = torch.zeros(nl)
         if self.flip_on_device:
             s["flip"] = flip  # pixels are delivered unflipped: dy_import_image_u8 mirrors them while converting
+            if self.hsv is not None:
+                s["hsv"] = torch.from_numpy(gains if gains is not None else np.ones(3, np.float32))
         return s
 
     def warp_slot(self, index, aug, M):
-        """The 40-word record dy_warp_import_u8 reads for this sample (see include/dealyolo_hip.h): inverse affine map, canvas,
+        """The 44-word record dy_warp_import_u8 reads for this sample (see include/dealyolo_hip.h): inverse affine map, canvas,
         mosaic centre, flip bits, up to four (pool image, destination rectangle, source corner) patches.  Pool images are the
         letterboxed s x s canvases the loader uploaded, so a patch's source corner is shifted by that image's letterbox pad."""
         s = self.imgsz
-        rec = np.zeros(40, dtype=np.int32)
+        rec = np.zeros(44, dtype=np.int32)
+        if aug.get("hsv") is not None:
+            rec[40:43] = np.asarray(aug["hsv"], np.float32).view(np.int32)
         minv = np.linalg.inv(M.astype(np.float64))[:2].astype(np.float32)  # cv2.warpAffine inverts the forward map
         rec[:6] = minv.reshape(-1).view(np.int32)
 
@@ -439,7 +455,7 @@ class YOLODataset:
                 value = torch.stack(value, 0)
             if k == "flip":
                 value = torch.tensor(value, dtype=torch.uint8)
-            if k == "warp":
+            if k in ("warp", "hsv"):
                 value = torch.stack(value, 0)
             if k in ("bboxes", "cls"):
                 value = torch.cat([v.reshape(-1, 4 if k == "bboxes" else 1) if v.numel() == 0 else v for v in value], 0)

@@ -67,7 +67,7 @@ SIGNATURES = {
     "dy_nms_hard": (i32, [vp, vp, vp, i32, C.c_float, vp, vp]),
     "dy_warp_import_u8": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "dy_warp_slot_bytes": (i32, []),
-    "dy_import_image_u8": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "dy_import_image_u8": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "dy_add": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]),
     "dy_upsample2x": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_maxpool5": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),

@@ -303,17 +303,18 @@ class Engine:
         self.call("dy_import_image", img.data_ptr(), out.ptr, N, Cc, H, W, cp, float(mul))
         return out
 
-    def import_image_u8(self, img, cp=8, flip=None, index=None):
+    def import_image_u8(self, img, cp=8, flip=None, index=None, hsv=None):
         """NHWC uint8 RGB image batch (the loader's format) -> NHWC fp16 Act, value/255, channels zero-padded to ``cp``;
         ``flip``: (N,) uint8 device tensor of flip bits (1 = left-right, 2 = up-down) applied while converting;
-        ``index``: (N,) int32 device tensor -- ``img`` then is a pool of images and slot i reads ``img[index[i]]``."""
+        ``index``: (N,) int32 device tensor -- ``img`` then is a pool of images and slot i reads ``img[index[i]]``;
+        ``hsv``: (N,3) float32 device tensor of RandomHSV gains."""
         N = img.shape[0] if index is None else index.shape[0]
         _, H, W, Cc = img.shape
         assert img.dtype == torch.uint8 and img.is_contiguous() and Cc == 3
         out = self.new_act(N, H, W, cp)
         out.needs_grad = False
         self.call("dy_import_image_u8", img.data_ptr(), out.ptr, N, H, W, cp, 0 if flip is None else flip.data_ptr(),
-                  0 if index is None else index.data_ptr())
+                  0 if index is None else index.data_ptr(), 0 if hsv is None else hsv.data_ptr())
         return out
 
     def import_warp(self, pool, slots, cp=8):

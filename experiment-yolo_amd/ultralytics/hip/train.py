@@ -50,7 +50,8 @@ class StepPlan:
         self.input_u8 = False  # decided by the first batch: uint8 NHWC (the loader's format) or float NCHW (the public tensor API)
         self.flip = None       # (B,) uint8 flip bits when the first loader batch carries them (flips folded into the import kernel)
         self.pool = self.index = None  # HBM-resident image pool + (B,) int32 slots when the loader keeps the dataset on the device
-        self.warp = None               # (B,40) int32 mosaic/affine records: the pool is then read through dy_warp_import_u8
+        self.warp = None               # (B,44) int32 mosaic/affine records: the pool is then read through dy_warp_import_u8
+        self.hsv = None                # (B,3) float32 RandomHSV gains applied inside dy_import_image_u8
         self.rec_fb = None
         self.rec_opt, self.graph_opt = {}, {}
         self.graph_fb = None
@@ -80,9 +81,9 @@ class StepPlan:
             if self.warp is not None:
                 x = eng.import_warp(self.pool, self.warp, 8)
             elif self.pool is not None:
-                x = eng.import_image_u8(self.pool, 8, self.flip, self.index)
+                x = eng.import_image_u8(self.pool, 8, self.flip, self.index, self.hsv)
             else:
-                x = eng.import_image_u8(self.img, 8, self.flip) if self.input_u8 else eng.import_image(self.img, 8)
+                x = eng.import_image_u8(self.img, 8, self.flip, None, self.hsv) if self.input_u8 else eng.import_image(self.img, 8)
             ho = model.forward_act(x)
             crit.bind(ho, self.nmax, gscale=self.state[0:1])
             crit.sync_modes()
@@ -120,6 +121,10 @@ class StepPlan:
             self.img = torch.zeros((self.B, *self.imgsz, 3), dtype=torch.uint8, device=self.img.device)
         if self.rec_fb is None and u8 and "flip" in batch:
             self.flip = torch.zeros(self.B, dtype=torch.uint8, device=self.img.device)
+        if self.rec_fb is None and u8 and "hsv" in batch and "warp" not in batch:
+            self.hsv = torch.ones((self.B, 3), dtype=torch.float32, device=self.img.device)
+        if self.hsv is not None:
+            self.hsv.copy_(batch["hsv"], non_blocking=True)
         if self.flip is not None:
             if "flip" not in batch:
                 raise KeyError("this plan was recorded for batches carrying 'flip' bits (loader with flip_on_device)")

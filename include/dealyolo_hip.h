@@ -133,13 +133,15 @@ int dy_import_image(const float* x_nchw, void* y, int n, int c, int h, int w, in
 /* The loader's batch: uint8 NHWC RGB (n,h,w,3), 4-byte aligned -> fp16 NHWC with channels zero-padded to cp, value u8/255
  * (models/yolo/detect/train.py:59 `batch["img"].float() / 255`).  flip: NULL, or n bytes -- bit 0 mirrors image i left-right,
  * bit 1 up-down while converting (RandomFlip, data/augment.py:651-683; the loader then ships unflipped pixels).  index: NULL,
- * or n ints -- batch slot i reads image index[i] of x, a pool of decoded images resident in HBM (no per-step host copy). */
+ * or n ints -- batch slot i reads image index[i] of x, a pool of decoded images resident in HBM (no per-step host copy).
+ * hsv: NULL, or n x 3 floats -- RandomHSV's hue / saturation / value gains of image i (data/augment.py:605-624). */
 int dy_import_image_u8(const void* x, void* y, int n, int h, int w, int cp, const void* flip, const int* index,
-                       hipStream_t stream);
+                       const float* hsv, hipStream_t stream);
 /* Mosaic (data/augment.py:208-241) + random affine (cv2.warpAffine of RandomPerspective :384-435, border 114) + flips, composed
  * from an HBM-resident pool of letterboxed s x s uint8 images straight into the fp16 NHWC stem input.  slots: n records of
  * dy_warp_slot_bytes() bytes = { float minv[6] (output pixel -> canvas); int canvas_w, canvas_h, xc, yc, flip, npatch;
- * int patch[4][7] = pool index, destination x1,y1,x2,y2 on the canvas, source x,y } built on the host from the random draws. */
+ * int patch[4][7] = pool index, destination x1,y1,x2,y2 on the canvas, source x,y; float hsv[3] (RandomHSV gains, 0 = off);
+ * int pad } built on the host from the random draws. */
 int dy_warp_import_u8(const void* pool, const void* slots, void* y, int n, int s, int cp, hipStream_t stream);
 int dy_warp_slot_bytes(void);
 int dy_add(const void* a, int lda, const void* b, int ldb, const void* c, int ldc, void* y, int ldy, long npix, int C,

@@ -11,12 +11,59 @@ from golden.cases import write_dataset
 pytestmark = pytest.mark.gpu
 
 
+def _hsv_reference(img, r):
+    """numpy restatement of RandomHSV's arithmetic on uint8 RGB (8-bit HSV with H in [0,180), the three LUTs, and back)."""
+    c = img.astype(np.float32)
+    R, G, B = c[..., 0], c[..., 1], c[..., 2]
+    V, mn = c.max(-1), c.min(-1)
+    d = V - mn
+    with np.errstate(divide="ignore", invalid="ignore"):
+        H = np.where(V == R, (G - B) / d, np.where(V == G, 2 + (B - R) / d, 4 + (R - G) / d)) * 30
+        H = np.where(d > 0, H, 0)
+        H = np.where(H < 0, H + 180, H)
+        h8 = np.rint(H)
+        h8 = np.where(h8 >= 180, h8 - 180, h8)
+        s8 = np.where(V > 0, np.rint(255 * d / V), 0)
+    hh = np.floor(np.fmod(h8 * np.float32(r[0]), 180)).astype(np.float32)
+    ss = np.floor(np.minimum(s8 * np.float32(r[1]), 255)).astype(np.float32)
+    vv = np.floor(np.minimum(V * np.float32(r[2]), 255)).astype(np.float32)
+    hs, sf = hh / 30, ss / 255
+    sec = np.floor(hs).astype(int) % 6
+    f = hs - np.floor(hs)
+    p, q, t = vv * (1 - sf), vv * (1 - sf * f), vv * (1 - sf * (1 - f))
+    table = [(vv, t, p), (q, vv, p), (p, vv, t), (p, q, vv), (t, p, vv), (vv, p, q)]
+    out = np.zeros_like(c)
+    for k, (r_, g_, b_) in enumerate(table):
+        m = sec == k
+        out[..., 0][m], out[..., 1][m], out[..., 2][m] = r_[m], g_[m], b_[m]
+    return np.clip(np.rint(out), 0, 255)
+
+
+def test_import_u8_hsv_jitter_matches_numpy_restatement():
+    from ultralytics.hip import check, lib
+    n, h, w = 3, 24, 20
+    x = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda")
+    x[0, 0, :4] = torch.tensor([[0, 0, 0], [255, 255, 255], [114, 114, 114], [200, 10, 10]], dtype=torch.uint8)
+    gains = torch.tensor([[1.0, 1.0, 1.0], [1.012, 0.55, 1.31], [0.99, 1.6, 0.7]], device="cuda")
+    y = torch.zeros((n, h, w, 8), dtype=torch.float16, device="cuda")
+    check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, None, None, gains.data_ptr(), None), "dy_import_image_u8")
+    torch.cuda.synchronize()
+    got = (y[..., :3].float().cpu().numpy() * 255).round()
+    xs = x.cpu().numpy()
+    for i in range(n):
+        ref = _hsv_reference(xs[i], gains[i].cpu().numpy())
+        d = np.abs(got[i] - ref)
+        assert d.max() <= 1 and (d > 0).mean() < 0.01, (i, d.max(), (d > 0).mean())
+    # unit gains are the identity up to the 8-bit HSV round trip (hue is quantised to 2 degrees: a few levels)
+    assert np.abs(got[0] - xs[0]).max() <= 6 and np.abs(got[0] - xs[0]).mean() < 0.6
+
+
 def test_import_u8_matches_float_division():
     from ultralytics.hip import check, lib
     for n, h, w in ((2, 5, 7), (1, 64, 64), (3, 33, 31)):
         x = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda")
         y = torch.full((n, h, w, 8), 7.0, dtype=torch.float16, device="cuda")
-        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, None, None, None), "dy_import_image_u8")
+        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, None, None, None, None), "dy_import_image_u8")
         torch.cuda.synchronize()
         ref = torch.zeros((n, h, w, 8), dtype=torch.float16, device="cuda")
         ref[..., :3] = (x.float() / 255).half()
@@ -24,7 +71,7 @@ def test_import_u8_matches_float_division():
         # flips folded into the conversion: bit 0 = left-right, bit 1 = up-down, per image
         flip = torch.tensor([(i * 3 + 1) % 4 for i in range(n)], dtype=torch.uint8, device="cuda")
         y.fill_(7.0)
-        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, flip.data_ptr(), None, None), "dy_import_image_u8")
+        check(lib().dy_import_image_u8(x.data_ptr(), y.data_ptr(), n, h, w, 8, flip.data_ptr(), None, None, None), "dy_import_image_u8")
         torch.cuda.synchronize()
         for i in range(n):
             f = int(flip[i])
@@ -171,8 +218,14 @@ def test_train_with_device_side_mosaic(tmp_path):
     y = YOLO("yolov8n-ASF-P2P2.yaml")
     hist = y.train(data=os.path.join(root, "data.yaml"), batch=4, imgsz=64, epochs=3, optimizer="SGD", workers=2, hipgraph=True, val=False,
                    cache="hbm", mosaic=1.0, degrees=5.0, translate=0.1, scale=0.5, shear=2.0, fliplr=0.5, mixup=0.0, copy_paste=0.0,
-                   hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, perspective=0.0, flipud=0.0)
+                   hsv_h=0.015, hsv_s=0.7, hsv_v=0.4, perspective=0.0, flipud=0.0)  # the reference's default gains
     assert y.trainer.plan.warp is not None and np.isfinite(np.asarray(hist, dtype=np.float64)).all()
+    # colour jitter + flips through the streaming loader (no pool): gains travel as a (B,3) tensor into dy_import_image_u8
+    y = YOLO("yolov8n-ASF-P2P2.yaml")
+    hist = y.train(data=os.path.join(root, "data.yaml"), batch=4, imgsz=64, epochs=2, optimizer="SGD", workers=2, hipgraph=True, val=False,
+                   mosaic=0.0, degrees=0.0, translate=0.0, scale=0.0, shear=0.0, fliplr=0.5, mixup=0.0, copy_paste=0.0,
+                   hsv_h=0.015, hsv_s=0.7, hsv_v=0.4, perspective=0.0, flipud=0.0)
+    assert y.trainer.plan.hsv is not None and np.isfinite(np.asarray(hist, dtype=np.float64)).all()
 
 
 def test_train_and_val_from_a_dataset_yaml(tmp_path):
