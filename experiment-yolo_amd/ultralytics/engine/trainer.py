@@ -102,6 +102,10 @@ class DetectionTrainer:
         for epoch in range(a.epochs):
             if getattr(self, "_epoch_hook", None):
                 self._epoch_hook(epoch)  # DistributedSampler.set_epoch (engine/trainer.py:766-767)
+            ds = getattr(loader, "dataset", None)
+            if ds is not None and getattr(ds, "mosaic", 0.0) and epoch == a.epochs - a.close_mosaic:
+                LOGGER.info("Closing dataloader mosaic")  # _close_dataloader_mosaic (engine/trainer.py:772-776, :934-940)
+                ds.mosaic = 0.0  # the affine / HSV / flip draws go on; batches keep their warp records
             t0, tloss = time.time(), None
             for i, batch in enumerate(loader):
                 ni = i + nb * epoch
@@ -147,6 +151,7 @@ class DetectionTrainer:
         if len(loader) == 0:
             raise ValueError(f"the training split holds {len(loader.dataset)} images, fewer than one batch of {batch_size}")
         self._epoch_hook = loader.set_epoch
+        self.train_loader = loader
         most = max((len(lb["cls"]) for lb in loader.dataset.labels), default=1)
         self.args.nmax = max(8, (most + 7) // 8 * 8)  # per-image label capacity of the recorded loss kernels
         hist = self.train(loader, batch_size, imgsz, log_every=log_every)  # log_every=1: per-epoch MEAN loss items, as results.csv
