@@ -113,14 +113,25 @@ class HipDataLoader:
         samples = [self.dataset.get(i, f, pixels=False) for i, f in zip(idx, flips)]
         batch = self.dataset.collate_fn(samples)
         batch["img"] = self._pool
-        if "warp" in batch:  # mosaic / affine: the device composes the pixels from per-slot records (flips included)
-            batch["warp"] = batch["warp"].to(self.device, non_blocking=True)
-        else:
-            batch["index"] = torch.tensor(idx, dtype=torch.int32).to(self.device, non_blocking=True)
-            batch["flip"] = batch["flip"].to(self.device, non_blocking=True)
-            if "hsv" in batch:
-                batch["hsv"] = batch["hsv"].to(self.device, non_blocking=True)
+        if "warp" not in batch:  # plain pool batch: slot indices (+ flip bits, HSV gains); mosaic / affine: the warp records
+            batch["index"] = torch.tensor(idx, dtype=torch.int32)
+        self._to_device(batch, ("warp", "index", "flip", "hsv"))
         return batch
+
+    def _to_device(self, batch, keys, slot=None):
+        """Host -> device for the listed entries, on the loader's own NON-BLOCKING stream, then one event the consumer waits on.
+        Nothing here may touch the legacy default stream: this runs in the producer thread while the consumer may be capturing
+        its step into a hipGraph, and work on the legacy stream implicitly synchronises with (and can invalidate) a capture."""
+        with torch.cuda.stream(self._copy_stream):
+            for k in keys:
+                if k in batch and torch.is_tensor(batch[k]) and not batch[k].is_cuda:
+                    batch[k] = batch[k].to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        if slot is not None:
+            self._events[slot] = ev
+        batch["_ready"] = ev
+        batch["_moved"] = [k for k in keys if k in batch]
 
     def _assemble(self, pool, idx, slot):
         """One batch.  Each worker decodes a contiguous chunk of samples and copies the pixels straight into the batch buffer
@@ -159,17 +170,8 @@ class HipDataLoader:
             s["img"] = v[:0]
         batch = self.dataset.collate_fn(samples)
         batch["img"] = buf
-        if "flip" in batch and self.device is not None:
-            batch["flip"] = batch["flip"].to(self.device, non_blocking=True)
-        if "hsv" in batch and self.device is not None:
-            batch["hsv"] = batch["hsv"].to(self.device, non_blocking=True)
         if self.device is not None:
-            with torch.cuda.stream(self._copy_stream):
-                batch["img"] = buf.to(self.device, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self._copy_stream)
-            self._events[slot] = ev
-            batch["_ready"] = ev
+            self._to_device(batch, ("img", "flip", "hsv"), slot)
         return batch
 
     def __iter__(self):
@@ -210,9 +212,11 @@ class HipDataLoader:
                 if ev is not None:
                     cur = torch.cuda.current_stream(self.device)
                     cur.wait_event(ev)
-                    # the device batch was allocated under the copy stream: tell the caching allocator that the consumer's
-                    # stream reads it, or the block could be handed to a later copy while queued kernels still need it
-                    b["img"].record_stream(cur)
+                    # device tensors allocated under the copy stream: tell the caching allocator that the consumer's stream
+                    # reads them, or a block could be handed to a later copy while queued kernels still need it
+                    for k in b.pop("_moved", ()):
+                        if torch.is_tensor(b[k]) and b[k].is_cuda and b[k] is not getattr(self, "_pool", None):
+                            b[k].record_stream(cur)
                 yield b
         finally:
             stop.set()

@@ -34,6 +34,9 @@ def test_public_api_training_reaches_the_reference_trainers_map(tmp_path, model,
     # optimizer steps, gradient accumulation over 32 batches -- loses 5 of them to the scale search on the LD model.)
     hist = np.asarray(hist, dtype=np.float64)
     m = y.trainer.metrics
+    st = y.trainer.plan.state.cpu().numpy()
+    print(f"optimizer steps taken {st[5]:.0f}, skipped {st[6]:.0f}, loss scale {st[0]:.0f}, last grad norm {st[3]:.3f}, "
+          f"nonfinite grads {int((~torch.isfinite(y.trainer.plan.rt.flat_g)).sum())}")
     for e in (0, 9, 19, 29, 39):
         print(f"epoch {e + 1:2d}  ours box/cls/dfl {np.round(hist[e], 3)}   reference "
               f"{[round(float(ref[k][e]), 3) for k in ('train/box_loss', 'train/cls_loss', 'train/dfl_loss')]}")
