@@ -78,7 +78,7 @@ struct StepArgs {
   float* state;
   long n, g0_end, g1_end;  // group boundaries: [0,g0_end) bias, [g0_end,g1_end) decayed weights, rest norm weights
   const uint8_t* frozen;   // optional per-element mask (1 = requires_grad False)
-  int adam;                // 0 SGD-nesterov, 1 Adam (L2 decay), 2 AdamW (decoupled), 3 RMSprop(alpha .99, momentum), 4 RAdam, 5 Adamax
+  int adam;                // 0 SGD-nesterov, 1 Adam (L2 decay), 2 AdamW (decoupled), 3 RMSprop(alpha .99, momentum), 4 RAdam, 5 Adamax, 6 NAdam
 };
 
 __global__ __launch_bounds__(256) void optim_step_kernel(StepArgs a) {
@@ -105,6 +105,18 @@ __global__ __launch_bounds__(256) void optim_step_kernel(StepArgs a) {
         const float buf = mom * (first ? 0.f : a.m[i]) + step;
         a.m[i] = buf;
         p -= lr * (mom > 0.f ? buf : step);
+      } else if (a.adam == 6) {  // torch.optim.NAdam (betas = (momentum, 0.999), eps 1e-8, momentum_decay 4e-3, L2 decay)
+        if (wd != 0.f) g += wd * p;
+        const float b2 = a.hyper[9], t = a.state[5] + 1.f;
+        const float mu = mom * (1.f - 0.5f * powf(0.96f, t * 0.004f)), mu_next = mom * (1.f - 0.5f * powf(0.96f, (t + 1.f) * 0.004f));
+        const float mu_prod = (first ? 1.f : a.state[7]) * mu;  // state[7]: product of the mu of the steps taken so far
+        const float m = mom * (first ? 0.f : a.m[i]) + (1.f - mom) * g;
+        const float v = b2 * (first ? 0.f : a.v[i]) + (1.f - b2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        const float denom = sqrtf(v / (1.f - powf(b2, t))) + 1e-8f;
+        p -= lr * (1.f - mu) / (1.f - mu_prod) * g / denom;
+        p -= lr * mu_next / (1.f - mu_prod * mu_next) * m / denom;
       } else if (a.adam == 4 || a.adam == 5) {  // torch.optim.RAdam / Adamax (betas = (momentum, 0.999), eps 1e-8, L2 decay)
         if (wd != 0.f) g += wd * p;
         const float b2 = a.hyper[9], t = a.state[5] + 1.f;
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(256) void optim_step_kernel(StepArgs a) {
 
 // EMA of the floating-point buffers (BN running statistics) + GradScaler.update bookkeeping
 __global__ __launch_bounds__(256) void ema_buffers_kernel(const float* s, float* es, long n, const float* hyper,
-                                                          float* state, int update_scaler) {
+                                                          float* state, int update_scaler, int mode) {
   const float d = hyper[7], found = state[2];
   if (es)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
@@ -156,6 +168,10 @@ __global__ __launch_bounds__(256) void ema_buffers_kernel(const float* s, float*
       state[1] = 0.f;
       state[6] += 1.f;
     } else {
+      if (mode == 6) {  // NAdam's running mu product (the parameter kernel of this step has already read the old value)
+        const float t = state[5] + 1.f;
+        state[7] = (state[5] == 0.f ? 1.f : state[7]) * hyper[3] * (1.f - 0.5f * powf(0.96f, t * 0.004f));
+      }
       state[5] += 1.f;
       state[1] += 1.f;
       if (state[1] >= 2000.f) {
@@ -170,7 +186,7 @@ extern "C" int dy_optimizer_step(float* params, const float* grads, float* mom, 
                                  long g0_end, long g1_end, const unsigned char* frozen, const float* buffers,
                                  float* ema_buffers, long n_buffers, const float* hyper, float* state,
                                  float* partials, int mode, hipStream_t stream) {
-  if (n <= 0 || mode < 0 || mode > 5 || (mode > 0 && !adam_v)) return DY_ERR_ARG;
+  if (n <= 0 || mode < 0 || mode > 6 || (mode > 0 && !adam_v)) return DY_ERR_ARG;
   int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(grad_sumsq_kernel, dim3(blocks), dim3(256), 0, stream, grads, n, partials);
   hipLaunchKernelGGL(grad_norm_final_kernel, dim3(1), dim3(256), 0, stream, partials, blocks, hyper, state);
@@ -180,7 +196,7 @@ extern "C" int dy_optimizer_step(float* params, const float* grads, float* mom, 
   if (b2 < 1) b2 = 1;
   if (b2 > 256) b2 = 256;
   hipLaunchKernelGGL(ema_buffers_kernel, dim3(b2), dim3(256), 0, stream, buffers, ema_buffers, n_buffers, hyper, state,
-                     1);
+                     1, mode);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

@@ -38,8 +38,8 @@ class DetectionTrainer:
             lr_fit = round(0.002 * 5 / (4 + nc), 6)
             name, lr, mom = ("SGD", 0.01, 0.9) if iterations > 10000 else ("AdamW", lr_fit, 0.9)
             self.args.warmup_bias_lr = 0.0
-        if name not in ("SGD", "Adam", "AdamW", "RMSProp", "RAdam", "Adamax"):
-            raise NotImplementedError(f"optimizer '{name}' is not on the HIP path (SGD, Adam, AdamW, Adamax, RAdam, RMSProp, auto)")
+        if name not in ("SGD", "Adam", "AdamW", "RMSProp", "RAdam", "Adamax", "NAdam"):
+            raise NotImplementedError(f"optimizer '{name}' is not on the HIP path (SGD, Adam, AdamW, Adamax, NAdam, RAdam, RMSProp, auto)")
         return name, lr, mom
 
     def setup(self, batches_per_epoch, batch_size, imgsz):

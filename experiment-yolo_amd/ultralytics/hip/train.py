@@ -32,7 +32,7 @@ class StepPlan:
         self.B, self.imgsz, self.nmax = batch_size, (imgsz, imgsz) if isinstance(imgsz, int) else tuple(imgsz), nmax
         self.world_size = world_size
         self.use_graph = use_graph
-        self.mode = {"SGD": 0, "Adam": 1, "AdamW": 2, "RMSProp": 3, "RAdam": 4, "Adamax": 5}[optimizer]
+        self.mode = {"SGD": 0, "Adam": 1, "AdamW": 2, "RMSProp": 3, "RAdam": 4, "Adamax": 5, "NAdam": 6}[optimizer]
         self.crit = model.criterion if hasattr(model, "criterion") else model.init_criterion()
         model.criterion = self.crit
         n = self.rt.n_params_flat

@@ -217,7 +217,7 @@ int dy_soft_nms(const float* boxes, float* scores, const float* cls, const int* 
 
 /* ---- BaseTrainer.optimizer_step engine/trainer.py:949-957 + build_optimizer groups :1146-1174 + ModelEMA.update
  *      utils/torch_utils.py:447-458 + GradScaler policy, over flat fp32 buffers.  mode: 0 SGD-nesterov, 1 Adam, 2 AdamW,
- *      3 RMSprop, 4 RAdam, 5 Adamax (betas = (momentum, 0.999) as build_optimizer :1159-1164 sets them). -------------- */
+ *      3 RMSprop, 4 RAdam, 5 Adamax, 6 NAdam (betas = (momentum, 0.999) as build_optimizer :1159-1164 sets them). -------------- */
 int dy_optimizer_step(float* params, const float* grads, float* mom, float* adam_v, float* ema, long n, long g0_end,
                       long g1_end, const unsigned char* frozen, const float* buffers, float* ema_buffers,
                       long n_buffers, const float* hyper, float* state, float* partials, int mode, hipStream_t stream);

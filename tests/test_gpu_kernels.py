@@ -243,7 +243,7 @@ def test_scalseq_backward_all_levels_matches_per_level():
         assert relerr(outs[l].float(), refs[l].float()) < 2e-3, l
 
 
-@pytest.mark.parametrize("name", ["SGD", "Adam", "AdamW", "RMSProp", "RAdam", "Adamax"])
+@pytest.mark.parametrize("name", ["SGD", "Adam", "AdamW", "RMSProp", "RAdam", "Adamax", "NAdam"])
 def test_flat_optimizer_step_matches_torch_optim(name):
     """dy_optimizer_step (unscale, global-norm clip, step per parameter group) against torch.optim on the CPU, built like the
     reference's build_optimizer (engine/trainer.py:1146-1180): betas = (momentum, 0.999), weight decay on the middle group."""
@@ -260,8 +260,9 @@ def test_flat_optimizer_step_matches_torch_optim(name):
            "AdamW": lambda: torch.optim.AdamW(groups, lr=lr, betas=(mom, 0.999)),
            "RMSProp": lambda: torch.optim.RMSprop(groups, lr=lr, momentum=mom),
            "RAdam": lambda: torch.optim.RAdam(groups, lr=lr, betas=(mom, 0.999)),
-           "Adamax": lambda: torch.optim.Adamax(groups, lr=lr, betas=(mom, 0.999))}[name]()
-    mode = {"SGD": 0, "Adam": 1, "AdamW": 2, "RMSProp": 3, "RAdam": 4, "Adamax": 5}[name]
+           "Adamax": lambda: torch.optim.Adamax(groups, lr=lr, betas=(mom, 0.999)),
+           "NAdam": lambda: torch.optim.NAdam(groups, lr=lr, betas=(mom, 0.999))}[name]()
+    mode = {"SGD": 0, "Adam": 1, "AdamW": 2, "RMSProp": 3, "RAdam": 4, "Adamax": 5, "NAdam": 6}[name]
     dev = "cuda:0"
     p = p0.clone().to(dev)
     m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
