@@ -201,6 +201,22 @@ extern "C" int dy_optimizer_step(float* params, const float* grads, float* mom, 
   return DY_OK;
 }
 
+// The per-step hyper-parameters travel as KERNEL ARGUMENTS (copied at enqueue time), not through a reused pinned host buffer:
+// the host may be many steps ahead of the device, and an asynchronous copy from a buffer the host has since overwritten would
+// hand step i the learning rate of step i+k.
+struct Hyper16 { float v[16]; };
+__global__ void set_hyper_kernel(float* dst, Hyper16 h) {
+  if (threadIdx.x < 16) dst[threadIdx.x] = h.v[threadIdx.x];
+}
+extern "C" int dy_set_hyper(float* hyper_dev, const float* host_values16, hipStream_t stream) {
+  if (!hyper_dev || !host_values16) return DY_ERR_ARG;
+  Hyper16 h;
+  for (int i = 0; i < 16; ++i) h.v[i] = host_values16[i];
+  hipLaunchKernelGGL(set_hyper_kernel, dim3(1), dim3(64), 0, stream, hyper_dev, h);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
 // y += a * x (fp32), used for gradient accumulation across micro-steps
 __global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, float a, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];

@@ -87,6 +87,7 @@ SIGNATURES = {
     "dy_decode_predictions": (i32, [vp, vp, ip, ip, C.POINTER(f32), i32, i32, i32, i32, vp, vp]),
     "dy_nms_candidates": (i32, [vp, i32, i32, i32, f32, i32, vp, i32, vp, vp, vp, vp, i32, vp]),
     "dy_soft_nms": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp]),
+    "dy_set_hyper": (i32, [vp, vp, vp]),
     "dy_optimizer_step": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, i64, vp, vp, vp, i32, vp]),
     "dy_axpy_f32": (i32, [vp, vp, f32, i64, vp]),
 }

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import check
+from . import check, lib
 from .dist import all_reduce_flat, broadcast_buffers
 from .engine import Recorder
 
@@ -41,7 +41,7 @@ class StepPlan:
         self.adam_v = f() if self.mode else None
         self.ema = self.rt.flat_p.clone()
         self.ema_b = self.rt.flat_b.clone()
-        self.hyper_host = torch.zeros(16, dtype=torch.float32).pin_memory()
+        self.hyper_host = (C.c_float * 16)()  # read by dy_set_hyper at enqueue time (the values travel as kernel arguments)
         self.hyper = torch.zeros(16, dtype=torch.float32, device=dev)
         self.state = torch.zeros(8, dtype=torch.float32, device=dev)
         self.state[0] = init_scale
@@ -62,13 +62,12 @@ class StepPlan:
     # ---- host-side schedule ------------------------------------------------------------------------------------
     def set_hyper(self, lr, momentum, wd, ema_decay=None, max_norm=10.0, beta2=0.999, eps=1e-8):
         h = self.hyper_host
-        h[0:3] = torch.tensor(lr, dtype=torch.float32)
-        h[3] = momentum
-        h[4:7] = torch.tensor(wd, dtype=torch.float32)
         if ema_decay is None:
             ema_decay = 0.9999 * (1 - math.exp(-(self.ema_updates + 1) / 2000))
-        h[7], h[8], h[9], h[10] = ema_decay, max_norm, beta2, eps
-        self.hyper.copy_(h, non_blocking=True)
+        vals = [*lr, momentum, *wd, ema_decay, max_norm, beta2, eps]
+        for i, v in enumerate(vals):
+            h[i] = float(v)
+        check(lib().dy_set_hyper(self.hyper.data_ptr(), h, torch.cuda.current_stream(self.hyper.device).cuda_stream), "dy_set_hyper")
 
     # ---- forward + loss + backward ----------------------------------------------------------------------------
     def _trace_fb(self, batch):

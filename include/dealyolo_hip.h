@@ -221,6 +221,9 @@ int dy_soft_nms(const float* boxes, float* scores, const float* cls, const int* 
 int dy_optimizer_step(float* params, const float* grads, float* mom, float* adam_v, float* ema, long n, long g0_end,
                       long g1_end, const unsigned char* frozen, const float* buffers, float* ema_buffers,
                       long n_buffers, const float* hyper, float* state, float* partials, int mode, hipStream_t stream);
+/* hyper (16 device floats read by dy_optimizer_step: lr per group, momentum, weight decay per group, EMA decay, max grad norm,
+ * beta2, eps) set from 16 HOST floats that are copied at enqueue time (kernel arguments): safe however far the host runs ahead. */
+int dy_set_hyper(float* hyper_dev, const float* host_values16, hipStream_t stream);
 int dy_axpy_f32(float* y, const float* x, float a, long n, hipStream_t stream);
 
 /* ---- validation: the per-batch half of DetectionValidator.update_metrics in ONE launch --
