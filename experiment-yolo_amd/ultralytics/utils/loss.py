@@ -107,9 +107,9 @@ class v8DetectionLoss:
         a.n_targets = n
         if self._ncount is None:
             self._ncount = torch.zeros(1, dtype=torch.int32, device=self.device)
-            self._ncount_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self._ncount_host[0] = n
-        self._ncount.copy_(self._ncount_host, non_blocking=True)
+        # the count travels by value (a fill kernel's argument), not through a reused pinned word: the host may be several steps
+        # ahead of the device, and a later step's count must not reach an earlier step's loss kernels
+        self._ncount.fill_(n)
         a.n_targets_dev = self._ncount.data_ptr()
         return n
 

@@ -152,3 +152,37 @@ def test_reference_checkpoint_runs_like_a_native_model():
     ya, _ = a(x)
     yb, _ = b(x)
     assert torch.equal(ya, yb)
+
+
+def test_steps_queued_behind_a_busy_device_keep_their_own_scalars():
+    """The host can enqueue several steps while the device is still busy.  Per-step scalars (target count, hyper-parameters)
+    therefore travel by value, never through a reused pinned word: two different batches queued back to back behind a parked
+    device must accumulate exactly the gradients they produce one at a time."""
+    from ultralytics.hip.train import StepPlan
+    from ultralytics.nn.tasks import DetectionModel
+    g = torch.Generator().manual_seed(12)
+    B, S = 2, 128
+
+    def batch(n_per):
+        n = B * n_per
+        return dict(img=torch.rand(B, 3, S, S, generator=g).cuda(), batch_idx=torch.arange(B).repeat_interleave(n_per).float().cuda(),
+                    cls=torch.randint(0, 6, (n, 1), generator=g).float().cuda(),
+                    bboxes=torch.cat([torch.rand(n, 2, generator=g) * 0.6 + 0.2, torch.rand(n, 2, generator=g) * 0.2 + 0.05], 1).cuda())
+
+    a, b = batch(2), batch(7)
+    torch.manual_seed(0)
+    m = DetectionModel("yolov8n-ASF-P2P2.yaml", verbose=False).cuda().train()
+    plan = StepPlan(m, B, S, nmax=8, optimizer="SGD", use_graph=True, init_scale=1.0)
+    plan.set_hyper([0.0] * 3, 0.9, [0.0] * 3)
+    ref = None
+    for bt in (a, b):  # one at a time, synchronised
+        plan.forward_backward(bt)
+        torch.cuda.synchronize()
+        ref = plan.rt.flat_g.clone() if ref is None else ref + plan.rt.flat_g
+    torch.cuda._sleep(400_000_000)  # park the device: everything below is enqueued before any of it runs
+    plan.forward_backward(a)
+    plan.accumulate()
+    plan.forward_backward(b)
+    plan.accumulate()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.gsum, ref)
