@@ -60,6 +60,7 @@ class YOLODataset:
         self.mosaic, self.degrees, self.translate, self.scale, self.shear = (float(v) for v in (mosaic, degrees, translate, scale, shear))
         self.geometric = augment and any((self.mosaic, self.degrees, self.translate, self.scale, self.shear))
         self.hsv = (float(hsv_h), float(hsv_s), float(hsv_v)) if augment and any((hsv_h, hsv_s, hsv_v)) else None
+        self._label_cache = {}
         self.buffer, self._in_buffer = [], set()  # BaseDataset.buffer (base.py:86-87, :170-176): what Mosaic draws its partners from
         self.stride, self.pad, self.data, self.fraction, self.layout, self.prefix = stride, pad, data or {}, fraction, layout, prefix
         self.im_files = self.get_img_files(img_path)
@@ -316,6 +317,35 @@ class YOLODataset:
         keep = (w2 > 2) & (h2 > 2) & (w2 * h2 / (w1 * h1 + eps) > np.float32(0.1)) & (ar < 100)
         return new[keep], cls[keep], size, M
 
+    def _letterbox_labels(self, lab, w, h, r, dw, dh, W, H):
+        """normalised xywh -> xyxy -> pixels of the (resized) image -> * r -> + pad (LetterBox._update_labels :744-750); in train
+        mode the identity RandomPerspective (:512-560: clip, candidate filter); -> pixel xywh (RandomFlip / Format :664, :918)."""
+        b = lab["bboxes"].astype(np.float32, copy=True)
+        cls = lab["cls"].copy()
+        xy = np.empty_like(b)
+        hw_, hh_ = b[:, 2] / 2, b[:, 3] / 2
+        xy[:, 0], xy[:, 1], xy[:, 2], xy[:, 3] = b[:, 0] - hw_, b[:, 1] - hh_, b[:, 0] + hw_, b[:, 1] + hh_
+        for j, sc in enumerate((w, h, w, h)):
+            xy[:, j] *= sc
+        for j in range(4):
+            xy[:, j] *= r
+        for j, off in enumerate((dw, dh, dw, dh)):
+            xy[:, j] += off
+        if self.augment:
+            before = xy.copy()
+            xy[:, [0, 2]] = xy[:, [0, 2]].clip(0, W)
+            xy[:, [1, 3]] = xy[:, [1, 3]].clip(0, H)
+            w1, h1 = before[:, 2] - before[:, 0], before[:, 3] - before[:, 1]
+            w2, h2 = xy[:, 2] - xy[:, 0], xy[:, 3] - xy[:, 1]
+            eps = np.float32(1e-16)
+            ar = np.maximum(w2 / (h2 + eps), h2 / (w2 + eps))
+            keep = (w2 > 2) & (h2 > 2) & (w2 * h2 / (w1 * h1 + eps) > np.float32(0.1)) & (ar < 100)
+            xy, cls = xy[keep], cls[keep]
+        out = np.empty_like(xy)
+        out[:, 0], out[:, 1] = (xy[:, 0] + xy[:, 2]) / 2, (xy[:, 1] + xy[:, 3]) / 2
+        out[:, 2], out[:, 3] = xy[:, 2] - xy[:, 0], xy[:, 3] - xy[:, 1]
+        return out, cls
+
     def get(self, index, flip=0, pixels=True):
         """One sample; ``pixels=False`` builds the labels only (the image already sits in the loader's HBM pool).  ``flip``: the
         value ``draw_augment`` returned (flip bits, or the dict of a geometric augmentation)."""
@@ -345,31 +375,13 @@ class YOLODataset:
             canvas[top:top + im.shape[0], left:left + im.shape[1]] = im
         else:
             canvas = im  # already the canvas size: handed on without a copy (the loader copies it into its pinned batch)
-        # labels: normalised xywh -> xyxy -> pixels of the (resized) image -> * r -> + pad   (LetterBox._update_labels :744-750)
-        b = lab["bboxes"].astype(np.float32, copy=True)
-        cls = lab["cls"].copy()
-        xy = np.empty_like(b)
-        hw_, hh_ = b[:, 2] / 2, b[:, 3] / 2
-        xy[:, 0], xy[:, 1], xy[:, 2], xy[:, 3] = b[:, 0] - hw_, b[:, 1] - hh_, b[:, 0] + hw_, b[:, 1] + hh_
-        for j, sc in enumerate((w, h, w, h)):
-            xy[:, j] *= sc
-        for j in range(4):
-            xy[:, j] *= r
-        for j, off in enumerate((dw, dh, dw, dh)):
-            xy[:, j] += off
-        if self.augment:  # RandomPerspective with the identity matrix (:512-560): clip, then filter the candidates
-            before = xy.copy()
-            xy[:, [0, 2]] = xy[:, [0, 2]].clip(0, W)
-            xy[:, [1, 3]] = xy[:, [1, 3]].clip(0, H)
-            w1, h1 = before[:, 2] - before[:, 0], before[:, 3] - before[:, 1]
-            w2, h2 = xy[:, 2] - xy[:, 0], xy[:, 3] - xy[:, 1]
-            eps = np.float32(1e-16)
-            ar = np.maximum(w2 / (h2 + eps), h2 / (w2 + eps))
-            keep = (w2 > 2) & (h2 > 2) & (w2 * h2 / (w1 * h1 + eps) > np.float32(0.1)) & (ar < 100)
-            xy, cls = xy[keep], cls[keep]
-        out = np.empty_like(xy)  # RandomFlip / Format (:664, :918): xyxy -> xywh; flips mirror the centre; normalise by the canvas
-        out[:, 0], out[:, 1] = (xy[:, 0] + xy[:, 2]) / 2, (xy[:, 1] + xy[:, 3]) / 2
-        out[:, 2], out[:, 3] = xy[:, 2] - xy[:, 0], xy[:, 3] - xy[:, 1]
+        # labels before the flips depend on the image alone: computed once per image, copied per sample
+        cached = self._label_cache.get(index) if not self.rect else None
+        if cached is None:
+            cached = self._letterbox_labels(lab, w, h, r, dw, dh, W, H)
+            if not self.rect:
+                self._label_cache[index] = cached
+        out, cls = cached[0].copy(), cached[1].copy()
         if flip & 2:
             out[:, 1] = H - out[:, 1]
         if flip & 1:
