@@ -84,7 +84,6 @@ class HipDataLoader:
         n = len(self.dataset) if self.world_size == 1 else math.ceil(len(self.dataset) / self.world_size)
         return n // self.batch_size if self.drop_last else math.ceil(n / self.batch_size)
 
-    # ---- batches -------------------------------------------------------------------------------------------------
     # ---- HBM-resident dataset ------------------------------------------------------------------------------------
     def _build_pool(self, workers):
         ds = self.dataset
@@ -118,6 +117,7 @@ class HipDataLoader:
         self._to_device(batch, ("warp", "index", "flip", "hsv"))
         return batch
 
+    # ---- batches -------------------------------------------------------------------------------------------------
     def _to_device(self, batch, keys, slot=None):
         """Host -> device for the listed entries, on the loader's own NON-BLOCKING stream, then one event the consumer waits on.
         Nothing here may touch the legacy default stream: this runs in the producer thread while the consumer may be capturing
