@@ -14,7 +14,7 @@ from ultralytics.data import SyntheticDetection  # noqa: E402
 
 if __name__ == "__main__":
     model = YOLO("yolov8n-ASF-P2P2.yaml")
-    data = sys.argv[1] if len(sys.argv) > 1 else SyntheticDetection(n_batches=20, batch=64, imgsz=640)
+    data = sys.argv[1] if len(sys.argv) > 1 else SyntheticDetection(n_batches=20, batch=64, imgsz=640, device="cuda:0")
     extra = dict(cache="hbm") if isinstance(data, str) else {}
     model.train(data=data, imgsz=640, **extra, epochs=2, batch=64, close_mosaic=10,
                 workers=8, device="0", optimizer="SGD", project="runs/train", name="exp")
