@@ -148,11 +148,13 @@ class DetectionTrainer:
         self.data = check_det_dataset(data_yaml)
         self.model.names = self.data["names"]
         loader = self.get_dataloader(self.data["train"], batch_size, self.rank, "train", self.data)
+        batch_size = loader.batch_size  # build_dataloader clamps it to the dataset size, as the reference does (data/build.py:104)
         if len(loader) == 0:
             raise ValueError(f"the training split holds {len(loader.dataset)} images, fewer than one batch of {batch_size}")
         self._epoch_hook = loader.set_epoch
         self.train_loader = loader
-        most = max((len(lb["cls"]) for lb in loader.dataset.labels), default=1)
+        counts = sorted((len(lb["cls"]) for lb in loader.dataset.labels), reverse=True) or [1]
+        most = sum(counts[:4]) if getattr(loader.dataset, "mosaic", 0.0) else counts[0]  # a mosaic carries four images' boxes
         self.args.nmax = max(8, (most + 7) // 8 * 8)  # per-image label capacity of the recorded loss kernels
         hist = self.train(loader, batch_size, imgsz, log_every=log_every)  # log_every=1: per-epoch MEAN loss items, as results.csv
         self.metrics = None

@@ -221,6 +221,11 @@ def test_train_with_device_side_mosaic(tmp_path):
                    hsv_h=0.015, hsv_s=0.7, hsv_v=0.4, perspective=0.0, flipud=0.0, close_mosaic=1)  # the reference's default gains
     assert y.trainer.plan.warp is not None and np.isfinite(np.asarray(hist, dtype=np.float64)).all()
     assert y.trainer.train_loader.dataset.mosaic == 0.0  # closed for the last epoch, the affine / HSV / flip path went on
+    # a batch larger than the dataset is clamped to it (data/build.py:104), and a mosaic's four images' labels fit the plan
+    y = YOLO("yolov8n-ASF-P2P2.yaml")
+    hist = y.train(data=os.path.join(root, "data.yaml"), batch=32, imgsz=64, epochs=2, optimizer="SGD", workers=2, val=False, cache="hbm",
+                   mixup=0.0, copy_paste=0.0, perspective=0.0)  # everything else at the reference's defaults (mosaic 1.0, HSV, ...)
+    assert y.trainer.plan.B == 9 and y.trainer.plan.nmax >= 8 and np.isfinite(np.asarray(hist, dtype=np.float64)).all()
     # colour jitter + flips through the streaming loader (no pool): gains travel as a (B,3) tensor into dy_import_image_u8
     y = YOLO("yolov8n-ASF-P2P2.yaml")
     hist = y.train(data=os.path.join(root, "data.yaml"), batch=4, imgsz=64, epochs=2, optimizer="SGD", workers=2, hipgraph=True, val=False,
