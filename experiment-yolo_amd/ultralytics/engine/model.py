@@ -63,8 +63,8 @@ class YOLO:
 
     __call__ = predict
 
-    def val(self, data=None, batch=32, **kw):
-        """``data``: a dataset YAML (its 'val' split, rectangular batches as in the reference) or a re-iterable of batch dicts.
+    def val(self, data=None, batch=32, split="val", **kw):
+        """``data``: a dataset YAML (its ``split``, rectangular batches as in the reference) or a re-iterable of batch dicts.
         Returns the metrics dict of the reference's DetMetrics.results_dict (precision, recall, mAP50, mAP50-95, fitness)."""
         from ..models.yolo.detect import DetectionValidator
         if data is None:
@@ -74,7 +74,9 @@ class YOLO:
             d = check_det_dataset(data)
             tr = DetectionTrainer(self.model, overrides=dict(batch=batch, **kw))
             self.model.names = d["names"]
-            data = tr.get_dataloader(d["val"], batch, 0, "val", d)
+            if not d.get(split):
+                raise KeyError(f"the dataset YAML has no '{split}' split")
+            data = tr.get_dataloader(d[split], batch, 0, "val", d)
             self.validator = DetectionValidator(dataloader=data, args=tr.args)
         else:
             self.validator = DetectionValidator(dataloader=data, args=kw or None)
