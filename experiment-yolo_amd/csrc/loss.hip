@@ -174,7 +174,8 @@ __global__ void pack_targets_kernel(LossCtx c, const float* bidx, const float* c
     int slot = 0;
     for (int j = 0; j < i; ++j) slot += ((j < ncache ? (int)sb[j] : (int)bidx[j]) == b);
     if (slot >= c.nmax) {
-      c.scal[9] = 1.f;  // capacity overflow: host raises
+      c.scal[9] = 1.f;   // capacity overflow in this call
+      c.scal[10] = 1.f;  // sticky: cleared only by the host, which raises on it wherever it already synchronises
       continue;
     }
     const float x = boxes[i * 4 + 0] * img_w, y = boxes[i * 4 + 1] * img_h;

@@ -8,7 +8,8 @@
 #include "dealyolo_hip.h"
 
 // hyper[] (float, written by the host before each step): 0..2 lr per group, 3 momentum/beta1, 4..6 weight decay per
-// group, 7 ema decay, 8 max grad norm, 9 adam beta2, 10 adam eps
+// group, 7 ema decay, 8 max grad norm, 9 adam beta2, 10 adam eps, 11 dynamic loss scale on (1) / off (0: amp=False -- the
+// scale stays where it is; a non-finite step is still skipped and counted, and the trainer raises on it)
 // state[] (float, device-resident): 0 loss scale, 1 growth tracker, 2 found_inf (this step), 3 grad norm (unscaled),
 // 4 clip coefficient, 5 optimizer steps taken, 6 skipped steps
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* g, long n, float* partials) {
@@ -163,8 +164,9 @@ __global__ __launch_bounds__(256) void ema_buffers_kernel(const float* s, float*
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
       es[i] = d * es[i] + (1.f - d) * s[i];
   if (update_scaler && blockIdx.x == 0 && threadIdx.x == 0) {
+    const bool dynamic = hyper[11] != 0.f;
     if (found != 0.f) {
-      state[0] *= 0.5f;
+      if (dynamic) state[0] *= 0.5f;
       state[1] = 0.f;
       state[6] += 1.f;
     } else {
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void ema_buffers_kernel(const float* s, float*
       }
       state[5] += 1.f;
       state[1] += 1.f;
-      if (state[1] >= 2000.f) {
+      if (dynamic && state[1] >= 2000.f) {
         state[0] *= 2.f;
         state[1] = 0.f;
       }

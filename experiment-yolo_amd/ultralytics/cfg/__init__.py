@@ -17,9 +17,10 @@ CFG_FLOAT_KEYS = "warmup_epochs", "box", "cls", "dfl", "degrees", "shear", "time
 CFG_FRACTION_KEYS = ("dropout", "iou", "lr0", "lrf", "momentum", "weight_decay", "warmup_momentum", "warmup_bias_lr",
                      "label_smoothing", "hsv_h", "hsv_s", "hsv_v", "translate", "scale", "perspective", "flipud", "fliplr",
                      "mosaic", "mixup", "copy_paste", "conf", "fraction", "iou_ratio")
-CFG_INT_KEYS = "epochs", "patience", "batch", "workers", "seed", "close_mosaic", "max_det", "vid_stride", "nbs", "save_period"
+CFG_INT_KEYS = ("epochs", "patience", "batch", "workers", "seed", "close_mosaic", "max_det", "vid_stride", "nbs", "save_period", "mask_ratio",
+                "nmax")
 CFG_BOOL_KEYS = ("save", "exist_ok", "verbose", "deterministic", "single_cls", "rect", "cos_lr", "amp", "val", "half",
-                 "agnostic_nms", "plots", "wiou", "nwd", "hipgraph", "multi_scale", "resume")
+                 "agnostic_nms", "plots", "wiou", "nwd", "hipgraph", "multi_scale", "overlap_mask")
 
 
 class IterableSimpleNamespace(SimpleNamespace):

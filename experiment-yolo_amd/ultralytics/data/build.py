@@ -52,7 +52,7 @@ class HipDataLoader:
         self.generator.manual_seed(6148914691236517205 + RANK)
         self._base_seed_drawn = False
         self.epoch = 0
-        self._pinned, self._events, self._copy_stream = {}, {}, None
+        self._pinned, self._copy_stream = {}, None
 
     # ---- order ---------------------------------------------------------------------------------------------------
     def set_epoch(self, epoch):
@@ -114,43 +114,39 @@ class HipDataLoader:
         batch["img"] = self._pool
         if "warp" not in batch:  # plain pool batch: slot indices (+ flip bits, HSV gains); mosaic / affine: the warp records
             batch["index"] = torch.tensor(idx, dtype=torch.int32)
-        self._to_device(batch, ("warp", "index", "flip", "hsv"))
-        return batch
+        return batch  # host tensors: the consumer's thread moves them (see the threading rule below)
 
     # ---- batches -------------------------------------------------------------------------------------------------
-    def _to_device(self, batch, keys, slot=None):
-        """Host -> device for the listed entries, on the loader's own NON-BLOCKING stream, then one event the consumer waits on.
-        Nothing here may touch the legacy default stream: this runs in the producer thread while the consumer may be capturing
-        its step into a hipGraph, and work on the legacy stream implicitly synchronises with (and can invalidate) a capture."""
+    # Threading rule ("Threads and hipGraphs"): ONLY the consumer's thread calls into HIP.  The producer
+    # thread and its decode workers do host work (decode, label arithmetic, memcpy into pinned slots the consumer allocated);
+    # every host->device copy, event and device allocation is issued by the thread that also launches the step's hipGraphs.
+    # Measured on this ROCm: a second thread enqueuing copies while hipGraphLaunch runs can break the ordering INSIDE the
+    # replayed graph (a gradient buffer came back non-finite, every optimizer step was skipped, the run trained nothing).
+    def _to_device(self, batch, keys):
+        """Host -> device for the listed entries on the loader's own non-blocking stream (called from the consumer's thread),
+        then one event the consumer's stream waits on.  The copy of batch k+1 is enqueued before batch k is handed out, so it
+        runs on the copy engine under step k's kernels."""
         with torch.cuda.stream(self._copy_stream):
             for k in keys:
                 if k in batch and torch.is_tensor(batch[k]) and not batch[k].is_cuda:
                     batch[k] = batch[k].to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
-        if slot is not None:
-            self._events[slot] = ev
         batch["_ready"] = ev
         batch["_moved"] = [k for k in keys if k in batch]
+        return ev
 
     def _assemble(self, pool, idx, slot):
-        """One batch.  Each worker decodes a contiguous chunk of samples and copies the pixels straight into the batch buffer
-        (memcpy, GIL released) -- a pinned ring slot when a device is set, fresh host memory otherwise; only the label tensors
-        go through collate_fn."""
+        """One batch, host side only.  Each worker decodes a contiguous chunk of samples and copies the pixels straight into the
+        batch buffer (memcpy, GIL released) -- the pinned ring slot the consumer allocated, or fresh pageable memory when the
+        shape is not the ring's (or no device is set); only the label tensors go through collate_fn."""
         n, W = len(idx), min(self.workers, len(idx))
         flips = [self.dataset.draw_augment(i) for i in idx]  # RNG consumed here, in sample order, whatever the worker schedule
         first = self.dataset.get(idx[0], flips[0])
         shape = tuple(first["img"].shape)
-        if self.device is not None:
-            key = (slot, n, shape)
-            if key not in self._pinned:
-                self._pinned = {k: v for k, v in self._pinned.items() if k[0] != slot}
-                self._pinned[key] = torch.empty((n, *shape), dtype=torch.uint8).pin_memory()
-            buf = self._pinned[key]
-            if slot in self._events:
-                self._events[slot].synchronize()  # the copy that last read this pinned buffer has finished
-        else:
-            buf = torch.empty((n, *shape), dtype=torch.uint8)
+        buf = self._pinned.get(slot)
+        if buf is None or tuple(buf.shape) != (n, *shape):
+            buf = torch.empty((n, *shape), dtype=torch.uint8)  # pageable: never a HIP call from this thread
         samples = [None] * n
         buf_np = buf.numpy()  # plain memcpy per image from the worker threads (torch's copy_ would nest its own thread pool)
 
@@ -170,54 +166,97 @@ class HipDataLoader:
             s["img"] = v[:0]
         batch = self.dataset.collate_fn(samples)
         batch["img"] = buf
-        if self.device is not None:
-            self._to_device(batch, ("img", "flip", "hsv"), slot)
         return batch
 
     def __iter__(self):
         idx = self._indices()
         nb = len(self)
         chunks = [idx[i * self.batch_size:(i + 1) * self.batch_size] for i in range(nb)]
-        if self.device is not None and self._copy_stream is None:
+        dev = self.device is not None
+        if dev and self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(self.device)
         q: queue.Queue = queue.Queue(maxsize=self.prefetch)
+        free: queue.Queue = queue.Queue()  # pinned ring slots the producer may fill
         stop = threading.Event()
 
-        hbm = self.device is not None and getattr(self.dataset, "cache_mode", False) == "hbm"
+        hbm = dev and getattr(self.dataset, "cache_mode", False) == "hbm"
         if hbm and getattr(self, "_pool", None) is None:
             with ThreadPoolExecutor(self.workers) as pool:
                 self._build_pool(pool)
+        nslots = self.prefetch + 3
+        if dev and not hbm:
+            ds = self.dataset
+            if ds.augment and not ds.rect and ds.layout == "nhwc":  # fixed canvas: pin the ring here, in the consumer's thread
+                shape = (self.batch_size, int(ds.imgsz), int(ds.imgsz), 3)
+                for s in range(nslots):
+                    if s not in self._pinned or tuple(self._pinned[s].shape) != shape:
+                        self._pinned[s] = torch.empty(shape, dtype=torch.uint8).pin_memory()
+        for s in range(nslots):
+            free.put(s)
 
-        def produce():
+        def produce():  # host work only -- see the threading rule above
             try:
                 with ThreadPoolExecutor(self.workers) as pool:
-                    for k, c in enumerate(chunks):
+                    for c in chunks:
+                        slot = None
+                        while not hbm and slot is None:
+                            if stop.is_set():
+                                return
+                            try:
+                                slot = free.get(timeout=0.05)
+                            except queue.Empty:
+                                pass
                         if stop.is_set():
                             return
-                        q.put(self._assemble_pool(pool, c) if hbm else self._assemble(pool, c, k % (self.prefetch + 2)))
+                        q.put((self._assemble_pool(pool, c) if hbm else self._assemble(pool, c, slot), slot))
                 q.put(None)
             except BaseException as e:  # surfaced in the consumer
                 q.put(e)
 
+        keys = ("warp", "index", "flip", "hsv") if hbm else ("img", "flip", "hsv")
+
+        def stage(item):
+            """Consumer's thread: enqueue the host->device copies of a produced batch on the copy stream."""
+            if isinstance(item, BaseException):
+                raise item
+            if item is None:
+                return None
+            batch, slot = item
+            ev = self._to_device(batch, keys) if dev else None
+            return batch, slot, ev
+
+        def release(slot, ev):
+            if slot is not None:
+                if ev is not None:
+                    ev.synchronize()  # the copy out of this pinned slot was enqueued a whole step ago
+                free.put(slot)
+
         t = threading.Thread(target=produce, daemon=True)
         t.start()
         try:
-            while True:
-                b = q.get()
-                if b is None:
-                    break
-                if isinstance(b, BaseException):
-                    raise b
-                ev = b.pop("_ready", None)
-                if ev is not None:
+            cur_item = stage(q.get())
+            done = cur_item is None
+            while not done:
+                nxt, have_next = None, False
+                try:  # batch k+1 already produced: its copy goes out before step k starts and overlaps it
+                    nxt, have_next = stage(q.get_nowait()), True
+                except queue.Empty:
+                    pass
+                b, slot, ev = cur_item
+                ready = b.pop("_ready", None)
+                if ready is not None:
                     cur = torch.cuda.current_stream(self.device)
-                    cur.wait_event(ev)
+                    cur.wait_event(ready)
                     # device tensors allocated under the copy stream: tell the caching allocator that the consumer's stream
                     # reads them, or a block could be handed to a later copy while queued kernels still need it
                     for k in b.pop("_moved", ()):
                         if torch.is_tensor(b[k]) and b[k].is_cuda and b[k] is not getattr(self, "_pool", None):
                             b[k].record_stream(cur)
                 yield b
+                if not have_next:
+                    nxt = stage(q.get())
+                release(slot, ev)
+                cur_item, done = nxt, nxt is None
         finally:
             stop.set()
             while t.is_alive():

@@ -26,7 +26,7 @@ class DetectionTrainer:
         self.model = model
         self.world_size = int(os.environ.get("WORLD_SIZE", 1))
         self.rank = int(os.environ.get("RANK", 0))
-        init_seeds(self.args.seed + 1 + (RANK if RANK >= 0 else -1) + 1, self.args.deterministic)
+        init_seeds(self.args.seed + 1 + RANK, self.args.deterministic)  # reference engine/trainer.py:526 (RANK = -1 single process)
         self.device = select_device(self.args.device)
         self.plan = self.ema = None
         self.lf = None
@@ -56,8 +56,8 @@ class DetectionTrainer:
         self.wd = a.weight_decay * global_bs * self.accumulate / a.nbs
         iterations = math.ceil(batches_per_epoch * batch_size / max(global_bs, a.nbs)) * a.epochs
         name, self.lr0, self.momentum = self._optimizer_choice(iterations, self.model.model[-1].nc)
-        self.plan = StepPlan(self.model, batch_size, imgsz, nmax=getattr(a, "nmax", 16) or 16, optimizer=name, world_size=self.world_size,
-                             use_graph=bool(a.hipgraph), init_scale=float(a.loss_scale) if a.amp else 1.0)
+        self.plan = StepPlan(self.model, batch_size, imgsz, nmax=getattr(a, "nmax", None) or 16, optimizer=name, world_size=self.world_size,
+                             use_graph=bool(a.hipgraph), init_scale=float(a.loss_scale) if a.amp else 1.0, dynamic_scale=bool(a.amp))
         bl = self.plan.crit.bbox_loss
         bl.use_wiseiou, bl.nwd_loss, bl.iou_ratio = bool(a.wiou), bool(a.nwd), float(a.iou_ratio)
         self.ema = ModelEMA(self.plan)
@@ -96,7 +96,18 @@ class DetectionTrainer:
         a = self.args
         if epochs is not None:
             a.epochs = epochs
+        if a.multi_scale:
+            raise NotImplementedError("multi_scale=True: the recorded launch list has one input size (reference detect/train.py:61-73 "
+                                      "re-interpolates every batch); train at a fixed imgsz")
+        if a.resume:
+            raise NotImplementedError("resume: optimizer state is not carried in this package's checkpoints (reference "
+                                      "engine/trainer.py:1050-1105); load the weights with YOLO(<ckpt>) and start a new schedule")
         nb = len(loader)
+        if not getattr(a, "nmax", None):  # per-image label capacity from the first batch, with head-room; exceeded later -> raises
+            from ..utils.loss import v8DetectionLoss
+            first = next(iter(loader))
+            a.nmax = max(16, 2 * v8DetectionLoss.capacity_for(first, batch_size))
+            del first
         self.setup(nb, batch_size, imgsz)
         hist = []
         for epoch in range(a.epochs):
@@ -115,6 +126,7 @@ class DetectionTrainer:
                     tloss = items if tloss is None else (tloss * i + items) / (i + 1)
             torch.cuda.synchronize()
             _, items = self.plan.loss_items()
+            self.plan.check_progress()  # raises when optimizer steps are not taking effect (counter stuck, all skipped, scale collapsed)
             hist.append(items if tloss is None else tloss)
             if self.rank == 0:
                 LOGGER.info(f"epoch {epoch + 1}/{a.epochs}  box/cls/dfl {[round(float(x), 4) for x in hist[-1]]}  "

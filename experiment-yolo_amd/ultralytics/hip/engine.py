@@ -28,13 +28,26 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+# Debug switch (tests/test_gpu_poison.py, env DY_POISON=1): every buffer the engine hands out uninitialised is filled with
+# 0xFF bytes -- NaN as fp16 / fp32, -1 as an integer -- so that a kernel reading memory nothing wrote shows up as a NaN in
+# the losses / gradients instead of depending on what the caching allocator happened to return.
+POISON = os.environ.get("DY_POISON", "0") == "1"
+
+
+def dev_empty(shape, dtype, device):
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if POISON and t.numel():
+        t.view(-1).view(torch.uint8).fill_(0xFF)
+    return t
+
+
 class Storage:
     """(N,H,W,C) fp16 buffer with an optional gradient twin and a record of which channel ranges of the twin hold data."""
 
     def __init__(self, eng, N, H, W, C, dtype=torch.float16):
         assert C % 8 == 0, f"channel count {C} must be a multiple of 8"
         self.eng, self.N, self.H, self.W, self.C = eng, N, H, W, C
-        self.buf = torch.empty((N, H, W, C), dtype=dtype, device=eng.device)
+        self.buf = dev_empty((N, H, W, C), dtype, eng.device)
         self.gbuf = None
         self.gwritten = []  # list of (c0, c1) already holding gradient
 
@@ -67,7 +80,7 @@ class Act:
     def _gbuf(self):
         st = self.st
         if st.gbuf is None:
-            st.gbuf = torch.empty_like(st.buf)
+            st.gbuf = dev_empty(st.buf.shape, st.buf.dtype, st.buf.device)
             st.eng.hold(st.gbuf)
         return st.gbuf
 
@@ -222,9 +235,11 @@ class Engine:
         if t is None or t.numel() < nbytes:
             # growing is safe while recording: launches already recorded keep using the old (kept-alive) buffer, and
             # scratch carries no state from one op to the next
-            t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+            t = dev_empty(max(nbytes, 1 << 20), torch.uint8, self.device)
             self._scratch[key] = t
             self.keep.append(t)
+        elif POISON:  # scratch carries no state between ops: what the previous user left is as undefined as fresh memory
+            t.fill_(0xFF)
         return t
 
     def new_storage(self, N, H, W, C, dtype=torch.float16):
@@ -236,7 +251,7 @@ class Engine:
         return self.new_storage(N, H, W, C).act()
 
     def f32(self, n, fill=None):
-        t = torch.empty(n, dtype=torch.float32, device=self.device) if fill is None else torch.full(
+        t = dev_empty(n, torch.float32, self.device) if fill is None else torch.full(
             (n,), float(fill), dtype=torch.float32, device=self.device)
         self.keep.append(t)
         return t
@@ -383,7 +398,7 @@ class Engine:
         if self.side_wgrad and self.deferred_wgrad is not None:
             # the weight gradient reads this buffer on the side stream while the main stream moves on to the next layer:
             # it cannot be the shared scratch
-            draw = torch.empty(npix * spec.cout, dtype=torch.float16, device=self.device)
+            draw = dev_empty(npix * spec.cout, torch.float16, self.device)
             self.hold(draw)
         else:
             draw = self.scratch("draw", npix * spec.cout * 2)
@@ -400,7 +415,7 @@ class Engine:
         self.L.dy_wgrad_workspace(x.N, x.H, x.W, spec.cin, spec.cout, spec.ks, spec.stride, C.byref(ns), C.byref(se))
         deferred = defer and not accumulate_w and self.deferred_wgrad is not None
         if deferred:
-            slabs = torch.empty(ns.value * se.value, dtype=torch.float32, device=self.device)
+            slabs = dev_empty(ns.value * se.value, torch.float32, self.device)
             self.hold(slabs)
             self.deferred_wgrad.append((spec, slabs, ns.value))
             dw = 0
@@ -489,7 +504,7 @@ class Engine:
         return y
 
     def maxpool5(self, x: Act, out: Act):
-        arg = torch.empty(x.npix * x.C, dtype=torch.uint8, device=self.device)
+        arg = dev_empty(x.npix * x.C, torch.uint8, self.device)
         self.hold(arg)
         self.call("dy_maxpool5", x.ptr, x.ld, out.ptr, out.ld, arg.data_ptr(), x.N, x.H, x.W, x.C)
         if self.tape is not None:
@@ -639,7 +654,7 @@ class Engine:
     # ---- LDConv (reference nn/modules/conv.py:366-410) -----------------------------------------------------------
     def ldconv(self, sp_p: ConvSpec, sp_c: ConvSpec, pn_i32, Np, stride, x: Act, out: Act | None = None):
         h, w = self.out_hw(sp_p, x)
-        off = torch.empty((x.N, h, w, 2 * Np), dtype=torch.float32, device=self.device)
+        off = dev_empty((x.N, h, w, 2 * Np), torch.float32, self.device)
         self.hold(off)
         doff = None
         if self.tape is not None:

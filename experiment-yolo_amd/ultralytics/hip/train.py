@@ -22,7 +22,7 @@ from .engine import Recorder
 
 class StepPlan:
     def __init__(self, model, batch_size, imgsz, nmax=16, optimizer="SGD", hyp=None, world_size=1, use_graph=False,
-                 init_scale=65536.0, side_wgrad=None):
+                 init_scale=65536.0, side_wgrad=None, dynamic_scale=True):
         self.model = model
         # weight gradients on a second stream beside the input-gradient chain (env DY_SIDE_WGRAD=0/1 overrides the default)
         self.side_wgrad = bool(int(os.environ.get("DY_SIDE_WGRAD", "0"))) if side_wgrad is None else bool(side_wgrad)
@@ -57,6 +57,8 @@ class StepPlan:
         self.graph_fb = None
         self.gsum, self._micro = None, 0
         self.ema_updates = 0
+        self.dynamic_scale = bool(dynamic_scale)  # False (amp=False): the loss scale is a constant, nothing ever halves it
+        self.opt_calls = 0                        # optimizer_step() calls so far; the device counts taken + skipped (state[5], state[6])
         self.rt.refresh_frozen()
 
     # ---- host-side schedule ------------------------------------------------------------------------------------
@@ -64,7 +66,7 @@ class StepPlan:
         h = self.hyper_host
         if ema_decay is None:
             ema_decay = 0.9999 * (1 - math.exp(-(self.ema_updates + 1) / 2000))
-        vals = [*lr, momentum, *wd, ema_decay, max_norm, beta2, eps]
+        vals = [*lr, momentum, *wd, ema_decay, max_norm, beta2, eps, 1.0 if self.dynamic_scale else 0.0]
         for i, v in enumerate(vals):
             h[i] = float(v)
         check(lib().dy_set_hyper(self.hyper.data_ptr(), h, torch.cuda.current_stream(self.hyper.device).cuda_stream), "dy_set_hyper")
@@ -146,17 +148,41 @@ class StepPlan:
             raise RuntimeError(f"{n} targets exceed the plan capacity {self.B}x{self.nmax}")
         self.crit.sync_modes()
         if self.rec_fb is None:
+            pre = (self.rt.flat_b.clone(), self.crit.scalars.clone()) if self.use_graph else None
             self.rec_fb = self._trace_fb(batch)
             if self.use_graph:
                 torch.cuda.synchronize()
                 self.graph_fb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
                     self.eng.replay(self.rec_fb)
+                self._verify_capture(*pre)
         elif self.graph_fb is not None:
             self.graph_fb.replay()
         else:
             self.eng.replay(self.rec_fb)
         return self.crit.scalars
+
+    def _verify_capture(self, buffers_before, scalars_before):
+        """Replay the freshly captured forward/backward graph once on the traced batch -- from the state the traced step started
+        from (BN running statistics, WIoU running mean), so nothing is applied twice -- and require it to reproduce the traced
+        step.  A capture can come out broken without any error: on this ROCm, device work issued by ANOTHER host thread while a
+        thread-local capture is open produced graphs whose every replay returned non-finite gradients."""
+        want_s, want_g, want_b = self.crit.scalars.clone(), self.rt.flat_g.clone(), self.rt.flat_b.clone()
+        self.rt.flat_b.copy_(buffers_before)
+        self.crit.scalars.copy_(scalars_before)
+        self.graph_fb.replay()
+        torch.cuda.synchronize()
+        got_s, got_g = self.crit.scalars, self.rt.flat_g
+        ds = float((got_s[5:9] - want_s[5:9]).abs().max() / want_s[5:9].abs().max().clamp_min(1e-12))
+        finite = bool(torch.isfinite(got_g).all()) or not bool(torch.isfinite(want_g).all())
+        # LDConv's far-sample side pass adds with fp32 atomics: gradients repeat to rounding order only (1e-3); all else is exact
+        dg = float((got_g - want_g).norm() / want_g.norm().clamp_min(1e-30)) if finite else float("inf")
+        db = float((self.rt.flat_b - want_b).abs().max() / want_b.abs().max().clamp_min(1e-12))
+        if not (ds <= 1e-5 and dg <= 2e-2 and db <= 1e-5):
+            self.graph_fb = self.rec_fb = None
+            raise RuntimeError("the captured step graph does not reproduce the traced step (loss items off by "
+                               f"{ds:.2e}, gradients by {dg:.2e}, BN statistics by {db:.2e} relative): was another host thread issuing "
+                               "device work during the capture?")
 
     # ---- optimizer ----------------------------------------------------------------------------------------------
     def all_reduce(self):
@@ -205,8 +231,27 @@ class StepPlan:
         else:
             eng.replay(self.rec_opt[key])
         self.ema_updates += 1
+        self.opt_calls += 1
         self._micro = 0
         rt.mark_dirty()
+
+    def check_progress(self):
+        """Fail loudly when optimizer steps do not take effect (synchronises; the trainer calls it where it already does: at
+        epoch end).  The device counts the steps it applied (state[5]) and the ones it skipped for non-finite gradients
+        (state[6]); a run whose steps are all skipped trains nothing and would otherwise only show as a flat loss curve."""
+        st = self.state.cpu().tolist()
+        scale, taken, skipped = st[0], int(st[5]), int(st[6])
+        if taken + skipped != self.opt_calls:
+            raise RuntimeError(f"optimizer step counter out of step with the host: {self.opt_calls} optimizer_step() calls, device took "
+                               f"{taken} and skipped {skipped} -- the recorded optimizer launches are not executing")
+        if not self.dynamic_scale and skipped:
+            raise RuntimeError(f"{skipped} of {self.opt_calls} optimizer steps were skipped for non-finite gradients at the fixed loss "
+                               f"scale {scale:g} (amp=False): the gradients are corrupt or overflow fp16 -- nothing was learned from them")
+        if self.dynamic_scale and (scale < 1.0 or (self.opt_calls >= 32 and taken == 0)):
+            raise RuntimeError(f"dynamic loss scale collapsed to {scale:g} ({skipped} of {self.opt_calls} optimizer steps skipped): "
+                               "gradients stay non-finite however small the scale")
+        self.crit.check_capacity()
+        return taken, skipped, scale
 
     def step(self, batch, lr, momentum, wd):
         """forward/backward + gradient all-reduce + optimizer/EMA: one iteration at accumulate == 1."""
@@ -218,6 +263,7 @@ class StepPlan:
     def loss_items(self):
         """(loss*B, [box, cls, dfl]) -- synchronises."""
         s = self.crit.scalars.cpu()
+        self.crit.check_capacity(s)
         return float(s[8]), s[5:8].clone()
 
     # ---- measurement helpers (bench.py) -------------------------------------------------------------------------

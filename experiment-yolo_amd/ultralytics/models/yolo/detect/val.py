@@ -11,6 +11,7 @@ import torch
 from ....hip import check, lib
 from ....utils import LOGGER, ops
 from ....utils.metrics import DetMetrics
+from ....hip.engine import dev_empty
 
 
 class DetectionValidator:
@@ -80,7 +81,7 @@ class DetectionValidator:
         tidx = batch["batch_idx"].reshape(-1).float().contiguous()
         tbox = batch["bboxes"].reshape(-1, 4).float().contiguous()
         tp = torch.zeros((ntot, self.niou), dtype=torch.uint8, device=dev)
-        predn = torch.empty((ntot, 6), dtype=torch.float32, device=dev)
+        predn = dev_empty((ntot, 6), torch.float32, dev)
         if ntot:
             geom = torch.from_numpy(self._geometry(batch, B, imgsz)).to(dev)
             offd = torch.from_numpy(off).to(dev)

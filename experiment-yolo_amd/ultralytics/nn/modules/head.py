@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from ...hip import DY_ACT_NONE
+from ...hip.engine import dev_empty
 from ...hip.runtime import HipModule
 from .block import DFL
 from .conv import Conv
@@ -89,10 +90,10 @@ class Detect(HipModule):
         eng = rt.eng
         ncp = (self.nc + 7) // 8 * 8
         nb = 4 * self.reg_max
-        boxes = [torch.empty((x.N, x.H, x.W, nb), dtype=torch.float32, device=eng.device) for x in xs]
+        boxes = [dev_empty((x.N, x.H, x.W, nb), torch.float32, eng.device) for x in xs]
         # the 1x1 class conv writes channels [0, nc): padding channels (nc rounded up to 8) need a defined value only if they exist
-        alloc = torch.empty if ncp == self.nc else torch.zeros
-        clss = [alloc((x.N, x.H, x.W, ncp), dtype=torch.float32, device=eng.device) for x in xs]
+        clss = [dev_empty((x.N, x.H, x.W, ncp), torch.float32, eng.device) if ncp == self.nc else
+                torch.zeros((x.N, x.H, x.W, ncp), dtype=torch.float32, device=eng.device) for x in xs]
         eng.hold(*boxes, *clss)
         ho = HeadOut(boxes, clss, self.nc, [float(s) for s in self.stride])
         if eng.tape is not None:

@@ -22,6 +22,7 @@ import torch
 
 from ..hip import check, lib
 from . import ops
+from ..hip.engine import dev_empty
 
 CONF_THRESHOLD = 0.25       # double_inference.py:25
 NMS_IOU_THRESHOLD = 0.45    # :27
@@ -63,7 +64,7 @@ def prepare_cropped_images(image, crop_infos, size=CROP_SIZE):
     geos = [crop_geometry(c, size) for c in crop_infos]
     assert all(g is not None and g["new_size"][0] > 0 and g["new_size"][1] > 0 for g in geos), "filter empty crops first"
     K = len(crop_infos)
-    out = torch.empty((K, size, size, 3), dtype=torch.uint8, device=image.device)
+    out = dev_empty((K, size, size, 3), torch.uint8, image.device)
     if K:
         rects = torch.tensor([[c["x1"], c["y1"], c["x2"], c["y2"]] for c in crop_infos], dtype=torch.int32).to(image.device)
         geom = torch.tensor([[g["new_size"][0], g["new_size"][1], g["pad_x"], g["pad_y"]] for g in geos], dtype=torch.int32).to(image.device)

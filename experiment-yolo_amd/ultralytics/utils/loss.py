@@ -85,7 +85,8 @@ class v8DetectionLoss:
         a.scalars = self.scalars.data_ptr()
         need = L.dy_loss_workspace_bytes(a.B, A, nmax)
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            from ..hip.engine import dev_empty
+            self._ws = dev_empty(need, torch.uint8, self.device)
         a.workspace = self._ws.data_ptr()
         self.A = A
         return a
@@ -112,6 +113,16 @@ class v8DetectionLoss:
         self._ncount.fill_(n)
         a.n_targets_dev = self._ncount.data_ptr()
         return n
+
+    def check_capacity(self, scalars_host=None):
+        """Raise if any image since the last check carried more labels than the per-image capacity ``nmax`` the loss kernels
+        were bound with (the packing kernel drops the surplus and raises the sticky flag scalars[10]).  The reference pads to
+        ``counts.max()`` (utils/loss.py:337-343) and never drops a label.  Synchronises unless the scalars are passed in."""
+        s = self.scalars.cpu() if scalars_host is None else scalars_host
+        if float(s[10]) != 0.0:
+            self.scalars[10] = 0.0
+            raise RuntimeError(f"an image carried more than nmax={self._args.nmax} labels: the surplus ground truth was dropped. "
+                               "Raise nmax (cfg key 'nmax', StepPlan(nmax=...)) to at least the largest per-image label count")
 
     def sync_modes(self):
         a, b = self._args, self.bbox_loss

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from ..hip import check, lib
+from ..hip.engine import dev_empty
 
 
 def box_iou(box1, box2, eps=1e-7):
@@ -20,7 +21,7 @@ def box_iou(box1, box2, eps=1e-7):
     if eps != 1e-7:
         raise NotImplementedError("box_iou: eps is fixed at the reference default 1e-7")
     a, b = box1.float().contiguous(), box2.float().contiguous()
-    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    out = dev_empty((a.shape[0], b.shape[0]), torch.float32, a.device)
     check(lib().dy_box_iou(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(),
                            torch.cuda.current_stream(a.device).cuda_stream), "dy_box_iou")
     return out

@@ -6,6 +6,7 @@ import ctypes as C
 import torch
 
 from ..hip import check, lib
+from ..hip.engine import dev_empty
 
 __all__ = ("non_max_suppression", "soft_nms", "decode_predictions", "xywh2xyxy", "xyxy2xywh", "make_divisible")
 
@@ -43,7 +44,7 @@ def decode_predictions(ho):
     nl, dev = len(ho.box), ho.box[0].device
     B = ho.box[0].shape[0]
     A = sum(b.shape[1] * b.shape[2] for b in ho.box)
-    y = torch.empty((B, 4 + ho.nc, A), dtype=torch.float32, device=dev)
+    y = dev_empty((B, 4 + ho.nc, A), torch.float32, dev)
     PP = C.c_void_p * nl
     box, cls = PP(*[b.data_ptr() for b in ho.box]), PP(*[c.data_ptr() for c in ho.cls])
     H = (C.c_int * nl)(*[b.shape[1] for b in ho.box])
@@ -65,7 +66,7 @@ def soft_nms(bboxes, scores, iou_thresh=0.5, sigma=0.5, score_threshold=0.25):
     b = bboxes.reshape(n, 4).float().contiguous()
     s = scores if (scores.dtype == torch.float32 and scores.is_contiguous()) else scores.float().contiguous()
     cnt = torch.tensor([n], dtype=torch.int32, device=dev)
-    oa, ob, keep = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
+    oa, ob, keep = (dev_empty(n, torch.int32, dev) for _ in range(3))
     nk = torch.zeros(1, dtype=torch.int32, device=dev)
     check(lib().dy_soft_nms(b.data_ptr(), s.data_ptr(), 0, cnt.data_ptr(), oa.data_ptr(), ob.data_ptr(), keep.data_ptr(),
                             nk.data_ptr(), 1, n, float(iou_thresh), float(sigma), float(score_threshold), 0.0, _stream(dev)),
@@ -97,9 +98,9 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     dev = pred.device
     multi_label = bool(multi_label) and nc > 1
     cap = A * (nc if multi_label else 1)
-    cbox = torch.empty((B, cap, 4), dtype=torch.float32, device=dev)
-    csc = torch.empty((B, cap), dtype=torch.float32, device=dev)
-    ccl = torch.empty((B, cap), dtype=torch.float32, device=dev)
+    cbox = dev_empty((B, cap, 4), torch.float32, dev)
+    csc = dev_empty((B, cap), torch.float32, dev)
+    ccl = dev_empty((B, cap), torch.float32, dev)
     cnt = torch.zeros(B, dtype=torch.int32, device=dev)
     cls_t = torch.tensor(list(classes), dtype=torch.int32, device=dev) if classes is not None else None
     L, st = lib(), _stream(dev)
@@ -115,7 +116,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
                 cbox[b, :max_nms], csc[b, :max_nms], ccl[b, :max_nms] = cbox[b, idx], csc[b, idx], ccl[b, idx]
                 cnt[b] = max_nms
         counts = cnt.cpu()
-    oa, ob, keep = (torch.empty((B, cap), dtype=torch.int32, device=dev) for _ in range(3))
+    oa, ob, keep = (dev_empty((B, cap), torch.int32, dev) for _ in range(3))
     nk = torch.zeros(B, dtype=torch.int32, device=dev)
     check(L.dy_soft_nms(cbox.data_ptr(), csc.data_ptr(), ccl.data_ptr(), cnt.data_ptr(), oa.data_ptr(), ob.data_ptr(), keep.data_ptr(),
                         nk.data_ptr(), B, cap, float(iou_thres), 0.5, 0.25, 0.0 if agnostic else float(max_wh), st), "dy_soft_nms")

@@ -261,3 +261,48 @@ def test_train_and_val_from_a_dataset_yaml(tmp_path):
                               val=False, cache=cache, **{**zero, "fliplr": 0.5}))
         assert (y2.trainer.plan.pool is not None) == (cache == "hbm")
     np.testing.assert_array_equal(np.asarray(hists[0], dtype=np.float64), np.asarray(hists[1], dtype=np.float64))
+
+
+@pytest.mark.parametrize("cache", [False, "hbm"])
+def test_only_the_consumer_thread_calls_into_hip(tmp_path, monkeypatch, cache):
+    """The threading rule of the loader: decode workers and the producer thread do host work only; every
+    device allocation, host->device copy, pinning and event comes from the thread that launches the step's hipGraphs.  (A
+    second thread enqueuing copies while hipGraphLaunch runs corrupted a gradient buffer of the replayed graph on this ROCm:
+    every optimizer step was skipped and the run trained nothing.)"""
+    import threading
+    from ultralytics.cfg import get_cfg
+    from ultralytics.data import build_dataloader, build_yolo_dataset, check_det_dataset
+    root = str(tmp_path / "ds")
+    write_dataset(root)
+    data = check_det_dataset(os.path.join(root, "data.yaml"))
+    geo = dict(mosaic=1.0, translate=0.1, scale=0.5) if cache else dict(mosaic=0.0, translate=0.0, scale=0.0)  # device-side composition
+    args = get_cfg(overrides=dict(imgsz=64, cache=cache, fliplr=0.5, hsv_h=0.015, hsv_s=0.7, hsv_v=0.4, mixup=0.0, copy_paste=0.0,
+                                  perspective=0.0, **geo))
+    ds = build_yolo_dataset(args, data["train"], 4, data, mode="train", layout="nhwc", flip_on_device=True)
+    loader = build_dataloader(ds, 4, 2, shuffle=True, device=torch.device("cuda", 0), drop_last=True)
+    main = threading.get_ident()
+    offenders = []
+
+    def watch(obj, name):
+        orig = getattr(obj, name)
+
+        def wrapped(*a, **k):
+            out = orig(*a, **k)
+            if threading.get_ident() != main and (name != "to" or getattr(out, "is_cuda", False)):  # .to(dtype) on the host is fine
+                offenders.append(name)
+            return out
+        monkeypatch.setattr(obj, name, wrapped)
+
+    for obj, name in ((torch.Tensor, "to"), (torch.Tensor, "cuda"), (torch.Tensor, "pin_memory"), (torch.Tensor, "record_stream"),
+                      (torch.cuda.Event, "record"), (torch.cuda.Event, "synchronize"), (torch.cuda.Event, "wait"),
+                      (torch.cuda.Stream, "wait_event"), (torch.cuda.Stream, "synchronize"), (torch.cuda, "synchronize"),
+                      (torch.cuda, "current_stream")):
+        watch(obj, name)
+    seen = 0
+    for epoch in range(2):
+        loader.set_epoch(epoch)
+        for b in loader:
+            assert b["img"].is_cuda and all(b[k].is_cuda for k in ("flip", "hsv", "index", "warp") if k in b)
+            seen += 1
+    assert seen == 2 * len(loader) and seen >= 4
+    assert not offenders, f"device API calls from a loader thread: {sorted(set(offenders))}"

@@ -28,6 +28,7 @@ def test_public_api_training_reaches_the_reference_trainers_map(tmp_path, model,
                 perspective=0.0, flipud=0.0, fliplr=0.0)
     torch.manual_seed(0)
     y = YOLO(model)
+    w0 = {k: v.detach().clone() for k, v in y.model.state_dict().items() if k.startswith("model.0.") and v.dtype.is_floating_point}
     hist = y.train(data=os.path.join(root, "data.yaml"), epochs=E2E["epochs"], batch=E2E["batch"], imgsz=E2E["imgsz"], workers=2,
                    optimizer="SGD", amp=False, val=True, close_mosaic=0, seed=0, deterministic=True, log_every=1, **zero)
     # amp=False as in the reference run: loss scale 1, no skipped steps.  (With the dynamic loss scale a run this short -- ~30
@@ -37,6 +38,12 @@ def test_public_api_training_reaches_the_reference_trainers_map(tmp_path, model,
     st = y.trainer.plan.state.cpu().numpy()
     print(f"optimizer steps taken {st[5]:.0f}, skipped {st[6]:.0f}, loss scale {st[0]:.0f}, last grad norm {st[3]:.3f}, "
           f"nonfinite grads {int((~torch.isfinite(y.trainer.plan.rt.flat_g)).sum())}")
+    plan = y.trainer.plan
+    # every optimizer_step() the trainer issued took effect: none skipped at amp=False, the device counter advanced with the host's
+    assert st[5] > 0 and st[6] == 0 and st[5] == plan.opt_calls and st[0] == 1.0, st.tolist()
+    w1 = y.trainer.model.state_dict()
+    moved = {k: float((w1[k].cpu() - w0[k].cpu()).abs().max()) for k in w0 if "running" not in k}
+    assert all(v > 0 for v in moved.values()), f"first-layer parameters that never moved: {[k for k, v in moved.items() if v == 0]}"
     for e in (0, 9, 19, 29, 39):
         print(f"epoch {e + 1:2d}  ours box/cls/dfl {np.round(hist[e], 3)}   reference "
               f"{[round(float(ref[k][e]), 3) for k in ('train/box_loss', 'train/cls_loss', 'train/dfl_loss')]}")

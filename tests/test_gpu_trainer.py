@@ -38,3 +38,55 @@ def test_p2_model_fused_inference():
         y, feats = m(torch.rand(2, 3, 128, 128).cuda())
     A = 32 * 32 + 16 * 16 + 8 * 8 + 4 * 4
     assert y.shape == (2, 84, A) and len(feats) == 4 and torch.isfinite(y).all()
+
+
+def _tiny_plan(**kw):
+    from ultralytics.hip.train import StepPlan
+    from ultralytics.nn.tasks import DetectionModel
+    torch.manual_seed(0)
+    m = DetectionModel(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"), verbose=False).cuda().train()
+    plan = StepPlan(m, 2, 64, nmax=8, use_graph=True, **kw)
+    batch = dict(img=torch.rand(2, 3, 64, 64), batch_idx=torch.tensor([0., 0., 1.]), cls=torch.tensor([[1.], [2.], [3.]]),
+                 bboxes=torch.tensor([[.5, .5, .3, .3], [.3, .6, .2, .2], [.6, .4, .4, .3]]))
+    return plan, batch
+
+
+def test_steps_that_do_not_take_effect_fail_loudly():
+    """A run whose optimizer steps are all skipped (non-finite gradients) or not executed must raise where the trainer already
+    synchronises, not show up as a flat loss curve (the silent no-training run of round 1)."""
+    plan, batch = _tiny_plan(init_scale=1.0, dynamic_scale=False)  # amp=False
+    for _ in range(3):
+        plan.step(batch, [0.01] * 3, 0.9, [0.0, 5e-4, 0.0])
+    assert plan.check_progress()[:2] == (3, 0)
+    plan.rt.flat_g[5] = float("nan")  # what a corrupted gradient buffer looks like to the optimizer
+    plan.set_hyper([0.01] * 3, 0.9, [0.0] * 3)
+    plan.optimizer_step()
+    assert float(plan.state[0]) == 1.0, "amp=False: the loss scale is a constant"
+    with pytest.raises(RuntimeError, match="skipped for non-finite gradients"):
+        plan.check_progress()
+    plan2, batch = _tiny_plan(init_scale=1.0, dynamic_scale=False)
+    plan2.step(batch, [0.01] * 3, 0.9, [0.0] * 3)
+    plan2.opt_calls += 1  # a recorded optimizer launch that never ran on the device
+    with pytest.raises(RuntimeError, match="out of step with the host"):
+        plan2.check_progress()
+    plan3, batch = _tiny_plan(init_scale=4.0, dynamic_scale=True)  # amp=True: a scale search is normal, a collapse is not
+    plan3.forward_backward(batch)
+    for _ in range(4):
+        plan3.rt.flat_g[5] = float("inf")
+        plan3.set_hyper([0.01] * 3, 0.9, [0.0] * 3)
+        plan3.optimizer_step()
+    with pytest.raises(RuntimeError, match="loss scale collapsed"):
+        plan3.check_progress()
+
+
+def test_more_labels_than_capacity_raises():
+    """one image above nmax while the batch total stays under B*nmax used to train on silently truncated labels."""
+    plan, batch = _tiny_plan(init_scale=1.0)
+    n = 10  # nmax = 8, B*nmax = 16
+    batch = dict(img=batch["img"], batch_idx=torch.zeros(n), cls=torch.zeros(n, 1),
+                 bboxes=torch.cat([torch.rand(n, 2) * 0.5 + 0.25, torch.rand(n, 2) * 0.2 + 0.05], 1))
+    plan.forward_backward(batch)
+    with pytest.raises(RuntimeError, match="more than nmax=8 labels"):
+        plan.loss_items()
+    plan.forward_backward(dict(batch, batch_idx=torch.tensor([0., 1.] * 5)))  # five per image: fits, and the flag was cleared
+    plan.loss_items()
