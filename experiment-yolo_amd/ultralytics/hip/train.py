@@ -87,6 +87,7 @@ class StepPlan:
                 x = eng.import_image_u8(self.img, 8, self.flip, None, self.hsv) if self.input_u8 else eng.import_image(self.img, 8)
             ho = model.forward_act(x)
             crit.bind(ho, self.nmax, gscale=self.state[0:1])
+            crit.__dict__["_last"] = crit
             crit.sync_modes()
             eng.call("dy_detection_loss", C.byref(crit._args))
             eng.deferred_wgrad = []

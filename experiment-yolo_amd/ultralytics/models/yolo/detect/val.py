@@ -85,13 +85,14 @@ class DetectionValidator:
         if ntot:
             geom = torch.from_numpy(self._geometry(batch, B, imgsz)).to(dev)
             offd = torch.from_numpy(off).to(dev)
-            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            if getattr(self, "_status", None) is None or self._status.device != dev:
+                self._status = torch.zeros(1, dtype=torch.int32, device=dev)  # ONE word for the whole run: every batch ORs into it
+            status = self._status
             iouv = self.iouv.to(dev)
             check(lib().dy_match_predictions(packed.data_ptr(), offd.data_ptr(), tidx.data_ptr(), tcls.data_ptr(), tbox.data_ptr(),
                                              tcls.numel(), geom.data_ptr(), iouv.data_ptr(), self.niou, B, imgsz[0], imgsz[1],
                                              tp.data_ptr(), predn.data_ptr(), status.data_ptr(),
                                              torch.cuda.current_stream(dev).cuda_stream), "dy_match_predictions")
-            self._status = status
         self.seen += B
         # images with neither predictions nor labels contribute nothing; label-only images contribute their target classes
         self.stats["tp"].append(tp.bool())
@@ -103,6 +104,7 @@ class DetectionValidator:
 
     def get_stats(self):
         if getattr(self, "_status", None) is not None and int(self._status.item()) & 1:
+            self._status.zero_()
             raise RuntimeError("an image carried more than 1024 labels (dy_match_predictions capacity)")
         stats = {k: torch.cat(v, 0).cpu().numpy() for k, v in self.stats.items() if len(v)}
         if len(stats) and stats["tp"].any():

@@ -239,10 +239,24 @@ class BaseModel(HipModule):
         return len(csd)
 
     def loss(self, batch, preds=None):
-        """Reference tasks.py:256-268: lazily build the criterion, run forward + loss."""
+        """Reference tasks.py:256-268: lazily build the criterion, ``preds = self.forward(batch["img"]) if preds is None else
+        preds``, ``return self.criterion(preds, batch)`` -> (loss.sum()*B, loss_items[box, cls, dfl]).  The forward keeps the raw
+        head outputs on the engine (no NCHW re-formatting); values only -- gradients are produced by ``StepPlan``."""
         if not hasattr(self, "criterion"):
             self.criterion = self.init_criterion()
-        return self.criterion(self, batch, preds)
+        if preds is None:
+            img = batch["img"]
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("the HIP hot path runs on the GPU only: move the model with .cuda() first (no CPU fallback)")
+            rt = self._runtime(dev)
+            rt.eng.training = self.training
+            with torch.no_grad():
+                rt.ensure_packed()
+                if img.dtype == torch.uint8:
+                    img = img.float() / 255
+                preds = self.forward_act(rt.to_act(img.to(dev)))
+        return self.criterion(preds, batch)
 
     def init_criterion(self):
         raise NotImplementedError

@@ -138,28 +138,61 @@ class v8DetectionLoss:
         return max(8, (int(counts.max()) + 7) // 8 * 8)
 
     def __call__(self, preds, batch):
-        """(loss.sum()*B, loss_items[box, cls, dfl]) as device tensors (reference utils/loss.py:356-361)."""
+        """(loss.sum()*B, loss_items[box, cls, dfl]) as device tensors (reference utils/loss.py:356-361).  ``preds``: the HIP
+        path's HeadOut, or the reference's list of (B, no, H, W) maps / eval-mode (y, feats) tuple.  Runs on its own argument
+        block, workspace and target buffers, so a call between two steps of a recorded StepPlan (which replays launches bound
+        to THIS object's buffers) disturbs nothing; the running WIoU mean and the result scalars are shared, as in the
+        reference where the criterion is one object."""
         from ..nn.modules.head import HeadOut
         if not isinstance(preds, HeadOut):
-            raise TypeError("v8DetectionLoss expects the HeadOut produced by Detect on the HIP path")
-        eng_stream = torch.cuda.current_stream(self.device).cuda_stream
+            preds = self._headout_from_reference(preds)
+        pub = self.__dict__.get("_pub")
+        if pub is None:
+            pub = object.__new__(type(self))
+            pub.__dict__.update({k: v for k, v in self.__dict__.items() if k != "_pub"})
+            pub._args, pub._ws, pub._tgt, pub._ncount = DyLossArgs(), None, None, None
+            self._pub = pub
+        pub.box_gain, pub.cls_gain, pub.dfl_gain = self.box_gain, self.cls_gain, self.dfl_gain
         B = preds.box[0].shape[0]
-        self.bind(preds, self.capacity_for(batch, B))
-        self.set_targets(batch)
-        self.sync_modes()
+        pub.bind(preds, self.capacity_for(batch, B))
+        pub.set_targets(batch)
+        pub.sync_modes()
         from ..hip import lib
-        check(lib().dy_detection_loss(C.byref(self._args), eng_stream), "dy_detection_loss")
+        check(lib().dy_detection_loss(C.byref(pub._args), torch.cuda.current_stream(self.device).cuda_stream), "dy_detection_loss")
+        self._last = pub
         return self.scalars[8].clone(), self.scalars[5:8].clone()
+
+    def _headout_from_reference(self, preds):
+        """The reference's ``preds`` protocol (utils/loss.py:356-368): the list of per-level ``(B, no, H, W)`` maps the head
+        returns in training mode, or the ``(y, feats)`` tuple of eval mode (``feats = preds[1] if isinstance(preds, tuple)``).
+        Re-laid as the kernels' fp32 NHWC (B,H,W,64) box logits + (B,H,W,ncp) class logits.  Loss values only."""
+        from ..nn.modules.head import HeadOut, LazyFeats
+        feats = preds[1] if isinstance(preds, tuple) else preds
+        if isinstance(feats, LazyFeats):
+            return feats._ho
+        if not isinstance(feats, (list, tuple)) or not all(torch.is_tensor(f) and f.dim() == 4 and f.shape[1] == self.no for f in feats):
+            raise TypeError(f"v8DetectionLoss expects the head's training output: a list of (B, {self.no}, H, W) tensors "
+                            "(or the HeadOut of the HIP path)")
+        nb, ncp = self.reg_max * 4, (self.nc + 7) // 8 * 8
+        box, cls = [], []
+        for f in feats:
+            f = f.detach().to(self.device, torch.float32).permute(0, 2, 3, 1)
+            box.append(f[..., :nb].contiguous())
+            c = torch.zeros((*f.shape[:3], ncp), dtype=torch.float32, device=self.device)
+            c[..., :self.nc] = f[..., nb:]
+            cls.append(c)
+        return HeadOut(box, cls, self.nc, [float(s) for s in self.stride])
 
     def debug_assignment(self):
         """(target_gt_idx (B,A) with -1 for background, target score (B,A), pred boxes (B,A,4)) of the last call."""
         from ..hip import lib
-        a = self._args
+        own = self.__dict__.get("_last", self)  # the public call works on its own buffers, a StepPlan on this object's
+        a = own._args
         o = [C.c_size_t() for _ in range(3)]
-        lib().dy_loss_workspace_layout(a.B, self.A, a.nmax, *[C.byref(x) for x in o])
-        BA = a.B * self.A
-        ws = self._ws
-        pb = ws[o[0].value:o[0].value + BA * 16].view(torch.float32).view(a.B, self.A, 4)
-        gt = ws[o[1].value:o[1].value + BA * 4].view(torch.int32).view(a.B, self.A)
-        ts = ws[o[2].value:o[2].value + BA * 4].view(torch.float32).view(a.B, self.A)
+        lib().dy_loss_workspace_layout(a.B, own.A, a.nmax, *[C.byref(x) for x in o])
+        BA = a.B * own.A
+        ws = own._ws
+        pb = ws[o[0].value:o[0].value + BA * 16].view(torch.float32).view(a.B, own.A, 4)
+        gt = ws[o[1].value:o[1].value + BA * 4].view(torch.int32).view(a.B, own.A)
+        ts = ws[o[2].value:o[2].value + BA * 4].view(torch.float32).view(a.B, own.A)
         return gt.clone(), ts.clone(), pb.clone()

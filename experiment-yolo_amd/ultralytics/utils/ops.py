@@ -97,22 +97,33 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         raise NotImplementedError("mask coefficients are outside the hot path")
     dev = pred.device
     multi_label = bool(multi_label) and nc > 1
-    cap = A * (nc if multi_label else 1)
-    cbox = dev_empty((B, cap, 4), torch.float32, dev)
-    csc = dev_empty((B, cap), torch.float32, dev)
-    ccl = dev_empty((B, cap), torch.float32, dev)
     cnt = torch.zeros(B, dtype=torch.int32, device=dev)
     cls_t = torch.tensor(list(classes), dtype=torch.int32, device=dev) if classes is not None else None
     L, st = lib(), _stream(dev)
-    check(L.dy_nms_candidates(pred.data_ptr(), B, nc, A, float(conf_thres), int(multi_label), 0 if cls_t is None else cls_t.data_ptr(),
-                              0 if cls_t is None else cls_t.numel(), cbox.data_ptr(), csc.data_ptr(), ccl.data_ptr(), cnt.data_ptr(), cap, st),
-          "dy_nms_candidates")
+
+    def candidates(cbox, csc, ccl, cap):
+        check(L.dy_nms_candidates(pred.data_ptr(), B, nc, A, float(conf_thres), int(multi_label), 0 if cls_t is None else cls_t.data_ptr(),
+                                  0 if cls_t is None else cls_t.numel(), 0 if cbox is None else cbox.data_ptr(),
+                                  0 if csc is None else csc.data_ptr(), 0 if ccl is None else ccl.data_ptr(), cnt.data_ptr(), cap, st),
+              "dy_nms_candidates")
+
+    # Pass 1 counts, pass 2 fills buffers sized by the largest count: A*nc slots per image (the multi-label worst case) would be
+    # 5.6 GB for yolov8n-p2 at 1280x1280, batch 32 (BASELINE configs[4]) where a trained model yields a few thousand candidates.
+    candidates(None, None, None, 0)
     counts = cnt.cpu()
-    if int(counts.max()) > max_nms:  # utils/ops.py:395-396: keep the max_nms most confident, in descending order
+    cap = max(int(counts.max()) if B else 0, 8)
+    cbox = dev_empty((B, cap, 4), torch.float32, dev)
+    csc = dev_empty((B, cap), torch.float32, dev)
+    ccl = dev_empty((B, cap), torch.float32, dev)
+    candidates(cbox, csc, ccl, cap)
+    if int(counts.max()) > max_nms:
+        # utils/ops.py:395-396 ``x[x[:, 4].argsort(descending=True)[:max_nms]]``: keep the max_nms most confident, in descending
+        # order.  The reference's argsort is unstable -- the order of EQUAL confidences is unspecified there; here ties keep their
+        # candidate (anchor-major) order.  Host plumbing through torch.sort, outside any timed path.
         for b in range(B):
             n = int(counts[b])
             if n > max_nms:
-                idx = csc[b, :n].argsort(descending=True)[:max_nms]
+                idx = torch.sort(csc[b, :n], descending=True, stable=True).indices[:max_nms]
                 cbox[b, :max_nms], csc[b, :max_nms], ccl[b, :max_nms] = cbox[b, idx], csc[b, idx], ccl[b, idx]
                 cnt[b] = max_nms
         counts = cnt.cpu()

@@ -409,6 +409,43 @@ def gen_fullsize():
     npz("fullsize", **arrs)
 
 
+def gen_fullsize_ld0():
+    """The LD variant at 640x640 in the regime the reference trains it in: LDConv.__init__ zero-initialises p_conv.weight
+    (nn/modules/conv.py:351-359), so |offset| = |p_conv.bias| < 1.  With the random p_conv weights of ``fullsize`` the offsets
+    reach tens of pixels and the reference's own gradients are not a stable function of its inputs (a 1e-4 relative change of the
+    image moves its per-parameter gradient norms by a median of 34 %, measured with the oracle), so gradient parity is pinned here."""
+    arrs = {}
+    name, mi = "yolov8n-LD-P2", 1
+    m = DetectionModel(os.path.join(CFG_DIR, name + ".yaml"), ch=3, verbose=False)
+    m.args = get_cfg(DEFAULT_CFG)
+    g = og.build_graph(og.load_yaml(os.path.join(CFG_DIR, name + ".yaml")))
+    sd = og.fill_state(og.state_layout(g), seed=21 + mi)
+    for k in sd:
+        if k.endswith("p_conv.weight"):
+            sd[k] = torch.zeros_like(sd[k])
+        elif k.endswith("p_conv.bias"):
+            sd[k] = sd[k].clamp(-0.9, 0.9)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    rng = np.random.default_rng(5 + mi)
+    B, nb = 2, 8
+    batch = dict(img=torch.from_numpy(rng.random((B, 3, 640, 640), dtype=np.float32)),
+                 batch_idx=torch.arange(B).repeat_interleave(nb).float(),
+                 cls=torch.from_numpy(rng.integers(0, 6, (B * nb, 1)).astype(np.float32)),
+                 bboxes=torch.from_numpy(np.concatenate([rng.random((B * nb, 2)) * 0.8 + 0.1,
+                                                         rng.random((B * nb, 2)) * 0.08 + 0.01], 1).astype(np.float32)))
+    for k in ("batch_idx", "cls", "bboxes"):
+        arrs[f"{name}/{k}"] = batch[k]
+    m.criterion = m.init_criterion()
+    loss, items = m(batch)
+    arrs[f"{name}/ciou/loss"], arrs[f"{name}/ciou/items"] = loss.detach(), items
+    loss.backward()
+    gn = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    arrs[f"{name}/grad_names"] = np.array(list(gn.keys()))
+    arrs[f"{name}/grad_l2"] = torch.stack([v.norm() for v in gn.values()])
+    npz("fullsize_ld0", **arrs)
+
+
 
 def gen_metrics():
     """Validation path: the reference's own box_iou, BaseValidator.match_predictions (numpy greedy

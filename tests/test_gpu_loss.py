@@ -79,3 +79,44 @@ def test_loss_vs_golden(golden, case, mode):
         assert torch.equal(gt[fg_ref].long(), tgi[fg_ref]), "target_gt_idx"
         assert relerr(ts, G.t(f"{case}/target_scores").sum(-1)) < 1e-5, "target_scores"
         _ = (A, ws)
+
+
+def test_reference_preds_protocol_and_model_batch_call(golden):
+    """The criterion takes the reference's ``preds`` (list of (B, no, H, W) maps, or the eval-mode (y, feats) tuple; reference
+    utils/loss.py:356-368) and ``model(batch_dict)`` runs forward + loss like BaseModel.loss (nn/tasks.py:256-268)."""
+    import os
+    from conftest import CFG_DIR
+    from ultralytics.hip.train import StepPlan
+    from ultralytics.nn.tasks import DetectionModel
+    from ultralytics.utils.loss import v8DetectionLoss
+    G = golden("loss")
+    case = "random5"
+    batch = {k: G.t(f"{case}/{k}") for k in ("batch_idx", "cls", "bboxes")}
+    crit = v8DetectionLoss(_M())
+    feats = [G.t(f"{case}/feat{l}").cuda() for l in range(3)]
+    for preds in (feats, (torch.zeros(1), feats)):
+        loss, items = crit(preds, batch)
+        assert abs(float(loss) - float(G[f"{case}/ciou/loss"])) <= 1e-4 * abs(float(G[f"{case}/ciou/loss"]))
+        assert relerr(items, G.t(f"{case}/ciou/items")) < 1e-4
+    with pytest.raises(TypeError):
+        crit([f[:, :10] for f in feats], batch)
+    # model(batch): same loss items as the recorded training step on the same weights and batch
+    torch.manual_seed(0)
+    m = DetectionModel(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"), verbose=False).cuda().train()
+    rng = torch.Generator().manual_seed(1)
+    b = dict(img=torch.rand(2, 3, 64, 64, generator=rng), batch_idx=torch.tensor([0., 0., 1.]), cls=torch.tensor([[1.], [2.], [3.]]),
+             bboxes=torch.tensor([[.5, .5, .3, .3], [.3, .6, .2, .2], [.6, .4, .4, .3]]))
+    rs = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+    loss, items = m(b)
+    run_after_call = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+    m.load_state_dict(rs, strict=False)  # a train-mode forward moved the BN running statistics, like the reference's does
+    plan = StepPlan(m, 2, 64, nmax=8, init_scale=1.0)
+    plan.forward_backward(b)
+    l2, i2 = plan.loss_items()
+    assert abs(float(loss) - l2) <= 1e-6 * abs(l2) and relerr(items, i2) < 1e-6, (float(loss), l2)
+    assert all(torch.equal(run_after_call[k], v) for k, v in m.state_dict().items() if "running" in k)
+    # a public call between two recorded steps leaves the plan's bound buffers alone
+    m.criterion(feats, batch)
+    plan.forward_backward(b)
+    torch.cuda.synchronize()
+    assert torch.isfinite(plan.crit.scalars[5:9]).all()
