@@ -7,9 +7,13 @@ A "step" is one full training iteration of DEAL-YOLO-N (yolov8n-ASF-P2P2) at 640
 configs[1]): image import, forward, detection loss (TAL + CIoU + DFL + BCE), hand-written backward, gradient all-reduce
 (RCCL, N>1), SGD-nesterov + EMA -- all through libdealyolo_hip.so.  Inputs are synthetic and already resident in HBM.
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     dominant kernel (the 64->64 3x3 @160x160 MFMA conv of the Detect head), algorithmic bytes / launch time
-               measured live with HIP events on the launch stream, against 8 TB/s HBM;
+  roofline     the kernel with the largest total time per step among ALL launches (whatever it is): algorithmic bytes per launch
+               (only convolutions have any; BatchNorm / activation passes count as fused away = 0) / its average
+               launch duration, measured live with HIP events on the launch stream, against 8 TB/s HBM; `traffic` = its PMC HBM
+               bytes per launch from profiles/; `step` = the whole step priced the same way (images/s x 367 MB / 8 TB/s);
+               `top_conv` = the most expensive convolution instantiation, for comparison with earlier rounds;
   cpu_baseline the CPU oracle (a port of the reference's PyTorch CPU path) timed on the host cores, bs=2, bounded.
+--loss ciou|wiou|ciou+nwd|wiou+nwd selects the box loss (reference default: ciou; BASELINE north_star names wiou+nwd).
 """
 import argparse
 import json
@@ -28,6 +32,8 @@ import torch.distributed as dist  # noqa: E402
 
 CFG = os.path.join(ROOT, "experiment-yolo_amd", "ultralytics", "cfg", "models", "yolov8n-ASF-P2P2.yaml")
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic bytes per image of one TRAINING step (3 x forward conv in+out at fp16), by model YAML stem
+ALG_BYTES_PER_IMAGE = {"yolov8n-ASF-P2P2": 367.1e6, "yolov8n-LD-P2": 407.8e6, "yolov8n-ASF-P2": 392.1e6}
 
 
 def synth_batch(seed, B, imgsz, nc, n_per=8):
@@ -87,6 +93,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--probe", type=int, default=1, help="time the dominant kernel with HIP events")
     ap.add_argument("--model", default="yolov8n-ASF-P2P2", help="model YAML stem (yolov8n-LD-P2 = BASELINE.json configs[3])")
+    ap.add_argument("--loss", default="ciou", choices=["ciou", "wiou", "ciou+nwd", "wiou+nwd"], help="box loss mode")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,6 +126,7 @@ def main():
     for k, v in model.named_parameters():
         v.requires_grad = ".dfl" not in k
     plan = StepPlan(model, a.batch, a.imgsz, nmax=8, optimizer="SGD", world_size=world, use_graph=bool(a.graph))
+    plan.crit.bbox_loss.use_wiseiou, plan.crit.bbox_loss.nwd_loss = a.loss.startswith("wiou"), a.loss.endswith("nwd")
     batch = {k: v.to(dev) for k, v in synth_batch(1 + rank, a.batch, a.imgsz, 6).items()}
     # the synthetic images live in the plan's static input buffer (what a loader's H2D copy would target): the step then starts
     # at the import kernel instead of with a 315 MB device-to-device staging copy
@@ -157,20 +165,30 @@ def main():
 
     roof = None
     if rank == 0 and a.probe:
-        roof = plan.probe_dominant_kernel(batch, reps=max(5, min(a.steps, 20)))
-        if roof:
-            traffic = None
+        pr = plan.probe_dominant_kernel(batch, reps=max(5, min(a.steps, 20)))
+        if pr:
             try:  # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/
-                tj = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")))
-                if tj.get("kernel") == roof["kernel"]:
-                    traffic = tj["traffic_bytes"]
-                else:
-                    traffic = tj.get("traffic_bytes_by_kernel", {}).get(roof["kernel"])
+                tj = json.load(open(os.path.join(ROOT, "profiles", "kernel_traffic.json")))
             except Exception:
-                pass
-            roof = {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": roof["kernel"], "avg_us": roof["us"], "bytes_per_launch": roof["bytes"],
-                    "launches_per_step": roof["launches_per_step"]}
+                tj = {}
+
+            def traffic(k):
+                by = tj.get("traffic_bytes_by_kernel", {})
+                return by.get(k, next((v for kk, v in by.items() if kk.startswith(k.split(" ")[0])), None)) if k else None
+
+            alg = ALG_BYTES_PER_IMAGE.get(a.model)
+            step_gbs = value * alg / 1e9 if alg else None
+            tc = pr["top_conv"]
+            roof = {"bound": "hbm", "achieved": pr["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pr["gbs"] / HBM_PEAK_GBS,
+                    "traffic": traffic(pr["kernel"]), "kernel": pr["kernel"], "avg_us": pr["us"], "bytes_per_launch": pr["bytes"],
+                    "launches_per_step": pr["launches_per_step"], "ms_per_step": pr["ms_per_step"],
+                    "step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS if step_gbs else None, "unit": "GB/s",
+                             "algorithmic_bytes_per_image": alg, "device_ms_sum_of_launches": pr["step_device_ms"],
+                             "traffic_bytes_per_step": tj.get("step_traffic_bytes")},
+                    "top_conv": None if tc is None else {"kernel": tc["kernel"], "achieved": tc["gbs"], "frac": tc["gbs"] / HBM_PEAK_GBS,
+                                                         "avg_us": tc["us"], "bytes_per_launch": tc["bytes"], "traffic": traffic(tc["kernel"]),
+                                                         "launches_per_step": tc["launches_per_step"]},
+                    "ranking": pr["ranking"]}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cpu = cpu_baseline(a.imgsz)
@@ -180,7 +198,8 @@ def main():
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": f"{'DEAL-YOLO-N' if a.model == 'yolov8n-ASF-P2P2' else a.model} ({a.model}.yaml) train step {a.imgsz}x{a.imgsz}, per-GPU batch {a.batch}, "
-                                      f"fwd+TAL/CIoU/DFL/BCE loss+bwd+SGD+EMA, BASELINE.json configs[1]",
+                                      f"fwd+TAL/{a.loss.upper()}/DFL/BCE loss+bwd+SGD+EMA, BASELINE.json configs[{3 if 'LD' in a.model else 1}]",
+                          "loss_mode": a.loss,
                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
                           "loss_items_last": [float(x) for x in s[5:8]], "loss_scale": float(plan.state[0]),
                           "skipped_steps": float(plan.state[6]),

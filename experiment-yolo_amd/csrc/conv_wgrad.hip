@@ -5,6 +5,7 @@
 // pixel-major (NHWC): fragments come from LDS through ds_read_b64_tr_b16 (hardware transpose), two reads per
 // fragment.  Workgroups are persistent over pixel tiles and keep dW in accumulators; each writes ONE fp32 slab,
 // reduced (deterministically, no atomics) by dy_wgrad_reduce into the OIHW fp32 gradient.
+#include <cstdio>
 #include "common.h"
 #include "dealyolo_hip.h"
 
@@ -384,6 +385,15 @@ extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks
 static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
                            int cin, int cout, int ks, int stride, int accumulate, int ld_taps, int ld_cphys, int ld_cin,
                            hipStream_t stream);
+
+// host-side: the kernel instantiation dy_conv_wgrad launches for this geometry, spelled as rocprofv3 prints it
+extern "C" int dy_wgrad_kernel_name(int cin, int cout, int ks, int stride, char* out, int cap) {
+  if (!out || cap < 8) return DY_ERR_ARG;
+  int cp, op, nci, mtc;
+  wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc);
+  snprintf(out, cap, "conv_wgrad_kernel<%d, %d, %d, %d>", ks, stride, nci, mtc);
+  return DY_OK;
+}
 
 extern "C" int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h,
                              int w, int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream) {

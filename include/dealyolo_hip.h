@@ -73,6 +73,8 @@ int dy_conv_kernel_name(int cin, int cout, int ks, int stride, char* out, int ca
 
 /* ---- weight-gradient half of aten::convolution_backward for the same modules. dw: fp32 OIHW (cout,cin,ks,ks). -- */
 int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int stride, int* nslabs, long* slab_elems);
+/* host-side: the kernel instantiation dy_conv_wgrad launches for this geometry, spelled as rocprofv3 prints it */
+int dy_wgrad_kernel_name(int cin, int cout, int ks, int stride, char* out, int cap);
 int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
                   int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream);
 /* dw == NULL in dy_conv_wgrad / dy_conv_wgrad_ld defers the slab reduction: the caller keeps that layer's slabs alive, fills one
