@@ -136,7 +136,6 @@ def main():
 
     def one_step():
         plan.set_hyper(lr, mom, wd)
-        plan.sync_buffers()
         plan.forward_backward(batch)
         if world > 1:
             plan.all_reduce()

@@ -21,13 +21,25 @@ from ..utils.torch_utils import ModelEMA, init_seeds, select_device
 
 
 class DetectionTrainer:
-    def __init__(self, model, cfg=None, overrides=None):
+    def __init__(self, model=None, cfg=None, overrides=None, _callbacks=None):
+        """``DetectionTrainer(model, overrides=...)`` (this package's YOLO facade) or, as in the reference
+        (engine/trainer.py:490-560), ``DetectionTrainer(cfg=..., overrides=dict(model=<yaml | pt>, data=<yaml>, ...)).train()``."""
+        if model is not None and not isinstance(model, torch.nn.Module):  # reference call shape: first positional is cfg
+            model, cfg = None, model
         self.args = get_cfg(cfg or {}, overrides) if cfg else get_cfg(overrides=overrides)
+        if model is None:
+            if not self.args.model:
+                raise ValueError("DetectionTrainer needs a model: pass a DetectionModel or overrides['model'] = <model yaml | checkpoint>")
+            from ..nn.tasks import DetectionModel, attempt_load_weights
+            m = str(self.args.model)
+            model = DetectionModel(m, verbose=False) if m.endswith((".yaml", ".yml")) else attempt_load_weights(m)
         self.model = model
         self.world_size = int(os.environ.get("WORLD_SIZE", 1))
         self.rank = int(os.environ.get("RANK", 0))
+        self.rehearsal = os.environ.get("DY_REHEARSE_ON_ONE_GPU") == "1"  # N ranks sharing GPU 0 over gloo: exercises the DP path
+        self.dataset_len = None
         init_seeds(self.args.seed + 1 + RANK, self.args.deterministic)  # reference engine/trainer.py:526 (RANK = -1 single process)
-        self.device = select_device(self.args.device)
+        self.device = torch.device("cuda", 0) if self.rehearsal else select_device(self.args.device)
         self.plan = self.ema = None
         self.lf = None
 
@@ -46,7 +58,10 @@ class DetectionTrainer:
         a = self.args
         if self.world_size > 1 and not dist.is_initialized():
             torch.cuda.set_device(self.device)
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world_size, device_id=self.device)
+            if self.rehearsal:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world_size)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world_size, device_id=self.device)
         self.model.to(self.device).train()
         self.model.args = a
         for k, v in self.model.named_parameters():  # always freeze .dfl (engine/trainer.py:670)
@@ -54,7 +69,10 @@ class DetectionTrainer:
         global_bs = batch_size * self.world_size
         self.accumulate = max(round(a.nbs / global_bs), 1)
         self.wd = a.weight_decay * global_bs * self.accumulate / a.nbs
-        iterations = math.ceil(batches_per_epoch * batch_size / max(global_bs, a.nbs)) * a.epochs
+        # reference engine/trainer.py:707: ceil(len(train_loader.dataset) / max(self.batch_size, nbs)) * epochs with the GLOBAL batch
+        # and the whole dataset, whatever the number of ranks
+        n_images = self.dataset_len if self.dataset_len is not None else batches_per_epoch * global_bs
+        iterations = math.ceil(n_images / max(global_bs, a.nbs)) * a.epochs
         name, self.lr0, self.momentum = self._optimizer_choice(iterations, self.model.model[-1].nc)
         self.plan = StepPlan(self.model, batch_size, imgsz, nmax=getattr(a, "nmax", None) or 16, optimizer=name, world_size=self.world_size,
                              use_graph=bool(a.hipgraph), init_scale=float(a.loss_scale) if a.amp else 1.0, dynamic_scale=bool(a.amp))
@@ -81,7 +99,6 @@ class DetectionTrainer:
             lr = [float(np.interp(ni, xi, [a.warmup_bias_lr if j == 0 else 0.0, self.lr0 * self.lf(epoch)])) for j in range(3)]
             mom = float(np.interp(ni, xi, [a.warmup_momentum, self.momentum]))
         p.set_hyper(lr, mom, [0.0, self.wd, 0.0])
-        p.sync_buffers()
         p.forward_backward(batch)
         if self.accumulate > 1 or acc > 1 or p._micro:
             p.accumulate()
@@ -91,9 +108,14 @@ class DetectionTrainer:
             self.last_opt_step = ni
         return lr, mom
 
-    def train(self, loader, batch_size, imgsz, epochs=None, log_every=0):
-        """loader: re-iterable of batch dicts.  Returns the list of per-epoch mean loss items."""
+    def train(self, loader=None, batch_size=None, imgsz=None, epochs=None, log_every=0):
+        """loader: re-iterable of batch dicts (``batch_size`` = its per-rank batch).  Without arguments -- the reference's call shape
+        -- trains on ``args.data`` with ``args.batch`` / ``args.imgsz``.  Returns the list of per-epoch mean loss items."""
         a = self.args
+        if loader is None:
+            if not a.data:
+                raise ValueError("train() without a loader needs overrides['data'] = <dataset yaml>")
+            return self.train_on_dataset(a.data, a.batch, a.imgsz, log_every=log_every)
         if epochs is not None:
             a.epochs = epochs
         if a.multi_scale:
@@ -159,7 +181,10 @@ class DetectionTrainer:
         from ..models.yolo.detect import DetectionValidator
         self.data = check_det_dataset(data_yaml)
         self.model.names = self.data["names"]
+        if self.world_size > 1:  # ``batch`` is the GLOBAL batch, split over the ranks (reference engine/trainer.py:692)
+            batch_size = max(batch_size // self.world_size, 1)
         loader = self.get_dataloader(self.data["train"], batch_size, self.rank, "train", self.data)
+        self.dataset_len = len(loader.dataset)
         batch_size = loader.batch_size  # build_dataloader clamps it to the dataset size, as the reference does (data/build.py:104)
         if len(loader) == 0:
             raise ValueError(f"the training split holds {len(loader.dataset)} images, fewer than one batch of {batch_size}")

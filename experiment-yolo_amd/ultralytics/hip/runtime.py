@@ -55,9 +55,20 @@ class Runtime:
             bounds.append(total)
         self.n_params_flat, self.group_bounds = total, bounds
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._n_params_for_gb = total  # flat_g is created with the buffers' staging tail once their size is known (below)
         self.frozen = torch.zeros(total, dtype=torch.uint8, device=dev)
         self.param_off = offs
+        # floating-point buffers (running statistics)
+        fb = []
+        for mname, mod in self.root.named_modules():
+            for bname, b in mod.named_buffers(recurse=False):
+                if b is not None and b.dtype.is_floating_point:
+                    fb.append((mod, bname, b))
+        tot = sum(_round(b.numel()) for _, _, b in fb)
+        # ONE exchange buffer [gradients | staging copy of the float buffers]: the data-parallel step all-reduces it whole, so the
+        # DDP-style "rank 0's BN statistics win" rides on the gradient all-reduce (rank 0 stages its buffers, the others zeros)
+        self.flat_gb = torch.zeros(total + max(tot, PAD), dtype=torch.float32, device=dev)
+        self.flat_g = self.flat_gb[:total]
         self.gviews = {}
         for g in groups:
             for n, p in g:
@@ -72,13 +83,6 @@ class Runtime:
                     self.frozen[o:o + _round(k)] = 1
                 else:
                     self.frozen[o + k:o + _round(k)] = 1  # padding never moves
-        # floating-point buffers (running statistics)
-        fb = []
-        for mname, mod in self.root.named_modules():
-            for bname, b in mod.named_buffers(recurse=False):
-                if b is not None and b.dtype.is_floating_point:
-                    fb.append((mod, bname, b))
-        tot = sum(_round(b.numel()) for _, _, b in fb)
         self.flat_b = torch.zeros(max(tot, PAD), dtype=torch.float32, device=dev)
         o = 0
         for mod, bname, b in fb:

@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import check, lib
-from .dist import all_reduce_flat, broadcast_buffers
+from .dist import all_reduce_flat
 from .engine import Recorder
 
 
@@ -191,24 +191,34 @@ class StepPlan:
 
     # ---- optimizer ----------------------------------------------------------------------------------------------
     def all_reduce(self):
-        """ONE RCCL all-reduce(SUM) over the flat fp32 gradient buffer (4 MB for DEAL-YOLO-N)."""
+        """The step's ONE collective: RCCL all-reduce(SUM) over [flat fp32 gradients | float buffers] (4 MB + 25 KB for
+        DEAL-YOLO-N).  The buffer tail makes rank 0's BatchNorm running statistics win on every rank, as DDP's
+        broadcast_buffers does before each forward (reference engine/trainer.py:640-651): rank 0 stages its buffers, every other
+        rank zeros, so the sum IS rank 0's copy.  (Training-mode forwards never read running statistics, so when the exchange
+        happens within the step is unobservable; rank 0's own statistics are never overwritten by another rank's.)"""
         if self.world_size > 1:
-            all_reduce_flat(self.gsum if self._micro else self.rt.flat_g, self.world_size)
+            rt, n = self.rt, self.rt.n_params_flat
+            t = self.gsum if self._micro else rt.flat_gb
+            if dist.get_rank() == 0:
+                t[n:].copy_(rt.flat_b)
+            else:
+                t[n:].zero_()
+            all_reduce_flat(t, self.world_size)
+            rt.flat_b.copy_(t[n:])
 
     def sync_buffers(self):
-        """DDP(broadcast_buffers=True) equivalent: rank 0's BN running statistics before the forward."""
-        if self.world_size > 1:
-            broadcast_buffers(self.rt.flat_b, 0)
+        """Kept for callers of the round-1 API: the buffer exchange now rides on ``all_reduce`` (one collective per step)."""
 
     def accumulate(self):
         """Gradient accumulation across micro-batches (reference engine/trainer.py:812: step only every ``accumulate``
         iterations): fold this micro-step's gradients into the running sum the optimizer will read."""
         if self.gsum is None:
-            self.gsum = torch.zeros_like(self.rt.flat_g)
+            self.gsum = torch.zeros_like(self.rt.flat_gb)  # same [gradients | buffer staging] layout as the exchange buffer
+        n = self.rt.n_params_flat
         if self._micro == 0:
-            self.gsum.copy_(self.rt.flat_g)
+            self.gsum[:n].copy_(self.rt.flat_g)
         else:
-            self.eng.call("dy_axpy_f32", self.gsum.data_ptr(), self.rt.flat_g.data_ptr(), 1.0, self.rt.n_params_flat)
+            self.eng.call("dy_axpy_f32", self.gsum.data_ptr(), self.rt.flat_g.data_ptr(), 1.0, n)
         self._micro += 1
 
     def optimizer_step(self):

@@ -8,7 +8,7 @@ import torch
 from ..hip import check, lib
 from ..hip.engine import dev_empty
 
-__all__ = ("non_max_suppression", "soft_nms", "decode_predictions", "xywh2xyxy", "xyxy2xywh", "make_divisible")
+__all__ = ("non_max_suppression", "soft_nms", "decode_predictions", "xywh2xyxy", "xyxy2xywh", "make_divisible", "scale_boxes", "clip_boxes")
 
 
 def make_divisible(x, divisor):
@@ -32,6 +32,37 @@ def xyxy2xywh(x):
     y[..., 0], y[..., 1] = (x[..., 0] + x[..., 2]) / 2, (x[..., 1] + x[..., 3]) / 2
     y[..., 2], y[..., 3] = x[..., 2] - x[..., 0], x[..., 3] - x[..., 1]
     return y
+
+
+def clip_boxes(boxes, shape):
+    """Clip xyxy boxes to an image of (h, w) in place (reference utils/ops.py:147-165)."""
+    if isinstance(boxes, torch.Tensor):
+        boxes[..., 0].clamp_(0, shape[1])
+        boxes[..., 1].clamp_(0, shape[0])
+        boxes[..., 2].clamp_(0, shape[1])
+        boxes[..., 3].clamp_(0, shape[0])
+    else:
+        boxes[..., [0, 2]] = boxes[..., [0, 2]].clip(0, shape[1])
+        boxes[..., [1, 3]] = boxes[..., [1, 3]].clip(0, shape[0])
+    return boxes
+
+
+def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None, padding=True, xywh=False):
+    """Rescale boxes from the letterboxed shape ``img1_shape`` (h, w) to the original ``img0_shape``, in place, then clip
+    (reference utils/ops.py:89-124; a few boxes per image: plain tensor arithmetic, the validator does it inside its kernel)."""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = round((img1_shape[1] - img0_shape[1] * gain) / 2 - 0.1), round((img1_shape[0] - img0_shape[0] * gain) / 2 - 0.1)
+    else:
+        gain, pad = ratio_pad[0][0], ratio_pad[1]
+    if padding:
+        boxes[..., 0] -= pad[0]
+        boxes[..., 1] -= pad[1]
+        if not xywh:
+            boxes[..., 2] -= pad[0]
+            boxes[..., 3] -= pad[1]
+    boxes[..., :4] /= gain
+    return clip_boxes(boxes, img0_shape)
 
 
 def _stream(dev):

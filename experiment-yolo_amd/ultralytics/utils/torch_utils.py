@@ -17,12 +17,15 @@ def select_device(device="", batch=0, newline=False, verbose=True):
     d = "" if device is None else str(device).lower().replace("cuda:", "").strip()
     if d in ("cpu", "mps"):
         raise ValueError("the MI355X DEAL-YOLO path runs on GPUs only (device='cpu' is served by the reference implementation)")
+    ids = [int(x) for x in d.split(",") if x != ""] or [0]
+    if len(ids) > 1 and "LOCAL_RANK" not in os.environ:
+        raise ValueError(f"device='{device}' lists {len(ids)} GPUs but this process is not a rank of a distributed launch: "
+                         "YOLO.train(device='0,1,...') re-launches itself under torch.distributed.run; other entry points take one GPU")
     if not torch.cuda.is_available():
         raise ValueError(f"Invalid device '{device}' requested: no GPU visible")
-    idx = int(d.split(",")[0]) if d else 0
-    if "LOCAL_RANK" in os.environ:
-        idx = int(os.environ["LOCAL_RANK"])
-    return torch.device("cuda", idx)
+    if "LOCAL_RANK" in os.environ:  # one rank per GPU under torch.distributed.run: the launcher narrowed the visible devices
+        return torch.device("cuda", 0 if os.environ.get("DY_REHEARSE_ON_ONE_GPU") == "1" else int(os.environ["LOCAL_RANK"]))
+    return torch.device("cuda", ids[0])
 
 
 def init_seeds(seed=0, deterministic=False):

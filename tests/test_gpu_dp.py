@@ -1,0 +1,59 @@
+"""-m gpu: the data-parallel step itself.  Two rank processes share the one GPU and exchange over gloo --
+the same StepPlan code path a multi-GPU run takes with RCCL: forward/backward on the rank's shard, accumulate(), ONE all-reduce
+of [gradients | float buffers], optimizer_step().  No multi-GPU oracle exists (the reference's DDP path needs CUDA devices), so
+the result is compared with the single-process emulation the survey defines: the W shards go through ONE replica in train mode
+one after another (per-shard BatchNorm statistics), their gradients of L_r * b are summed, one optimizer step follows, and the
+running-statistic buffers must be rank 0's."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from dp_common import STEPS, build_model, global_batch, hyper
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _emulate(world, b):
+    from ultralytics.hip.dist import shard_batch
+    from ultralytics.hip.train import StepPlan
+    m = build_model().cuda().train()
+    plan = StepPlan(m, b, 64, nmax=8, optimizer="SGD", world_size=1, use_graph=False, init_scale=1.0, dynamic_scale=False)
+    rt = plan.rt
+    for it, accumulate in enumerate(STEPS):
+        buf_rank0 = rt.flat_b.clone()  # rank 0's running statistics evolve through ITS shards only
+        start = rt.flat_b.clone()
+        for r in range(world):  # every rank starts the iteration from the same buffers (they were exchanged at the last step)
+            rt.flat_b.copy_(start)
+            for micro in range(accumulate):
+                plan.set_hyper(*hyper(it))
+                plan.forward_backward(shard_batch(global_batch(it, micro, b * world), r, world))
+                plan.accumulate()
+            if r == 0:
+                buf_rank0 = rt.flat_b.clone()
+        rt.flat_b.copy_(buf_rank0)
+        plan.optimizer_step()
+    torch.cuda.synchronize()
+    return rt.flat_p.cpu(), rt.flat_b.cpu(), plan.ema.cpu()
+
+
+def test_two_rank_step_equals_the_single_process_emulation(tmp_path):
+    world, b = 2, 2
+    port = 29500 + os.getpid() % 2000
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    ranks = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    assert torch.equal(ranks[0]["p"], ranks[1]["p"]) and torch.equal(ranks[0]["b"], ranks[1]["b"]), "replicas diverged"
+    p, bufs, ema = _emulate(world, b)
+    # same kernels, same per-shard arithmetic; only the order of the fp32 gradient sum differs (gloo ring vs axpy chain)
+    dp = float((ranks[0]["p"] - p).abs().max() / p.abs().max())
+    db = float((ranks[0]["b"] - bufs).abs().max() / bufs.abs().max())
+    de = float((ranks[0]["ema"] - ema).abs().max() / ema.abs().max())
+    print(f"2 ranks vs emulation: weights {dp:.2e}, buffers {db:.2e}, EMA {de:.2e} (relative to the largest entry)")
+    assert dp < 1e-6 and db < 1e-6 and de < 1e-6

@@ -27,7 +27,7 @@ def test_trainer_learns_and_exports():
     we = dict(ema.named_parameters())["model.0.conv.weight"]
     assert we.shape == w.shape and not torch.equal(we.to(w.device), w)
     out = y.predict(torch.rand(2, 3, 64, 64), conf=0.001)
-    assert len(out) == 2 and all(o.shape[1] == 6 for o in out)
+    assert len(out) == 2 and all(o.boxes.data.shape[1] == 6 and o.orig_shape == (64, 64) for o in out)
 
 
 def test_p2_model_fused_inference():

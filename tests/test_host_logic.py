@@ -109,3 +109,65 @@ def test_reference_format_checkpoint_roundtrip(tmp_path):
     back = attempt_load_weights(path)
     for (k, a), (_, b) in zip(m.state_dict().items(), back.state_dict().items()):
         assert torch.equal(a.half().float() if a.is_floating_point() else a, b if not b.is_floating_point() else b.float()), k
+
+
+def test_reference_entry_script_arguments_are_accepted():
+    """The keyword sets of the reference's entry scripts (train.py:9-24, detect.py:7-14, val.py:8-16, get_FPS.py:40-52) pass the
+    cfg check, device lists parse without touching a GPU, and the multi-GPU launch is the reference's torch.distributed.run
+    command (utils/dist.py:47-65) around a script that rebuilds the model and calls train with the same overrides."""
+    import ast
+    from ultralytics.cfg import DEFAULT_CFG_DICT, get_cfg
+    from ultralytics.utils.dist import ddp_cleanup, generate_ddp_command, parse_devices
+    from ultralytics.utils.torch_utils import select_device
+    train_kw = dict(data="VisDrone.yaml", cache=False, imgsz=640, epochs=300, batch=8, close_mosaic=10, workers=8, device="0",
+                    optimizer="SGD", project="runs/train", name="yolov8m-ASF-P2")
+    a = get_cfg(overrides=train_kw)
+    assert a.epochs == 300 and a.batch == 8 and a.device == "0" and a.project == "runs/train"
+    get_cfg(overrides=dict(source="images/test", imgsz=640, project="runs/detect", name="exp", verbose=True, save=True, conf=0.2, visualize=False))
+    get_cfg(overrides=dict(data="data.yaml", split="test", imgsz=640, batch=16, rect=False, save_json=False, project="runs/val", name="x"))
+    with pytest.raises(SyntaxError):
+        get_cfg(overrides=dict(not_a_key=1))
+    # defaults are the reference's (cfg/default.yaml)
+    assert (DEFAULT_CFG_DICT["epochs"], DEFAULT_CFG_DICT["batch"], DEFAULT_CFG_DICT["device"], DEFAULT_CFG_DICT["optimizer"]) == (200, 8, 0, "auto")
+    assert parse_devices("0,1,2,3") == [0, 1, 2, 3] and parse_devices(None) == [0] and parse_devices([2, 3]) == [2, 3] and parse_devices("cuda:1") == [1]
+    with pytest.raises(ValueError, match="not a rank of a distributed launch"):
+        select_device("0,1")  # outside a launch a device list is an error, never a silent "first GPU"
+    cmd, file, result = generate_ddp_command(4, "yolov8-ASF-P2.yaml", dict(train_kw, device="0,1,2,3"))
+    try:
+        assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc_per_node=4" in cmd and "127.0.0.1" in cmd and cmd[-1] == file
+        src = open(file).read()
+        ast.parse(src)
+        assert "YOLO('yolov8-ASF-P2.yaml')" in src and "'device': '0,1,2,3'" in src and "model.train(**overrides)" in src
+    finally:
+        ddp_cleanup(file)
+    assert not os.path.exists(file)
+
+
+def test_import_paths_of_the_reference():
+    """Module paths the reference's own code imports on this path."""
+    from ultralytics import YOLO  # noqa: F401
+    from ultralytics.engine.results import Boxes, Results  # noqa: F401
+    from ultralytics.models.yolo.detect import DetectionPredictor, DetectionTrainer, DetectionValidator  # noqa: F401
+    from ultralytics.models.yolo.detect.predict import DetectionPredictor as P2  # noqa: F401
+    from ultralytics.models.yolo.detect.train import DetectionTrainer as T2  # noqa: F401
+    from ultralytics.models.yolo.model import YOLO as Y2  # noqa: F401
+    from ultralytics.nn.tasks import attempt_load_weights  # noqa: F401
+    from ultralytics.utils.ops import clip_boxes, scale_boxes
+    from ultralytics.utils.tal import TaskAlignedAssigner, bbox2dist, dist2bbox, make_anchors
+    from ultralytics.utils.torch_utils import select_device  # noqa: F401
+    from oracle import metrics as om, nn as onn
+    # the tensor helpers against the oracle's restatements of the reference (utils/tal.py:294-324, utils/ops.py:89-124)
+    feats = [torch.zeros(1, 8, 4, 6), torch.zeros(1, 8, 2, 3)]
+    pts, st = make_anchors(feats, [8, 16])
+    pts_o, st_o = onn.make_anchors([(4, 6), (2, 3)], [8, 16])
+    assert torch.equal(pts, pts_o) and torch.equal(st, st_o)
+    d = torch.rand(2, 4, 30)
+    x = dist2bbox(d, pts.t().unsqueeze(0), xywh=True, dim=1)
+    lt, rb = d.chunk(2, 1)
+    assert torch.allclose(x[:, :2], (pts.t() - lt + pts.t() + rb) / 2) and torch.allclose(x[:, 2:], lt + rb)
+    assert bbox2dist(pts, torch.cat((pts - 1, pts + 20), -1), 16).max() <= 16 - 0.01
+    b = torch.tensor([[100., 50., 300., 400.], [-5., 10., 700., 650.]])
+    got = scale_boxes((640, 640), b.clone(), (480, 640, 3))
+    want = torch.from_numpy(om.scale_boxes((640, 640), b.numpy().copy(), (480, 640)))
+    assert torch.allclose(got, want.float(), atol=1e-4) and float(clip_boxes(b.clone(), (100, 100)).max()) == 100
+    assert TaskAlignedAssigner(topk=10, num_classes=6, alpha=0.5, beta=6.0).topk == 10
