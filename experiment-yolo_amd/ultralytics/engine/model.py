@@ -79,17 +79,25 @@ class YOLO:
             if not isinstance(data, (str, Path)):
                 raise ValueError("multi-GPU training re-launches itself: data must be a dataset YAML path, not an in-memory iterable")
             return self._train_ddp(devices, dict(kwargs, data=str(data)))
+        T = trainer or DetectionTrainer
         if isinstance(data, (str, Path)):
             from ..data import check_det_dataset
             nc = check_det_dataset(data)["nc"]
-            if nc != self.model.model[-1].nc:  # the reference rebuilds the model with the dataset's class count
-                if self.ckpt_path is not None:
-                    raise ValueError(f"checkpoint has {self.model.model[-1].nc} classes, dataset has {nc}")
-                self.model = DetectionModel(self.model.yaml, nc=nc, verbose=False)
-            self.trainer = (trainer or DetectionTrainer)(self.model, overrides=dict(kwargs, data=str(data)))
+            if self.ckpt_path is not None and nc != self.model.model[-1].nc:
+                raise ValueError(f"checkpoint has {self.model.model[-1].nc} classes, dataset has {nc}")
+            self.trainer = T(self.model, overrides=dict(kwargs, data=str(data)))  # seeds the RNGs: init_seeds(seed + 1 + RANK)
+            self._fresh_model(nc)
             return self.trainer.train_on_dataset(data, batch, imgsz, log_every=log_every)
-        self.trainer = (trainer or DetectionTrainer)(self.model, overrides=dict(kwargs))
+        self.trainer = T(self.model, overrides=dict(kwargs))
+        self._fresh_model(self.model.model[-1].nc)
         return self.trainer.train(data, batch, imgsz)
+
+    def _fresh_model(self, nc):
+        """reference engine/model.py:583-586: ``trainer.model = trainer.get_model(weights=self.model if self.ckpt else None,
+        cfg=self.model.yaml)`` -- training from a YAML always starts from a model built AFTER the trainer seeded the RNGs, with the
+        dataset's class count (detect/train.py:75-81), so ``seed`` alone decides the initial weights, as in the reference."""
+        if self.ckpt_path is None:
+            self.model = self.trainer.model = DetectionModel(self.model.yaml, nc=nc, verbose=False)
 
     def _train_ddp(self, devices, overrides):
         """reference engine/trainer.py:607-627: spawn ``torch.distributed.run`` with one rank per GPU and wait for it."""

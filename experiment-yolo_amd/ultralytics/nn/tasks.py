@@ -279,12 +279,28 @@ class DetectionModel(BaseModel):
         if isinstance(m, Detect):
             m.inplace = self.inplace
             self.stride = m.stride
+            self._stride_probe_side_effects()
             m.bias_init()
         else:
             self.stride = torch.Tensor([32])
         initialize_weights(self)
         if verbose:
             self.info()
+
+    def _stride_probe_side_effects(self):
+        """The reference derives the strides from a TRAIN-mode forward of ``zeros(1, ch, 256, 256)`` (tasks.py:309-317) -- before
+        ``initialize_weights`` sets the BatchNorm momentum, so with nn.BatchNorm's default 0.1.  Every activation of that
+        forward is exactly zero (bias-free convs, BN beta = 0, SiLU(0) = 0; LDConv samples zeros whatever its offsets; ScalSeq's
+        Conv3d adds its bias, a per-channel constant that its BatchNorm3d removes again), so its only lasting effect is on the
+        BN buffers: running_var = 0.9 * 1 + 0.1 * 0, num_batches_tracked = 1, and running_mean = 0.1 * conv3d.bias in ScalSeq.
+        Strides are static here; this reproduces the buffers a freshly built reference model starts training from (checked
+        against the reference in tests/test_host_logic.py; the reference's rounding noise of ~1e-8 in a few means is not)."""
+        for mod in self.modules():
+            if isinstance(mod, (nn.BatchNorm2d, nn.BatchNorm3d)):
+                mod.running_var.fill_(0.9)
+                mod.num_batches_tracked.fill_(1)
+            if isinstance(mod, ScalSeq):
+                mod.bn.running_mean.copy_(0.1 * mod.conv3d.bias.detach())
 
     def _layer_channels(self, ch):
         out = []

@@ -409,6 +409,20 @@ def gen_fullsize():
     npz("fullsize", **arrs)
 
 
+def gen_init():
+    """What a freshly constructed reference model holds after torch.manual_seed(0): per-entry sum and abs-sum of the state dict
+    (weights come from the global RNG in construction order; BN buffers carry the side effects of the stride-probe forward)."""
+    arrs = {}
+    for name in ["yolov8n-ASF-P2P2", "yolov8n-LD-P2", "yolov8n-ASF-P2", "yolov8n-p2"]:
+        torch.manual_seed(0)
+        m = DetectionModel(os.path.join(CFG_DIR, name + ".yaml"), ch=3, nc=6 if name != "yolov8n-p2" else 80, verbose=False)
+        sd = m.state_dict()
+        arrs[f"{name}/keys"] = np.array(list(sd.keys()))
+        arrs[f"{name}/sum"] = np.array([float(v.double().sum()) for v in sd.values()])
+        arrs[f"{name}/abssum"] = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    npz("init_state", **arrs)
+
+
 def gen_fullsize_ld0():
     """The LD variant at 640x640 in the regime the reference trains it in: LDConv.__init__ zero-initialises p_conv.weight
     (nn/modules/conv.py:351-359), so |offset| = |p_conv.bias| < 1.  With the random p_conv weights of ``fullsize`` the offsets

@@ -2,8 +2,11 @@
 reference's UNMODIFIED trainer (its own dataset reader, loader, loss, optimizer, warm-up, EMA, validator; CPU, fp32) on the
 synthetic set of golden.cases.write_e2e_dataset: 16 + 16 images of 640x640, 40 epochs, batch 2, no augmentation.  Here the
 same files and overrides go through this package's public API -- YOLO(yaml).train(data=...) -- on the GPU, and the north-star
-clause is checked: mAP50 on the held-out images within 0.2 of the reference (weights are initialised from different random
-streams, so trajectories are compared statistically, not step by step)."""
+clause is checked: mAP50 on the held-out images within 0.2 of the reference.  The run reproduces the reference's starting point
+and data order -- init_seeds(seed + 1 + RANK), a model built after it in the reference's construction order (same draws from the
+global RNG, same BN buffers), the DataLoader generator seed -- so the first epochs are compared number for number (measured: epoch 1
+and 2 within 0.4 %); fp16 activations against fp32 then decorrelate the two trajectories (3 % at epoch 3, 5-10 % later) and the
+rest of the curve and the final metrics are compared statistically."""
 import os
 
 import numpy as np
@@ -44,6 +47,11 @@ def test_public_api_training_reaches_the_reference_trainers_map(tmp_path, model,
     w1 = y.trainer.model.state_dict()
     moved = {k: float((w1[k].cpu() - w0[k].cpu()).abs().max()) for k in w0 if "running" not in k}
     assert all(v > 0 for v in moved.values()), f"first-layer parameters that never moved: {[k for k, v in moved.items() if v == 0]}"
+    keys = ("train/box_loss", "train/cls_loss", "train/dfl_loss")
+    dev = np.array([[abs(hist[e][j] - ref[k][e]) / ref[k][e] for j, k in enumerate(keys)] for e in range(E2E["epochs"])])
+    print("relative deviation of the per-epoch mean losses from the reference's results.csv: epoch 1", np.round(dev[0], 4), " worst over epochs 1-5",
+          np.round(dev[:5].max(0), 4), " worst over all", np.round(dev.max(0), 4))
+    print("per-epoch deviation, epochs 1-10:\n", np.round(dev[:10], 4))
     for e in (0, 9, 19, 29, 39):
         print(f"epoch {e + 1:2d}  ours box/cls/dfl {np.round(hist[e], 3)}   reference "
               f"{[round(float(ref[k][e]), 3) for k in ('train/box_loss', 'train/cls_loss', 'train/dfl_loss')]}")
@@ -51,8 +59,8 @@ def test_public_api_training_reaches_the_reference_trainers_map(tmp_path, model,
           f"mAP50-95 {m['metrics/mAP50-95(B)']:.3f}   reference P {ref['metrics/precision(B)'][-1]:.3f} R {ref['metrics/recall(B)'][-1]:.3f} "
           f"mAP50 {ref['metrics/mAP50(B)'][-1]:.3f} mAP50-95 {ref['metrics/mAP50-95(B)'][-1]:.3f}")
     assert hist.shape == (E2E["epochs"], 3) and np.isfinite(hist).all()
-    r1 = np.array([ref[k][0] for k in ("train/box_loss", "train/cls_loss", "train/dfl_loss")])
-    assert np.all(np.abs(hist[0] - r1) / r1 < 0.15), "first-epoch mean losses (different random initial weights: 15 %)"
+    assert dev[0].max() < 1e-2 and dev[1].max() < 1e-2, "epochs 1 and 2: same initial weights, same batches -> the reference's losses to 1 %"
+    assert dev[:5].max() < 0.12, "epochs 3-5: decorrelating (measured up to 8 %)"
     rl = np.array([ref[k][-1] for k in ("train/box_loss", "train/cls_loss", "train/dfl_loss")])
     assert np.all(np.abs(hist[-1] - rl) / rl < 0.25), "last-epoch mean losses"
     assert abs(m["metrics/mAP50(B)"] - ref["metrics/mAP50(B)"][-1]) < 0.2  # the north-star bound

@@ -171,3 +171,20 @@ def test_import_paths_of_the_reference():
     want = torch.from_numpy(om.scale_boxes((640, 640), b.numpy().copy(), (480, 640)))
     assert torch.allclose(got, want.float(), atol=1e-4) and float(clip_boxes(b.clone(), (100, 100)).max()) == 100
     assert TaskAlignedAssigner(topk=10, num_classes=6, alpha=0.5, beta=6.0).topk == 10
+
+
+@pytest.mark.parametrize("name", ["yolov8n-ASF-P2P2", "yolov8n-LD-P2", "yolov8n-ASF-P2", "yolov8n-p2"])
+def test_fresh_model_equals_a_fresh_reference_model(golden, name):
+    """torch.manual_seed(s) + construction gives the reference's initial state entry for entry: same construction order and
+    tensor shapes (so the same draws from the global RNG), same BN buffers as its stride-probe forward leaves behind -- which is
+    what lets ``seed`` reproduce the reference trainer's starting point."""
+    from ultralytics.nn.tasks import DetectionModel
+    G = golden("init_state")
+    torch.manual_seed(0)
+    m = DetectionModel(name + ".yaml", ch=3, nc=6 if name != "yolov8n-p2" else 80, verbose=False)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in G[f"{name}/keys"]]
+    s = np.array([float(v.double().sum()) for v in sd.values()])
+    a = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    np.testing.assert_allclose(s, G[f"{name}/sum"], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(a, G[f"{name}/abssum"], rtol=1e-6, atol=1e-5)
