@@ -74,8 +74,10 @@ class DetectionTrainer:
         n_images = self.dataset_len if self.dataset_len is not None else batches_per_epoch * global_bs
         iterations = math.ceil(n_images / max(global_bs, a.nbs)) * a.epochs
         name, self.lr0, self.momentum = self._optimizer_choice(iterations, self.model.model[-1].nc)
-        self.plan = StepPlan(self.model, batch_size, imgsz, nmax=getattr(a, "nmax", None) or 16, optimizer=name, world_size=self.world_size,
-                             use_graph=bool(a.hipgraph), init_scale=float(a.loss_scale) if a.amp else 1.0, dynamic_scale=bool(a.amp))
+        self._plan_kw = dict(nmax=getattr(a, "nmax", None) or 16, optimizer=name, world_size=self.world_size, use_graph=bool(a.hipgraph),
+                             init_scale=float(a.loss_scale) if a.amp else 1.0, dynamic_scale=bool(a.amp))
+        self.plan = StepPlan(self.model, batch_size, imgsz, **self._plan_kw)
+        self.plans = {batch_size: self.plan}  # forward/backward launch lists by batch size (the ragged last batch gets its own)
         bl = self.plan.crit.bbox_loss
         bl.use_wiseiou, bl.nwd_loss, bl.iou_ratio = bool(a.wiou), bool(a.nwd), float(a.iou_ratio)
         self.ema = ModelEMA(self.plan)
@@ -99,7 +101,7 @@ class DetectionTrainer:
             lr = [float(np.interp(ni, xi, [a.warmup_bias_lr if j == 0 else 0.0, self.lr0 * self.lf(epoch)])) for j in range(3)]
             mom = float(np.interp(ni, xi, [a.warmup_momentum, self.momentum]))
         p.set_hyper(lr, mom, [0.0, self.wd, 0.0])
-        p.forward_backward(batch)
+        self._plan_for(batch).forward_backward(batch)  # writes the shared flat gradient buffer; everything below is the main plan's
         if self.accumulate > 1 or acc > 1 or p._micro:
             p.accumulate()
         if ni - self.last_opt_step >= acc:
@@ -107,6 +109,17 @@ class DetectionTrainer:
             p.optimizer_step()
             self.last_opt_step = ni
         return lr, mom
+
+    def _plan_for(self, batch):
+        """The recorded forward/backward for this batch's size: the reference trains on the ragged last batch of an epoch too
+        (data/build.py:104-124 has no drop_last), a recorded launch list has one batch size -> one plan per size, optimizer
+        state shared (StepPlan(share=...))."""
+        img = batch["img"]
+        B = len(batch["index"]) if "index" in batch else (len(batch["warp"]) if "warp" in batch else img.shape[0])
+        fb = self.plans.get(B)
+        if fb is None:
+            fb = self.plans[B] = StepPlan(self.model, B, self.plan.imgsz, share=self.plan, **self._plan_kw)
+        return fb
 
     def train(self, loader=None, batch_size=None, imgsz=None, epochs=None, log_every=0):
         """loader: re-iterable of batch dicts (``batch_size`` = its per-rank batch).  Without arguments -- the reference's call shape
@@ -157,8 +170,8 @@ class DetectionTrainer:
 
     # ---- dataset-backed entry points (reference models/yolo/detect/train.py:33-55, engine/trainer.py:517-548) -------------
     def get_dataloader(self, dataset_path, batch_size=16, rank=0, mode="train", data=None):
-        """Loader over a YOLO-format image folder.  Train: shuffled, fixed-size batches (``drop_last`` -- the recorded launch
-        list has one batch size; the reference also trains on the ragged tail), images delivered as uint8 NHWC on the device;
+        """Loader over a YOLO-format image folder.  Train: shuffled batches, the ragged last one included as in the reference (it
+        runs through its own recorded launch list, ``_plan_for``), images delivered as uint8 NHWC on the device;
         val: the reference's rectangular batches, uint8 NCHW on the host side until ``preprocess``."""
         from ..data import build_dataloader, build_yolo_dataset
         a = self.args
@@ -173,7 +186,7 @@ class DetectionTrainer:
         ds = build_yolo_dataset(a, dataset_path, batch_size, data, mode=mode, rect=mode == "val", stride=32,
                                 layout="nhwc" if mode == "train" else "nchw", flip_on_device=mode == "train")
         return build_dataloader(ds, batch_size, a.workers, shuffle=mode == "train", rank=rank if self.world_size > 1 else -1,
-                                world_size=self.world_size, device=self.device if mode == "train" else None, drop_last=mode == "train")
+                                world_size=self.world_size, device=self.device if mode == "train" else None, drop_last=False)
 
     def train_on_dataset(self, data_yaml, batch_size, imgsz, log_every=0):
         """``YOLO.train(data=<yaml>)``: check the dataset YAML, build the loaders, train, validate the EMA model on 'val'."""

@@ -22,7 +22,10 @@ from .engine import Recorder
 
 class StepPlan:
     def __init__(self, model, batch_size, imgsz, nmax=16, optimizer="SGD", hyp=None, world_size=1, use_graph=False,
-                 init_scale=65536.0, side_wgrad=None, dynamic_scale=True):
+                 init_scale=65536.0, side_wgrad=None, dynamic_scale=True, share=None):
+        """``share``: another StepPlan on the SAME model whose optimizer state this one uses (momentum / Adam moments, EMA, loss
+        scale and step counters, hyper-parameters): a plan records ONE batch size, so the ragged last batch of an epoch gets its
+        own forward/backward launch list while accumulate / all_reduce / optimizer_step stay with the main plan."""
         self.model = model
         # weight gradients on a second stream beside the input-gradient chain (env DY_SIDE_WGRAD=0/1 overrides the default)
         self.side_wgrad = bool(int(os.environ.get("DY_SIDE_WGRAD", "0"))) if side_wgrad is None else bool(side_wgrad)
@@ -33,19 +36,26 @@ class StepPlan:
         self.world_size = world_size
         self.use_graph = use_graph
         self.mode = {"SGD": 0, "Adam": 1, "AdamW": 2, "RMSProp": 3, "RAdam": 4, "Adamax": 5, "NAdam": 6}[optimizer]
-        self.crit = model.criterion if hasattr(model, "criterion") else model.init_criterion()
-        model.criterion = self.crit
-        n = self.rt.n_params_flat
-        f = lambda: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
-        self.mom = f()
-        self.adam_v = f() if self.mode else None
-        self.ema = self.rt.flat_p.clone()
-        self.ema_b = self.rt.flat_b.clone()
         self.hyper_host = (C.c_float * 16)()  # read by dy_set_hyper at enqueue time (the values travel as kernel arguments)
-        self.hyper = torch.zeros(16, dtype=torch.float32, device=dev)
-        self.state = torch.zeros(8, dtype=torch.float32, device=dev)
-        self.state[0] = init_scale
-        self.partials = torch.zeros(4096, dtype=torch.float32, device=dev)
+        if share is not None:
+            if share.model is not model or share.mode != self.mode:
+                raise ValueError("StepPlan(share=...): the plans must drive the same model with the same optimizer")
+            self.crit = share.crit.clone_for_plan()
+            self.mom, self.adam_v, self.ema, self.ema_b = share.mom, share.adam_v, share.ema, share.ema_b
+            self.hyper, self.state, self.partials = share.hyper, share.state, share.partials
+        else:
+            self.crit = model.criterion if hasattr(model, "criterion") else model.init_criterion()
+            model.criterion = self.crit
+            n = self.rt.n_params_flat
+            f = lambda: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
+            self.mom = f()
+            self.adam_v = f() if self.mode else None
+            self.ema = self.rt.flat_p.clone()
+            self.ema_b = self.rt.flat_b.clone()
+            self.hyper = torch.zeros(16, dtype=torch.float32, device=dev)
+            self.state = torch.zeros(8, dtype=torch.float32, device=dev)
+            self.state[0] = init_scale
+            self.partials = torch.zeros(4096, dtype=torch.float32, device=dev)
         self.img = torch.zeros((batch_size, 3, *self.imgsz), dtype=torch.float32, device=dev)
         self.input_u8 = False  # decided by the first batch: uint8 NHWC (the loader's format) or float NCHW (the public tensor API)
         self.flip = None       # (B,) uint8 flip bits when the first loader batch carries them (flips folded into the import kernel)

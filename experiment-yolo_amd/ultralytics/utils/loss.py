@@ -65,6 +65,15 @@ class v8DetectionLoss:
         self._tgt = None
         self._ncount = None
 
+    def clone_for_plan(self):
+        """A criterion for a second recorded StepPlan on the same model (the ragged last batch of an epoch has its own launch
+        list): own argument block, workspace and target buffers; the result scalars, the running WIoU mean and the mode toggles
+        (``bbox_loss``) are THE SAME objects, as there is one criterion in the reference."""
+        c = object.__new__(type(self))
+        c.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_pub", "_last")})
+        c._args, c._ws, c._tgt, c._ncount = DyLossArgs(), None, None, None
+        return c
+
     # ---- argument block ----------------------------------------------------------------------------------------
     def bind(self, ho, nmax, gscale=None):
         """Fill the DyLossArgs block for one HeadOut geometry; returns it (kept alive by self)."""

@@ -306,3 +306,24 @@ def test_only_the_consumer_thread_calls_into_hip(tmp_path, monkeypatch, cache):
             seen += 1
     assert seen == 2 * len(loader) and seen >= 4
     assert not offenders, f"device API calls from a loader thread: {sorted(set(offenders))}"
+
+
+@pytest.mark.parametrize("cache", [False, "hbm"])
+def test_ragged_last_batch_is_trained_on_like_the_reference(tmp_path, cache):
+    """9 training images at batch 4 -> batches of 4, 4 and 1 per epoch (reference data/build.py:104-124 has no drop_last, so
+    nb = ceil(n / batch) also sets the warm-up length and the schedule).  The batch of 1 runs through its own recorded launch
+    list; gradient accumulation, the optimizer state and the step counters are the main plan's."""
+    from ultralytics import YOLO
+    root = str(tmp_path / "ds")
+    write_dataset(root)
+    zero = dict(mosaic=0.0, mixup=0.0, copy_paste=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, degrees=0.0, translate=0.0, scale=0.0, shear=0.0,
+                perspective=0.0, flipud=0.0, fliplr=0.5)
+    y = YOLO("yolov8n-ASF-P2P2.yaml")
+    hist = y.train(data=os.path.join(root, "data.yaml"), batch=4, imgsz=64, epochs=3, optimizer="SGD", workers=2, hipgraph=True, val=False,
+                   cache=cache, nbs=4, amp=False, **zero)
+    tr = y.trainer
+    assert len(tr.train_loader) == 3 and tr.nb == 3 and sorted(tr.plans) == [1, 4]
+    assert np.isfinite(np.asarray(hist, dtype=np.float64)).all()
+    taken, skipped, _ = tr.plan.check_progress()
+    assert (taken, skipped) == (9, 0) and tr.plan.opt_calls == 9  # nbs = batch: one optimizer step per batch, the tail's included
+    assert tr.plans[1].state is tr.plan.state and tr.plans[1].ema is tr.plan.ema and tr.plans[1].crit.scalars is tr.plan.crit.scalars
