@@ -74,6 +74,37 @@ def loss_cases():
     }
 
 
+def tal_filler_case():
+    """Adversarial input for the task-aligned assigner's zero-metric fillers (reference utils/tal.py:94-98, 145-161): one ground
+    truth over the top-left quarter of a 64x64 image and a head whose box logits put (almost) every anchor's four distances at
+    zero, so a predicted box is its anchor point, CIoU with the gt is negative and clamps to 0, and the alignment metric is 0
+    everywhere -- except three anchors that predict the gt well.  ``torch.topk(metrics, 10)`` then fills seven places with
+    zero-metric anchors in an implementation-defined order; those inside the gt box become foreground with target score 0.
+    Returns (feats [3 x (2, 70, h, w)], batch)."""
+    import torch
+    # 256x256 image: 64x64 + 32x32 + 16x16 = 5,376 anchors.  (On a row this long torch.topk's CPU kernel returns the zero-metric
+    # fillers from anchor indices 0-9 -- the top-left cells of level 0, inside this gt; on the 336-anchor rows of the other loss
+    # fixtures it takes them from indices ~220-231, outside every gt of those cases.)
+    shapes, strides = [(64, 64), (32, 32), (16, 16)], [4.0, 8.0, 16.0]
+    feats = []
+    for l, (h, w) in enumerate(shapes):
+        f = rnd(700 + l, 2, 70, h, w, scale=0.3)
+        box = f[:, :64].view(2, 4, 16, h, w)
+        box[:, :, 0] += 12.0  # softmax mass on bin 0: every distance ~ 0
+        feats.append(f)
+    # three anchors of level 0 in image 0 that regress the gt (x1, y1, x2, y2) = (0, 0, 48, 48) px = (0, 0, 12, 12) grid units well
+    for (iy, ix) in ((5, 5), (6, 6), (5, 6)):
+        cx, cy = ix + 0.5, iy + 0.5
+        for side, d in enumerate((cx - 0.0, cy - 0.0, 12.0 - cx, 12.0 - cy)):
+            b = feats[0][0, 16 * side:16 * side + 16, iy, ix]
+            b[:] = -6.0
+            lo = int(d)
+            b[lo], b[min(lo + 1, 15)] = 6.0 + 3.0 * (1 - (d - lo)), 6.0 + 3.0 * (d - lo)
+        feats[0][0, 64 + 2, iy, ix] = 2.0  # a confident score for the gt's class
+    batch = _boxes([[0, 2, 0.09375, 0.09375, 0.1875, 0.1875], [1, 1, 0.6, 0.6, 0.3, 0.3]])
+    return feats, batch
+
+
 def metric_cases():
     """Synthetic detection/label sets for the validation path: (name, seed, n_images, nc, max_labels, max_dets, jitter)."""
     return [("small", 11, 4, 3, 6, 12, 0.04), ("crowded", 12, 3, 2, 24, 60, 0.08), ("sparse", 13, 5, 6, 3, 5, 0.02),

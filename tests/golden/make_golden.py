@@ -39,7 +39,7 @@ from ultralytics.utils.metrics import WiseIouLoss  # noqa: E402
 from ultralytics.utils.torch_utils import ModelEMA, initialize_weights  # noqa: E402
 
 from oracle import graph as og  # noqa: E402
-from cases import DATASET_IMGSZ, E2E, write_dataset, write_e2e_dataset, MODES, loss_cases, metric_cases, metric_geometry, module_cases, planted_batches, module_shapes, rnd, synth_batch, synth_detections  # noqa: E402
+from cases import tal_filler_case, DATASET_IMGSZ, E2E, write_dataset, write_e2e_dataset, MODES, loss_cases, metric_cases, metric_geometry, module_cases, planted_batches, module_shapes, rnd, synth_batch, synth_detections  # noqa: E402
 
 CFG_DIR = os.path.join(_refimport.REF, "ultralytics/cfg/models")
 torch.set_num_threads(8)
@@ -407,6 +407,43 @@ def gen_fullsize():
                 arrs[f"{name}/grad_names"] = np.array(list(gn.keys()))
                 arrs[f"{name}/grad_l2"] = torch.stack([v.norm() for v in gn.values()])
     npz("fullsize", **arrs)
+
+
+def gen_tal_filler():
+    """The assigner's zero-metric fillers (cases.tal_filler_case): assignment tensors, losses and gradients of the reference in
+    CIoU and WIoU mode."""
+    arrs = {}
+    feats0, batch = tal_filler_case()  # inputs are regenerated from cases.py on both sides: only outputs go into the fixture
+    for mode in ("ciou", "wiou"):
+        wiou, nwd = MODES[mode]
+        crit = v8DetectionLoss(_FakeModel(6, [4.0, 8.0, 16.0]))
+        crit.bbox_loss.use_wiseiou, crit.bbox_loss.nwd_loss = wiou, nwd
+        if wiou:
+            crit.bbox_loss.wiou_loss = WiseIouLoss(ltype="WIoU", monotonous=False, inner_iou=False, focaler_iou=False)
+        feats = [f.clone().requires_grad_(True) for f in feats0]
+        captured = {}
+        orig = crit.assigner.forward
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            captured["asg"] = out
+            return out
+
+        crit.assigner.forward = spy
+        loss, items = crit(feats, dict(batch))
+        loss.backward()
+        arrs[f"{mode}/loss"], arrs[f"{mode}/items"] = loss.detach(), items
+        for l, f in enumerate(feats):  # whole-level checksums + the top-left patch of image 0 where the gt and the fillers live
+            arrs[f"{mode}/gfeat{l}_sum"], arrs[f"{mode}/gfeat{l}_abssum"] = f.grad.double().sum(), f.grad.double().abs().sum()
+        arrs[f"{mode}/gfeat0_patch"] = feats[0].grad[0, :, :16, :16]
+        if wiou:
+            arrs[f"{mode}/iou_mean"] = crit.bbox_loss.wiou_loss.iou_mean.clone()
+        if mode == "ciou":
+            tl, tb, ts, fg, tgi = captured["asg"]
+            arrs["target_scores_sum"], arrs["fg_mask"], arrs["target_gt_idx"] = ts.sum(-1), fg, tgi
+            print("foreground anchors", int(fg.sum()), "of which with zero target score", int((fg & (ts.sum(-1) == 0)).sum()),
+                  "at", (fg & (ts.sum(-1) == 0)).nonzero().tolist())
+    npz("tal_filler", **arrs)
 
 
 def gen_init():

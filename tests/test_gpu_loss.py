@@ -120,3 +120,58 @@ def test_reference_preds_protocol_and_model_batch_call(golden):
     plan.forward_backward(b)
     torch.cuda.synchronize()
     assert torch.isfinite(plan.crit.scalars[5:9]).all()
+
+
+def test_tal_zero_metric_fillers_divergence_budget(golden):
+    """DESIGN.md section 5 'TAL zero-metric fillers', pinned: when a gt has fewer than 10 positive-metric candidates the
+    reference's torch.topk fills up with zero-metric anchors in an implementation-defined order (here: anchors 1,3,4,5,7,8,9 of
+    level 0 -- inside the adversarial gt of cases.tal_filler_case), which become foreground with target score 0.  The kernels never
+    select a zero-metric anchor.  Budget, asserted: the foreground sets differ ONLY by such anchors; they carry weight 0 in every
+    loss term, so losses and gradients are the reference's in CIoU/NWD mode; in WIoU mode they enter the UNWEIGHTED running mean
+    of L_IoU (utils/metrics.py:591-627) -- the one observable difference, bounded below."""
+    from golden.cases import tal_filler_case
+    from ultralytics.nn.modules.head import HeadOut
+    from ultralytics.utils.loss import v8DetectionLoss
+    G = golden("tal_filler")
+    feats, batch = tal_filler_case()
+
+    def headout():
+        box, cls = [], []
+        for f in feats:
+            f = f.cuda().permute(0, 2, 3, 1).contiguous()
+            box.append(f[..., :64].contiguous())
+            c = torch.zeros(*f.shape[:3], 8, device="cuda")
+            c[..., :6] = f[..., 64:]
+            cls.append(c)
+        ho = HeadOut(box, cls, 6, [4.0, 8.0, 16.0])
+        ho.alloc_grads()
+        return ho
+
+    crit = v8DetectionLoss(_M())
+    ho = headout()
+    loss, items = crit(ho, batch)
+    gt, ts, _ = crit.debug_assignment()
+    fg, fg_ref = (gt >= 0).cpu(), G.t("fg_mask").bool()
+    ts_ref = G.t("target_scores_sum")
+    extra, missing = fg & ~fg_ref, fg_ref & ~fg
+    print(f"foreground: reference {int(fg_ref.sum())}, kernels {int(fg.sum())}; only in the reference {missing.nonzero().tolist()} "
+          f"(their target scores {ts_ref[missing].tolist()})")
+    assert int(extra.sum()) == 0, "the kernels may only LACK anchors the reference has"
+    assert int(missing.sum()) == 7 and float(ts_ref[missing].abs().max()) == 0.0, "... and only zero-score fillers"
+    assert torch.equal(gt.cpu()[fg].long(), G.t("target_gt_idx").long()[fg])
+    assert relerr(items, G.t("ciou/items")) < 1e-4 and abs(float(loss) - float(G["ciou/loss"])) < 1e-4 * float(G["ciou/loss"])
+    got = torch.cat((ho.dbox[0].float(), ho.dcls[0][..., :6].float()), -1)[0, :16, :16].permute(2, 0, 1).cpu()
+    assert relerr(got, G.t("ciou/gfeat0_patch")) < 2e-3
+    for l in range(3):
+        g = torch.cat((ho.dbox[l].float(), ho.dcls[l][..., :6].float()), -1).double()
+        assert abs(float(g.abs().sum()) - float(G[f"ciou/gfeat{l}_abssum"])) < 5e-3 * float(G[f"ciou/gfeat{l}_abssum"])
+    # WIoU: the seven fillers (L_IoU ~ 1: their predicted boxes are points) are in the reference's mean over 10 boxes and not in ours
+    # over 3: iou_mean after one update differs by momentum * |mean_10 - mean_3| <= 0.01 -- measured and bounded here
+    crit = v8DetectionLoss(_M())
+    crit.bbox_loss.use_wiseiou = True
+    loss_w, items_w = crit(headout(), batch)
+    d_mean = abs(float(crit.bbox_loss.wiou_loss.iou_mean) - float(G["wiou/iou_mean"]))
+    d_items = relerr(items_w, G.t("wiou/items"))
+    print(f"WIoU mode: iou_mean {float(crit.bbox_loss.wiou_loss.iou_mean):.6f} vs reference {float(G['wiou/iou_mean']):.6f} (|d| {d_mean:.2e}); "
+          f"loss items relative difference {d_items:.2e}")
+    assert d_mean <= 1e-2 and d_items < 2e-2
