@@ -192,6 +192,8 @@ class BaseModel(HipModule):
                 dst = st.act(sum(widths[:pos]), widths[pos])
             x = m.forward_act(x, dst) if dst is not None else m.forward_act(x)
             ys.append(x if m.i in self.save else None)
+            if self.__dict__.get("_capture") is not None:  # tests: per-layer outputs (engine Acts) of this forward
+                self._capture.append(x)
         return x
 
     def _export(self, rt, y):

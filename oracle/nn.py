@@ -11,6 +11,17 @@ import torch.nn.functional as F
 
 from .graph import REG_MAX, Graph
 
+# Storage emulation (tests only): with STORAGE_FP16 on, every tensor the HIP engine keeps in HBM as fp16 -- the raw conv output,
+# the activation after BN + SiLU, pooled / up-sampled / summed maps -- is rounded to fp16 at the same point here, while all
+# arithmetic stays fp32 and BN batch statistics come from the un-rounded conv output (as the conv epilogue sums them from its
+# fp32 accumulators).  Against THIS oracle the engine differs only by its kernels' arithmetic (summation order), not by storage.
+STORAGE_FP16 = False
+
+
+def _q(t):
+    return t.half().float() if STORAGE_FP16 else t
+
+
 BN2D_EPS, BN2D_MOM = 1e-3, 0.03  # utils/torch_utils.py:347-349 (applies to every nn.BatchNorm2d)
 BN3D_EPS, BN3D_MOM = 1e-5, 0.1  # nn.BatchNorm3d defaults, untouched by initialize_weights
 
@@ -23,12 +34,29 @@ def _bn(sd, p, x, training, eps, mom):
                         training, mom, eps)
 
 
-def conv_bn_silu(sd, p, x, k, s, training, act=True):
-    """Conv.forward / forward_fuse, nn/modules/conv.py:41-59 (autopad k//2 :32-38)."""
+def _bn_q(sd, p, y, training, eps, mom):
+    """BatchNorm of a conv output; under STORAGE_FP16 the normalised tensor is the fp16-rounded one, the batch statistics are the
+    un-rounded one's (2-D maps only; ScalSeq's 5-D volume is handled in scalseq)."""
+    if not (STORAGE_FP16 and training):
+        return _bn(sd, p, _q(y), training, eps, mom)
+    dims = [0] + list(range(2, y.dim()))
+    mean, var = y.mean(dims), y.var(dims, unbiased=False)
+    n = y.numel() / y.shape[1]
+    sd[f"{p}.running_mean"].mul_(1 - mom).add_(mom * mean.detach())
+    sd[f"{p}.running_var"].mul_(1 - mom).add_(mom * (var.detach() * n / max(n - 1, 1)))
+    shape = [1, -1] + [1] * (y.dim() - 2)
+    sc = sd[f"{p}.weight"] / torch.sqrt(var + eps)
+    return _q(y) * sc.view(shape) + (sd[f"{p}.bias"] - mean * sc).view(shape)
+
+
+def conv_bn_silu(sd, p, x, k, s, training, act=True, round_out=True):
+    """Conv.forward / forward_fuse, nn/modules/conv.py:41-59 (autopad k//2 :32-38).  ``round_out=False``: the caller adds a
+    residual before the result is stored (one rounding, as the engine's fused epilogue does)."""
     y = F.conv2d(x, sd[f"{p}.conv.weight"], sd.get(f"{p}.conv.bias"), s, k // 2)
     if f"{p}.bn.weight" in sd:  # absent after fuse (nn/tasks.py:168-195)
-        y = _bn(sd, f"{p}.bn", y, training, BN2D_EPS, BN2D_MOM)
-    return F.silu(y) if act else y
+        y = _bn_q(sd, f"{p}.bn", y, training, BN2D_EPS, BN2D_MOM)
+    y = F.silu(y) if act else y
+    return _q(y) if round_out else y
 
 
 def ld_sample(x, off, pn, N, s):
@@ -68,9 +96,9 @@ def ldconv(sd, p, x, N, s, training):
     h, w = off.shape[2:]
     xo = ld_sample(x, off, sd[f"{p}.p_n"], N, s)
     xo = xo.permute(0, 1, 2, 4, 3).reshape(B, C, h * N, w)  # 'b c h w n -> b c (h n) w'  :494-503
-    y = F.conv2d(xo, sd[f"{p}.conv.0.weight"], sd.get(f"{p}.conv.0.bias"), (N, 1))
-    y = _bn(sd, f"{p}.conv.1", y, training, BN2D_EPS, BN2D_MOM)
-    return F.silu(y)
+    y = F.conv2d(_q(xo), sd[f"{p}.conv.0.weight"], sd.get(f"{p}.conv.0.bias"), (N, 1))
+    y = _bn_q(sd, f"{p}.conv.1", y, training, BN2D_EPS, BN2D_MOM)
+    return _q(F.silu(y))
 
 
 def c2f(sd, p, x, n, shortcut, training):
@@ -78,8 +106,8 @@ def c2f(sd, p, x, n, shortcut, training):
     y = list(conv_bn_silu(sd, f"{p}.cv1", x, 1, 1, training).chunk(2, 1))
     for j in range(n):
         t = conv_bn_silu(sd, f"{p}.m.{j}.cv1", y[-1], 3, 1, training)
-        t = conv_bn_silu(sd, f"{p}.m.{j}.cv2", t, 3, 1, training)
-        y.append(y[-1] + t if shortcut else t)
+        t = conv_bn_silu(sd, f"{p}.m.{j}.cv2", t, 3, 1, training, round_out=not shortcut)
+        y.append(_q(y[-1] + t) if shortcut else t)
     return conv_bn_silu(sd, f"{p}.cv2", torch.cat(y, 1), 1, 1, training)
 
 
@@ -102,16 +130,16 @@ def scalseq(sd, p, xs, training):
     p5 = F.interpolate(conv_bn_silu(sd, f"{p}.conv2", p5, 1, 1, training), size, mode="nearest")
     vol = torch.stack([p3, p4, p5], 2)  # (B,C,3,H,W)
     vol = F.conv3d(vol, sd[f"{p}.conv3d.weight"], sd[f"{p}.conv3d.bias"])
-    vol = _bn(sd, f"{p}.bn", vol, training, BN3D_EPS, BN3D_MOM)
+    vol = _bn_q(sd, f"{p}.bn", vol, training, BN3D_EPS, BN3D_MOM)
     vol = F.leaky_relu(vol, 0.1)
-    return F.max_pool3d(vol, (3, 1, 1)).squeeze(2)
+    return _q(F.max_pool3d(vol, (3, 1, 1)).squeeze(2))
 
 
 def zoom_cat(xs):
     """Zoom_cat.forward, nn/extra_modules/block.py:3406-3412."""
     l, m, s = xs
     size = m.shape[2:]
-    l = F.adaptive_max_pool2d(l, size) + F.adaptive_avg_pool2d(l, size)
+    l = _q(F.adaptive_max_pool2d(l, size) + F.adaptive_avg_pool2d(l, size))
     s = F.interpolate(s, size, mode="nearest")
     return torch.cat([l, m, s], 1)
 
@@ -183,7 +211,7 @@ def apply_layer(L, sd, x, training=True, strides=None, p=None):
     if k == "Zoom_cat":
         return zoom_cat(x)
     if k == "Add":
-        return torch.stack(x, 0).sum(0)
+        return _q(torch.stack(x, 0).sum(0))
     if k == "ScalSeq":
         return scalseq(sd, p, x, training)
     if k == "Detect":

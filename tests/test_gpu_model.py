@@ -43,10 +43,12 @@ def test_model_step_vs_golden(golden, mi, name, mode):
         assert (e2 < 5e-2) if ld else (e < 3e-2)
     s = plan.crit.scalars.cpu()
     ref_items = G.t(f"{name}/{mode}/items")
-    print("items", s[5:8].tolist(), ref_items.tolist())
-    # fp16 activations perturb the head logits by ~1e-3..1e-2 relative; the averaged losses agree to better than 5e-3
-    assert relerr(s[5:8], ref_items) < (2e-2 if ld else 5e-3)
-    assert abs(float(s[8]) - float(G[f"{name}/{mode}/loss"])) < (2e-2 if ld else 5e-3) * float(G[f"{name}/{mode}/loss"])
+    per_item = float(((s[5:8] - ref_items).abs() / ref_items.abs()).max())
+    print("items", s[5:8].tolist(), ref_items.tolist(), f"worst per-item relative error {per_item:.2e}")
+    # fp16 activation storage against the fp32 reference at this 64x64 fixture (randomly filled weights and BN statistics): measured
+    # 5.7e-3 on the box / dfl items of N, 5e-5 on LD; at 640x640 (tests/test_gpu_configs.py) 6e-5 .. 6e-4.  Tolerance = 2x measured.
+    assert per_item < 1.2e-2
+    assert abs(float(s[8]) - float(G[f"{name}/{mode}/loss"])) < 5e-3 * float(G[f"{name}/{mode}/loss"])
     names = list(G[f"{name}/{mode}/grad_names"])
     params = dict(m.named_parameters())
     scale = float(plan.state[0])
@@ -54,7 +56,8 @@ def test_model_step_vs_golden(golden, mi, name, mode):
     ref = G.t(f"{name}/{mode}/grad_l2")
     rel = ((l2 - ref).abs() / (ref.abs() + 1e-3 * ref.abs().max())).numpy()
     print("grad-l2 rel err: median %.2e max %.2e (%s)" % (np.median(rel), rel.max(), names[int(rel.argmax())]))
-    assert np.median(rel) < (6e-2 if ld else 2e-2) and rel.max() < (0.5 if ld else 0.15)
+    # measured: N median 1.7e-3 / max 1.9e-2, LD median 4.2e-3 / max 8.5e-2 (p_conv.bias: gradients through floor()-ed coordinates)
+    assert np.median(rel) < (1e-2 if ld else 4e-3) and rel.max() < (0.2 if ld else 4e-2)
     if mode == "ciou":
         first = params[names[0]].grad.float().cpu() / scale
         print("grad_first relerr %.3e l2err %.3e" % (relerr(first, G.t(f"{name}/{mode}/grad_first")), l2err(first, G.t(f"{name}/{mode}/grad_first"))))
@@ -186,3 +189,51 @@ def test_steps_queued_behind_a_busy_device_keep_their_own_scalars():
     plan.accumulate()
     torch.cuda.synchronize()
     assert torch.equal(plan.gsum[:plan.rt.n_params_flat], ref)
+
+
+@pytest.mark.parametrize("mi,name", list(enumerate(MODELS)))
+def test_layer_outputs_vs_the_fp16_storage_oracle(golden, mi, name):
+    """Separates storage rounding from kernel error.  The engine keeps activations in fp16; against the fp32 reference that alone
+    costs ~1e-3 per layer and 1e-2 at the head, which is what the model-level tolerances above absorb.  Here the oracle rounds to
+    fp16 at exactly the points where the engine stores (oracle.nn.STORAGE_FP16: raw conv output, activation, sums / pools; batch
+    statistics from the un-rounded conv output), so what is left is the kernels' own arithmetic: every layer of the training-mode
+    forward must agree to a few 1e-4 (relative L2) -- a regression of 1e-3 in any kernel fails here although it would pass the
+    comparisons with the fp32 goldens."""
+    import oracle.nn as onn
+    from gpu_util import l2err
+    from ultralytics.hip.runtime import Runtime
+    G = golden("models")
+    m, g = _build(name, mi)
+    img = G.t(f"{name}/img")
+    sd = og.fill_state(og.state_layout(g), 7 + mi)
+    sd = {k: (v.half().float() if v.dim() >= 4 else v) for k, v in sd.items()}  # conv weights reach the MFMAs as fp16 packs
+    rt = m._runtime(torch.device("cuda", 0))
+    rt.eng.training = True
+    m._capture = []
+    with torch.no_grad():
+        rt.ensure_packed()
+        m.forward_act(rt.to_act(img.cuda()))
+    torch.cuda.synchronize()
+    acts, m._capture = m._capture, None
+    outs = [Runtime.to_tensor(a).float().cpu() if not isinstance(a, (list, tuple)) and hasattr(a, "st") else None for a in acts]
+    ld = "LD" in name
+    worst = 0.0
+    onn.STORAGE_FP16 = True
+    try:
+        for i, L in enumerate(g.layers[:-1]):  # all but Detect (its fp32 maps are compared by the golden tests)
+            # teacher forcing: the oracle layer gets the ENGINE's inputs, so one layer's arithmetic is compared at a time and
+            # fp16 rounding decisions that flip in an earlier layer do not pile up
+            at = lambda j: outs[i + j] if j < 0 else outs[j]  # noqa: E731  (negative 'from' indices are relative to this layer)
+            src = img.half().float() if i == 0 else (at(L.f) if isinstance(L.f, int) else [at(j) for j in L.f])
+            with torch.no_grad():
+                r = onn.apply_layer(L, {k: v.clone() for k, v in sd.items()}, src, True, g.strides)
+            e = l2err(outs[i], r)
+            fp32 = l2err(outs[i], G.t(f"{name}/layer{i}")) if f"{name}/layer{i}" in G else float("nan")
+            worst = max(worst, e)
+            print(f"{name} layer {i:2d} {L.kind:12s} vs fp16-storage oracle on the same input {e:.2e}   vs fp32 reference (whole chain) {fp32:.2e}")
+            # measured: 1e-7 .. 5e-5 for single convolutions / LDConv / SPPF / ScalSeq, 2e-5 .. 4.4e-4 for C2f (a chain of up to six
+            # convolutions whose intermediate fp16 roundings can flip); copies (Upsample, Concat, Add of two maps) exactly 0
+            assert e < 1e-3, f"layer {i} ({L.kind})"
+    finally:
+        onn.STORAGE_FP16 = False
+    print(f"{name}: worst layer {worst:.2e}")
