@@ -80,6 +80,8 @@ class YOLO:
                 raise ValueError("multi-GPU training re-launches itself: data must be a dataset YAML path, not an in-memory iterable")
             return self._train_ddp(devices, dict(kwargs, data=str(data)))
         T = trainer or DetectionTrainer
+        if kwargs.get("resume") and self.ckpt_path and kwargs.get("resume") is True:
+            kwargs["resume"] = self.ckpt_path  # YOLO('<run>/weights/last.pt').train(resume=True), reference engine/model.py:579-581
         if isinstance(data, (str, Path)):
             from ..data import check_det_dataset
             nc = check_det_dataset(data)["nc"]

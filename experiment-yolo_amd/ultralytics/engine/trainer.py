@@ -134,9 +134,6 @@ class DetectionTrainer:
         if a.multi_scale:
             raise NotImplementedError("multi_scale=True: the recorded launch list has one input size (reference detect/train.py:61-73 "
                                       "re-interpolates every batch); train at a fixed imgsz")
-        if a.resume:
-            raise NotImplementedError("resume: optimizer state is not carried in this package's checkpoints (reference "
-                                      "engine/trainer.py:1050-1105); load the weights with YOLO(<ckpt>) and start a new schedule")
         nb = len(loader)
         if not getattr(a, "nmax", None):  # per-image label capacity from the first batch, with head-room; exceeded later -> raises
             from ..utils.loss import v8DetectionLoss
@@ -144,8 +141,10 @@ class DetectionTrainer:
             a.nmax = max(16, 2 * v8DetectionLoss.capacity_for(first, batch_size))
             del first
         self.setup(nb, batch_size, imgsz)
+        self.start_epoch = self.resume_training(a.resume) if a.resume else 0
+        self.save_dir = self._save_dir()
         hist = []
-        for epoch in range(a.epochs):
+        for epoch in range(self.start_epoch, a.epochs):
             if getattr(self, "_epoch_hook", None):
                 self._epoch_hook(epoch)  # DistributedSampler.set_epoch (engine/trainer.py:766-767)
             ds = getattr(loader, "dataset", None)
@@ -163,10 +162,49 @@ class DetectionTrainer:
             _, items = self.plan.loss_items()
             self.plan.check_progress()  # raises when optimizer steps are not taking effect (counter stuck, all skipped, scale collapsed)
             hist.append(items if tloss is None else tloss)
+            self.epoch = epoch
             if self.rank == 0:
                 LOGGER.info(f"epoch {epoch + 1}/{a.epochs}  box/cls/dfl {[round(float(x), 4) for x in hist[-1]]}  "
                             f"{nb * batch_size * self.world_size / (time.time() - t0):.1f} img/s")
+                if self.save_dir is not None:  # reference engine/trainer.py:898-923: last.pt after every epoch
+                    self.save_model(self.save_dir / "weights" / "last.pt")
         return hist
+
+    def _save_dir(self):
+        """``project/name`` as in the reference (cfg get_save_dir), created only when one of the two was given explicitly: this
+        package does not write run folders unasked (the reference always creates runs/detect/trainN)."""
+        from pathlib import Path
+        a = self.args
+        if not (a.save and (a.project or a.name)) or self.rank != 0:
+            return None
+        d = Path(a.project or "runs/detect") / (a.name or "train")
+        (d / "weights").mkdir(parents=True, exist_ok=True)
+        return d
+
+    def resume_training(self, resume):
+        """reference engine/trainer.py:1050-1105 ``check_resume`` + ``resume_training``: restore the optimizer state (momentum / Adam
+        moments, loss scale and step counters), the EMA and its update count and the weights from a checkpoint written by
+        ``save_model`` (this package's format), and continue the schedule at the epoch after the saved one."""
+        path = resume if isinstance(resume, str) else self.args.model
+        if not path or not str(path).endswith(".pt"):
+            raise FileNotFoundError("resume=True needs the checkpoint: YOLO('<run>/weights/last.pt').train(resume=True) or resume='<path>'")
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        opt = ck.get("optimizer") if isinstance(ck, dict) else None
+        if not isinstance(opt, dict) or "flat" not in opt:
+            raise ValueError(f"{path} carries no resumable optimizer state (written by DetectionTrainer.save_model of this package?)")
+        p, rt = self.plan, self.plan.rt
+        if list(opt["param_names"]) != list(rt.param_names) or opt["mode"] != p.mode:
+            raise ValueError("the checkpoint's parameter layout / optimizer does not match this model and optimizer")
+        f = opt["flat"]
+        for dst, key in ((rt.flat_p, "p"), (rt.flat_b, "b"), (p.ema, "ema"), (p.ema_b, "ema_b"), (p.mom, "mom"), (p.state, "state")):
+            dst.copy_(f[key])
+        if p.adam_v is not None:
+            p.adam_v.copy_(f["adam_v"])
+        p.ema_updates, self.last_opt_step = int(ck["updates"]), int(opt["last_opt_step"])
+        p.opt_calls = int(f["state"][5]) + int(f["state"][6])
+        rt.mark_dirty()
+        LOGGER.info(f"Resuming training from {path} from epoch {int(ck['epoch']) + 2} to {self.args.epochs} total epochs")
+        return int(ck["epoch"]) + 1
 
     # ---- dataset-backed entry points (reference models/yolo/detect/train.py:33-55, engine/trainer.py:517-548) -------------
     def get_dataloader(self, dataset_path, batch_size=16, rank=0, mode="train", data=None):
@@ -220,6 +258,14 @@ class DetectionTrainer:
         if reference_format:
             from ..nn.tasks import save_reference_format
             return save_reference_format(path, self.model, ema=self.ema.ema, updates=self.plan.ema_updates, train_args=vars(self.args))
-        torch.save({"model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+        p, rt = self.plan, self.plan.rt
+        flat = {"p": rt.flat_p, "b": rt.flat_b, "ema": p.ema, "ema_b": p.ema_b, "mom": p.mom, "state": p.state}
+        if p.adam_v is not None:
+            flat["adam_v"] = p.adam_v
+        torch.save({"epoch": getattr(self, "epoch", -1),
+                    "model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
                     "ema": {k: v.detach().cpu() for k, v in self.ema.state_dict().items()},
-                    "updates": self.plan.ema_updates, "train_args": vars(self.args), "yaml": self.model.yaml}, path)
+                    "updates": p.ema_updates, "train_args": vars(self.args), "yaml": self.model.yaml,
+                    # what resume needs (reference engine/trainer.py:911 keeps optimizer.state_dict()): the flat optimizer buffers
+                    "optimizer": {"mode": p.mode, "param_names": list(rt.param_names), "last_opt_step": self.last_opt_step,
+                                  "flat": {k: v.detach().cpu().clone() for k, v in flat.items()}}}, path)

@@ -90,3 +90,38 @@ def test_more_labels_than_capacity_raises():
         plan.loss_items()
     plan.forward_backward(dict(batch, batch_idx=torch.tensor([0., 1.] * 5)))  # five per image: fits, and the flag was cleared
     plan.loss_items()
+
+
+def test_resume_continues_from_the_saved_optimizer_state(tmp_path):
+    """reference engine/trainer.py:1050-1105: last.pt after every epoch (when project/name name a run folder) carries the optimizer
+    state; ``YOLO(last.pt).train(resume=True)`` restores weights, momentum, EMA + update count, loss scale and step counters and
+    continues at the next epoch of the schedule."""
+    from ultralytics import YOLO
+    from ultralytics.data import SyntheticDetection
+    src = SyntheticDetection(n_batches=6, batch=4, imgsz=64, boxes_per_image=3, wh=(0.1, 0.4), seed=3)
+    kw = dict(batch=4, imgsz=64, optimizer="SGD", warmup_epochs=0.0, lr0=0.01, nbs=4, hipgraph=True, amp=False, project=str(tmp_path), name="run")
+    y = YOLO(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"))
+    y.train(data=src, epochs=2, **kw)
+    last = tmp_path / "run" / "weights" / "last.pt"
+    assert last.exists()
+    ck = torch.load(last, map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 1 and ck["updates"] == 12 and float(ck["optimizer"]["flat"]["state"][5]) == 12
+    saved = {k: v.clone() for k, v in ck["optimizer"]["flat"].items()}
+    import shutil
+    keep = tmp_path / "epoch2.pt"  # the resumed run below overwrites last.pt after each of its epochs
+    shutil.copy(last, keep)
+    y2 = YOLO(str(last))
+    hist = y2.train(data=src, resume=True, epochs=4, **kw)
+    tr = y2.trainer
+    assert tr.start_epoch == 2 and len(hist) == 2  # epochs 3 and 4 of 4
+    st = tr.plan.state.cpu()
+    assert float(st[5]) == 24 and tr.plan.ema_updates == 24 and tr.plan.opt_calls == 24
+    assert not torch.equal(tr.plan.mom.cpu(), saved["mom"])  # ... and it kept training
+    # the state the resumed run STARTED from is the saved one: replay the restore on a fresh trainer and compare
+    y3 = YOLO(str(keep))
+    y3.train(data=src, resume=True, epochs=2, **dict(kw, name="other"))  # nothing left to do: restores and returns
+    assert y3.trainer.start_epoch == 2
+    assert torch.equal(y3.trainer.plan.mom.cpu(), saved["mom"]) and torch.equal(y3.trainer.plan.ema.cpu(), saved["ema"])
+    assert torch.equal(y3.trainer.plan.rt.flat_p.cpu(), saved["p"]) and torch.equal(y3.trainer.plan.state.cpu(), saved["state"])
+    with pytest.raises(ValueError, match="no resumable optimizer state"):
+        YOLO(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml")).train(data=src, resume=os.path.join(os.path.dirname(CFG_DIR), "..", "..", "..", "tests", "golden", "ref_ckpt.pt"), **kw)
