@@ -157,8 +157,10 @@ struct WarpSlot {
   int flip, npatch;
   int patch[4][7];                 // pool index, x1a, y1a, x2a, y2a (destination, exclusive ends), source x, y of the rectangle's corner
   float hsv[3];                    // RandomHSV gains (hue, saturation, value multipliers); hsv[0] == 0: off
-  int pad_;
+  float pinv[3];                   // third row of the inverse map (RandomPerspective); (0, 0, 1) for an affine warp
+  double mix_r;                    // MixUp ratio of THIS image against the partner record that follows; < 0: no partner
 };
+static_assert(sizeof(WarpSlot) == 48 * 4, "WarpSlot is 48 words (ultralytics/data/dataset.py: warp_slot)");
 
 static __device__ __forceinline__ void warp_fetch(const unsigned char* pool, const WarpSlot& w, int S, int cx, int cy, float (&v)[3]) {
   v[0] = v[1] = v[2] = 114.f;
@@ -172,35 +174,50 @@ static __device__ __forceinline__ void warp_fetch(const unsigned char* pool, con
   v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2];
 }
 
+// one bilinear sample of a record's virtual canvas at output pixel (ox, oy), rounded and clamped to the uint8 range like
+// cv2.warpAffine / warpPerspective's uint8 result
+static __device__ __forceinline__ void warp_sample(const unsigned char* pool, const WarpSlot& w, int S, int ox, int oy, float (&px)[3]) {
+  const float fx = (float)ox, fy = (float)oy;
+  const float den = w.pinv[0] * fx + w.pinv[1] * fy + w.pinv[2];  // exactly 1 for an affine map
+  const float u = (w.minv[0] * fx + w.minv[1] * fy + w.minv[2]) / den;
+  const float vv = (w.minv[3] * fx + w.minv[4] * fy + w.minv[5]) / den;
+  const float fu = floorf(u), fv = floorf(vv);
+  const int x0 = (int)fu, y0 = (int)fv;
+  const float ax = u - fu, ay = vv - fv;
+  float c00[3], c01[3], c10[3], c11[3];
+  warp_fetch(pool, w, S, x0, y0, c00);
+  warp_fetch(pool, w, S, x0 + 1, y0, c01);
+  warp_fetch(pool, w, S, x0, y0 + 1, c10);
+  warp_fetch(pool, w, S, x0 + 1, y0 + 1, c11);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float top = c00[c] * (1.f - ax) + c01[c] * ax, bot = c10[c] * (1.f - ax) + c11[c] * ax;
+    px[c] = fminf(fmaxf(rintf(top * (1.f - ay) + bot * ay), 0.f), 255.f);
+  }
+}
+
+// slots: (N, 2) records -- the sample and its MixUp partner (read only when the sample's mix_r >= 0)
 __global__ __launch_bounds__(256) void warp_import_kernel(const unsigned char* pool, const WarpSlot* slots, f16* y, int N, int S, int Cp) {
   const long per = (long)S * S, total = per * N;
   for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long)gridDim.x * 256) {
     const int n = (int)(pix / per);
     const int r = (int)(pix - (long)n * per);
     int oy = r / S, ox = r - oy * S;
-    const WarpSlot& w = slots[n];
-    if (w.flip & 1) ox = S - 1 - ox;
+    const WarpSlot& w = slots[2 * n];
+    if (w.flip & 1) ox = S - 1 - ox;  // RandomFlip follows MixUp: both images are mirrored together
     if (w.flip & 2) oy = S - 1 - oy;
-    const float u = w.minv[0] * (float)ox + w.minv[1] * (float)oy + w.minv[2];
-    const float vv = w.minv[3] * (float)ox + w.minv[4] * (float)oy + w.minv[5];
-    const float fu = floorf(u), fv = floorf(vv);
-    const int x0 = (int)fu, y0 = (int)fv;
-    const float ax = u - fu, ay = vv - fv;
-    float c00[3], c01[3], c10[3], c11[3];
-    warp_fetch(pool, w, S, x0, y0, c00);
-    warp_fetch(pool, w, S, x0 + 1, y0, c01);
-    warp_fetch(pool, w, S, x0, y0 + 1, c10);
-    warp_fetch(pool, w, S, x0 + 1, y0 + 1, c11);
+    float px[3];
+    warp_sample(pool, w, S, ox, oy, px);
+    if (w.mix_r >= 0.0) {  // MixUp._mix_transform (augment.py:341): (img1 * r + img2 * (1 - r)).astype(np.uint8), float64, truncating
+      float p2[3];
+      warp_sample(pool, slots[2 * n + 1], S, ox, oy, p2);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) px[c] = (float)floor((double)px[c] * w.mix_r + (double)p2[c] * (1.0 - w.mix_r));
+    }
     half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
-    float px[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float top = c00[c] * (1.f - ax) + c01[c] * ax, bot = c10[c] * (1.f - ax) + c11[c] * ax;
-      px[c] = fminf(fmaxf(rintf(top * (1.f - ay) + bot * ay), 0.f), 255.f);
-    }
-    if (w.hsv[0] != 0.f) hsv_jitter(px, w.hsv[0], w.hsv[1], w.hsv[2]);  // RandomHSV follows the warp in the reference too
+    if (w.hsv[0] != 0.f) hsv_jitter(px, w.hsv[0], w.hsv[1], w.hsv[2]);  // RandomHSV follows the warp (and MixUp) in the reference too
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = (f16)(px[c] / 255.f);
     *reinterpret_cast<half8*>(y + pix * Cp) = o;
@@ -215,7 +232,7 @@ extern "C" int dy_warp_import_u8(const void* pool, const void* slots, void* y, i
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
-extern "C" int dy_warp_slot_bytes(void) { return (int)sizeof(WarpSlot); }
+extern "C" int dy_warp_slot_bytes(void) { return 2 * (int)sizeof(WarpSlot); }  // per sample: itself + its MixUp partner
 
 // ---- generic 8-channel-granule element-wise kernels
 struct EwArgs {

@@ -30,7 +30,8 @@ AUGMENT_KEYS = ("mosaic", "mixup", "copy_paste", "hsv_h", "hsv_s", "hsv_v", "deg
 
 
 def build_yolo_dataset(cfg, img_path, batch, data, mode="train", rect=False, stride=32, layout="nhwc", flip_on_device=False):
-    flips = {k: float(getattr(cfg, k, 0.0) or 0.0) for k in ("flipud", "fliplr", "mosaic", "degrees", "translate", "scale", "shear", "hsv_h", "hsv_s", "hsv_v")} if mode == "train" else {}
+    flips = {k: float(getattr(cfg, k, 0.0) or 0.0) for k in ("flipud", "fliplr", "mosaic", "degrees", "translate", "scale", "shear", "hsv_h", "hsv_s", "hsv_v",
+                                                             "perspective", "mixup", "copy_paste")} if mode == "train" else {}
     return YOLODataset(img_path=img_path, imgsz=cfg.imgsz, batch_size=batch, augment=mode == "train", flip_on_device=flip_on_device, **flips,
                        rect=bool(getattr(cfg, "rect", False)) or rect, stride=int(stride), pad=0.0 if mode == "train" else 0.5,
                        data=data, fraction=getattr(cfg, "fraction", 1.0) if mode == "train" else 1.0,

@@ -54,11 +54,15 @@ def letterbox_geometry(shape, new_shape, scaleup):
 class YOLODataset:
     def __init__(self, img_path, imgsz=640, batch_size=16, augment=False, rect=False, stride=32, pad=0.0, data=None, fraction=1.0,
                  cache=False, layout="nhwc", prefix="", flipud=0.0, fliplr=0.0, flip_on_device=False, mosaic=0.0, degrees=0.0,
-                 translate=0.0, scale=0.0, shear=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0):
+                 translate=0.0, scale=0.0, shear=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, perspective=0.0, mixup=0.0, copy_paste=0.0):
         self.img_path, self.imgsz, self.batch_size, self.augment, self.rect = img_path, int(imgsz), batch_size, augment, rect
         self.flipud, self.fliplr, self.flip_on_device = float(flipud), float(fliplr), flip_on_device
         self.mosaic, self.degrees, self.translate, self.scale, self.shear = (float(v) for v in (mosaic, degrees, translate, scale, shear))
-        self.geometric = augment and any((self.mosaic, self.degrees, self.translate, self.scale, self.shear))
+        self.perspective, self.mixup = float(perspective), float(mixup)
+        # copy_paste: the reference's CopyPaste only acts on segment labels (augment.py:`if self.p and len(instances.segments)`) and
+        # draws nothing before that test, so for box-only detection labels it is a no-op at any probability -- accepted and ignored
+        self.copy_paste = float(copy_paste)
+        self.geometric = augment and any((self.mosaic, self.degrees, self.translate, self.scale, self.shear, self.perspective, self.mixup))
         self.hsv = (float(hsv_h), float(hsv_s), float(hsv_v)) if augment and any((hsv_h, hsv_s, hsv_v)) else None
         self._label_cache = {}
         self.buffer, self._in_buffer = [], set()  # BaseDataset.buffer (base.py:86-87, :170-176): what Mosaic draws its partners from
@@ -167,18 +171,12 @@ class YOLODataset:
         if len(self.buffer) >= self.max_buffer_length:
             self._in_buffer.discard(self.buffer.pop(0))
 
-    def draw_augment(self, index=None):
-        """The random decisions of one training sample, drawn from Python's ``random`` in the reference's order (call this in
-        sample order from ONE thread; pixels and labels can then be produced by any worker).  Returns the flip bits (1 = left-
-        right, 2 = up-down) or, when a geometric augmentation is on, a dict with them plus the mosaic partners / centre and the
-        affine parameters."""
-        if not self.augment:
-            return 0
-        aug = None
-        if self.geometric:
-            self._touch(index)                                # get_image_and_label(index) ran before the transforms
-            aug = {"mosaic": None}
-        if random.uniform(0, 1) <= self.mosaic and self.geometric:   # Mosaic.__call__ (augment.py:105): skipped when u > p
+    def _draw_pre(self, index):
+        """Draws of the reference's ``pre_transform`` = Compose([Mosaic, CopyPaste, RandomPerspective]) for ONE sample, in its order
+        (augment.py:105-110, 159-162, 212, 406-425); ``get_image_and_label(index)`` ran before (buffer bookkeeping)."""
+        self._touch(index)
+        aug = {"mosaic": None}
+        if random.uniform(0, 1) <= self.mosaic:                      # Mosaic.__call__ (augment.py:105): skipped when u > p
             partners = random.choices(list(self.buffer), k=3)        # get_indexes(buffer=True) :159-162
             for i in partners:
                 self._touch(i)
@@ -186,14 +184,36 @@ class YOLODataset:
             yc = int(random.uniform(-b, 2 * self.imgsz + b))          # _mosaic4 :212 (y first)
             xc = int(random.uniform(-b, 2 * self.imgsz + b))
             aug["mosaic"] = (partners, yc, xc)
-        random.uniform(0, 0), random.uniform(0, 0)            # RandomPerspective.affine_transform :406-407 (perspective = 0)
+        px = random.uniform(-self.perspective, self.perspective)    # RandomPerspective.affine_transform :406-407
+        py = random.uniform(-self.perspective, self.perspective)
         a = random.uniform(-self.degrees, self.degrees)       # :411
         sc = random.uniform(1 - self.scale, 1 + self.scale)   # :413
         shx = math.tan(random.uniform(-self.shear, self.shear) * math.pi / 180)   # :419-420
         shy = math.tan(random.uniform(-self.shear, self.shear) * math.pi / 180)
         tx = random.uniform(0.5 - self.translate, 0.5 + self.translate)           # :424-425
         ty = random.uniform(0.5 - self.translate, 0.5 + self.translate)
-        random.uniform(0, 1)                                  # MixUp.__call__ probability check    :105
+        aug["affine"], aug["persp"] = (a, sc, shx, shy, tx, ty), (px, py)
+        return aug
+
+    def draw_augment(self, index=None):
+        """The random decisions of one training sample, drawn from Python's ``random`` (and numpy's global RNG for MixUp's ratio
+        and the HSV gains) in the reference's order (call this in sample order from ONE thread; pixels and labels can then be
+        produced by any worker).  Returns the flip bits (1 = left-right, 2 = up-down) or, when a geometric augmentation is on, a
+        dict with them plus the mosaic partners / centre, the affine + perspective parameters and the MixUp partner."""
+        if not self.augment:
+            return 0
+        aug = None
+        if self.geometric:
+            aug = self._draw_pre(index)
+            if random.uniform(0, 1) <= self.mixup:             # MixUp.__call__ (BaseMixTransform :105): mixes unless u > p
+                i2 = random.randint(0, len(self) - 1)          # MixUp.get_indexes :336
+                aug2 = self._draw_pre(i2)                      # get_image_and_label(i2), then pre_transform on it :112-116
+                aug["mix"] = (i2, aug2, float(np.random.beta(32.0, 32.0)))   # _mix_transform :340
+        else:
+            random.uniform(0, 1)                               # Mosaic's probability draw (p = 0)
+            for _ in range(8):                                 # RandomPerspective's eight draws (all ranges empty)
+                random.uniform(0, 0)
+            random.uniform(0, 1)                               # MixUp's probability draw (p = 0)
         gains = None
         if self.hsv is not None:                              # RandomHSV :613 -- numpy's global RNG, three draws per sample
             gains = (np.random.uniform(-1, 1, 3) * self.hsv + 1).astype(np.float32)
@@ -204,8 +224,6 @@ class YOLODataset:
             return flip
         aug = aug if aug is not None else {}
         aug.update(flip=flip, hsv=gains)
-        if self.geometric:
-            aug["affine"] = (a, sc, shx, shy, tx, ty)
         return aug
 
     def __getitem__(self, index):
@@ -253,11 +271,12 @@ class YOLODataset:
         return out
 
     def affine_matrix(self, aug, img_w, img_h, size):
-        """RandomPerspective.affine_transform (:384-435) with perspective 0: M = T @ S @ R @ P @ C in float32."""
+        """RandomPerspective.affine_transform (:384-435): M = T @ S @ R @ P @ C in float32."""
         a, sc, shx, shy, tx, ty = aug["affine"]
         Cm = np.eye(3, dtype=np.float32)
         Cm[0, 2], Cm[1, 2] = -img_w / 2, -img_h / 2
         P = np.eye(3, dtype=np.float32)
+        P[2, 0], P[2, 1] = aug.get("persp", (0.0, 0.0))
         R = np.eye(3, dtype=np.float32)
         al, be = sc * math.cos(math.radians(a)), sc * math.sin(math.radians(a))  # cv2.getRotationMatrix2D(angle, (0, 0), scale)
         R[:2] = np.array([[al, be, 0.0], [-be, al, 0.0]])
@@ -300,7 +319,8 @@ class YOLODataset:
         if n:
             pts = np.ones((n * 4, 3), dtype=xy.dtype)
             pts[:, :2] = xy[:, [0, 1, 2, 3, 0, 3, 2, 1]].reshape(n * 4, 2)  # x1y1, x2y2, x1y2, x2y1
-            pts = (pts @ M.T)[:, :2].reshape(n, 8)
+            pts = pts @ M.T
+            pts = (pts[:, :2] / pts[:, 2:3] if self.perspective else pts[:, :2]).reshape(n, 8)  # apply_bboxes :454
             px, py = pts[:, [0, 2, 4, 6]], pts[:, [1, 3, 5, 7]]
             new = np.concatenate((px.min(1), py.min(1), px.max(1), py.max(1)), dtype=xy.dtype).reshape(4, n).T
         else:
@@ -405,16 +425,21 @@ class YOLODataset:
                 s["hsv"] = torch.from_numpy(gains if gains is not None else np.ones(3, np.float32))
         return s
 
-    def warp_slot(self, index, aug, M):
-        """The 44-word record dy_warp_import_u8 reads for this sample (see include/dealyolo_hip.h): inverse affine map, canvas,
-        mosaic centre, flip bits, up to four (pool image, destination rectangle, source corner) patches.  Pool images are the
-        letterboxed s x s canvases the loader uploaded, so a patch's source corner is shifted by that image's letterbox pad."""
+    WARP_WORDS = 48  # one record; a sample carries two (itself + its MixUp partner, unused when it has none)
+
+    def warp_slot(self, index, aug, M, mix_r=None):
+        """The 48-word record dy_warp_import_u8 reads (see include/dealyolo_hip.h): inverse map (rows 0-1 in words 0-5, the
+        perspective row in 43-45), canvas, mosaic centre, flip bits, up to four (pool image, destination rectangle, source corner)
+        patches, HSV gains (40-42), MixUp ratio as float64 (46-47; negative: no partner).  Pool images are the letterboxed s x s
+        canvases the loader uploaded, so a patch's source corner is shifted by that image's letterbox pad."""
         s = self.imgsz
-        rec = np.zeros(44, dtype=np.int32)
+        rec = np.zeros(self.WARP_WORDS, dtype=np.int32)
         if aug.get("hsv") is not None:
             rec[40:43] = np.asarray(aug["hsv"], np.float32).view(np.int32)
-        minv = np.linalg.inv(M.astype(np.float64))[:2].astype(np.float32)  # cv2.warpAffine inverts the forward map
-        rec[:6] = minv.reshape(-1).view(np.int32)
+        minv = np.linalg.inv(M.astype(np.float64)).astype(np.float32)  # cv2.warpAffine / warpPerspective invert the forward map
+        rec[:6] = minv[:2].reshape(-1).view(np.int32)
+        rec[43:46] = (minv[2] if self.perspective else np.array([0, 0, 1], np.float32)).view(np.int32)
+        rec[46:48] = np.array([-1.0 if mix_r is None else mix_r], np.float64).view(np.int32)
 
         def pad_of(i):
             h, w = self._hw(i)
@@ -423,22 +448,29 @@ class YOLODataset:
 
         if aug["mosaic"] is not None:
             _, yc, xc = aug["mosaic"]
-            rec[6:12] = (2 * s, 2 * s, xc, yc, aug["flip"], 4)
+            rec[6:12] = (2 * s, 2 * s, xc, yc, aug.get("flip", 0), 4)
             for k, (i, x1a, y1a, x2a, y2a, x1b, y1b) in enumerate(self.mosaic_layout(index, aug)):
                 left, top = pad_of(i)
                 rec[12 + 7 * k:19 + 7 * k] = (i, x1a, y1a, x2a, y2a, x1b + left, y1b + top)
         else:
-            rec[6:12] = (s, s, s, s, aug["flip"], 1)
+            rec[6:12] = (s, s, s, s, aug.get("flip", 0), 1)
             rec[12:19] = (index, 0, 0, s, s, 0, 0)
         return rec
 
     def _get_geometric(self, index, aug, pixels):
-        """Mosaic / affine sample: labels on the host; the pixels of this path are composed on the device from the loader's HBM
-        pool (the reference warps with cv2), so only ``pixels=False`` is served here."""
+        """Mosaic / affine / perspective / MixUp sample: labels on the host; the pixels of this path are composed on the device
+        from the loader's HBM pool (the reference warps with cv2), so only ``pixels=False`` is served here."""
         if pixels:
             raise NotImplementedError("mosaic / affine pixels are composed on the device from the HBM image pool (cache='hbm')")
         lab = self.labels[index]
         xy, cls, (W, H), M = self._geo_labels(index, aug)
+        mix = aug.get("mix")
+        rec2 = np.zeros(self.WARP_WORDS, dtype=np.int32)
+        if mix is not None:  # MixUp._mix_transform (augment.py:338-345): the partner went through the same pre_transform
+            i2, aug2, r = mix
+            xy2, cls2, _, M2 = self._geo_labels(i2, aug2)
+            xy, cls = np.concatenate((xy, xy2), 0), np.concatenate((cls, cls2), 0)
+            rec2 = self.warp_slot(i2, aug2, M2)
         flip = aug["flip"]
         out = np.empty_like(xy)
         out[:, 0], out[:, 1] = (xy[:, 0] + xy[:, 2]) / 2, (xy[:, 1] + xy[:, 3]) / 2
@@ -454,7 +486,7 @@ class YOLODataset:
         s["cls"] = torch.from_numpy(cls) if nl else torch.zeros(nl)
         s["bboxes"] = torch.from_numpy(out) if nl else torch.zeros((nl, 4))
         s["batch_idx"] = torch.zeros(nl)
-        s["warp"] = torch.from_numpy(self.warp_slot(index, aug, M))
+        s["warp"] = torch.from_numpy(np.concatenate((self.warp_slot(index, aug, M, None if mix is None else mix[2]), rec2)))
         return s
 
     @staticmethod

@@ -214,13 +214,12 @@ class DetectionTrainer:
         from ..data import build_dataloader, build_yolo_dataset
         a = self.args
         if mode == "train":
-            geo = [k for k in ("mosaic", "degrees", "translate", "scale", "shear") if getattr(a, k, 0)]
-            off = [k for k in ("mixup", "copy_paste", "perspective") if getattr(a, k, 0)]  # HSV jitter runs in the import kernels
-            if geo and a.cache != "hbm":  # mosaic / affine pixels are composed on the device from the HBM image pool
+            # HSV jitter and flips run in the import kernels; mosaic / affine / perspective / MixUp pixels are composed on the device
+            # from the HBM image pool; copy_paste is a no-op for box-only labels, as in the reference
+            geo = [k for k in ("mosaic", "degrees", "translate", "scale", "shear", "perspective", "mixup") if getattr(a, k, 0)]
+            if geo and a.cache != "hbm":
                 LOGGER.warning(f"WARNING augmentations {geo} need cache='hbm' (device-side composition): training without them")
                 a = type(a)(**{**vars(a), **{k: 0.0 for k in geo}})
-            if off:
-                LOGGER.warning(f"WARNING augmentations {off} are not on this path: training without them")
         ds = build_yolo_dataset(a, dataset_path, batch_size, data, mode=mode, rect=mode == "val", stride=32,
                                 layout="nhwc" if mode == "train" else "nchw", flip_on_device=mode == "train")
         return build_dataloader(ds, batch_size, a.workers, shuffle=mode == "train", rank=rank if self.world_size > 1 else -1,

@@ -60,7 +60,7 @@ class StepPlan:
         self.input_u8 = False  # decided by the first batch: uint8 NHWC (the loader's format) or float NCHW (the public tensor API)
         self.flip = None       # (B,) uint8 flip bits when the first loader batch carries them (flips folded into the import kernel)
         self.pool = self.index = None  # HBM-resident image pool + (B,) int32 slots when the loader keeps the dataset on the device
-        self.warp = None               # (B,44) int32 mosaic/affine records: the pool is then read through dy_warp_import_u8
+        self.warp = None               # (B,96) int32 mosaic / affine / perspective / MixUp records (two 48-word records per sample): the pool is then read through dy_warp_import_u8
         self.hsv = None                # (B,3) float32 RandomHSV gains applied inside dy_import_image_u8
         self.rec_fb = None
         self.rec_opt, self.graph_opt = {}, {}

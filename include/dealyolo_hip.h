@@ -139,11 +139,13 @@ int dy_import_image(const float* x_nchw, void* y, int n, int c, int h, int w, in
  * hsv: NULL, or n x 3 floats -- RandomHSV's hue / saturation / value gains of image i (data/augment.py:605-624). */
 int dy_import_image_u8(const void* x, void* y, int n, int h, int w, int cp, const void* flip, const int* index,
                        const float* hsv, hipStream_t stream);
-/* Mosaic (data/augment.py:208-241) + random affine (cv2.warpAffine of RandomPerspective :384-435, border 114) + flips, composed
- * from an HBM-resident pool of letterboxed s x s uint8 images straight into the fp16 NHWC stem input.  slots: n records of
- * dy_warp_slot_bytes() bytes = { float minv[6] (output pixel -> canvas); int canvas_w, canvas_h, xc, yc, flip, npatch;
+/* Mosaic (data/augment.py:208-241) + random affine / perspective (cv2.warpAffine | warpPerspective of RandomPerspective :384-435,
+ * border 114) + MixUp (:326-345) + flips, composed from an HBM-resident pool of letterboxed s x s uint8 images straight into the
+ * fp16 NHWC stem input.  slots: n x 2 records (dy_warp_slot_bytes() bytes per sample: the sample, then its MixUp partner) of
+ * 48 words = { float minv[6] (output pixel -> canvas, rows 0-1 of the inverse map); int canvas_w, canvas_h, xc, yc, flip, npatch;
  * int patch[4][7] = pool index, destination x1,y1,x2,y2 on the canvas, source x,y; float hsv[3] (RandomHSV gains, 0 = off);
- * int pad } built on the host from the random draws. */
+ * float pinv[3] (row 2 of the inverse map; 0,0,1 when affine); double mix_r (MixUp ratio of this image; < 0: no partner) },
+ * built on the host from the random draws. */
 int dy_warp_import_u8(const void* pool, const void* slots, void* y, int n, int s, int cp, hipStream_t stream);
 int dy_warp_slot_bytes(void);
 int dy_add(const void* a, int lda, const void* b, int ldb, const void* c, int ldc, void* y, int ldy, long npix, int C,

@@ -729,6 +729,55 @@ def gen_data():
     shutil.rmtree(root)
 
 
+def gen_data_mix():
+    """MixUp + perspective (+ CopyPaste, a no-op for box-only labels: augment.py's CopyPaste only acts on segments) on top of the
+    mosaic / affine / flip pipeline: labels of the REFERENCE pipeline over three epochs (pixels are not part of the fixture: cv2's
+    warps are absent and stand in as grey canvases, as in gen_data).  Python's random seeded 13, numpy's (MixUp's beta draw) 5."""
+    import math
+    import random
+    import shutil
+    import tempfile
+    import cv2
+    from ultralytics.data import build_dataloader, build_yolo_dataset
+
+    def copy_make_border(img, top, bottom, left, right, border_type, value=(0, 0, 0)):
+        out = np.empty((img.shape[0] + top + bottom, img.shape[1] + left + right, img.shape[2]), img.dtype)
+        out[...] = np.asarray(value, img.dtype)
+        out[top:top + img.shape[0], left:left + img.shape[1]] = img
+        return out
+
+    def rotation_matrix(angle, center, scale):
+        a, b = scale * math.cos(math.radians(angle)), scale * math.sin(math.radians(angle))
+        return np.array([[a, b, (1 - a) * center[0] - b * center[1]], [-b, a, b * center[0] + (1 - a) * center[1]]])
+
+    def grey_warp(img, M, dsize=None, borderValue=(114, 114, 114), **k):
+        return np.full((dsize[1], dsize[0], 3), 114, np.uint8)
+
+    cv2.copyMakeBorder, cv2.getRotationMatrix2D = copy_make_border, rotation_matrix
+    cv2.warpAffine = cv2.warpPerspective = grey_warp
+    cv2.BORDER_CONSTANT, cv2.INTER_LINEAR = 0, 1
+    root = tempfile.mkdtemp(prefix="dy_dataset_")
+    write_dataset(root)
+    data = {"names": {0: "a", 1: "b", 2: "c", 3: "d"}, "nc": 4}
+    mix = dict(mosaic=0.7, mixup=0.5, copy_paste=0.3, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, degrees=5.0, translate=0.1, scale=0.5, shear=2.0,
+               perspective=0.0005, flipud=0.1, fliplr=0.5)
+    cfg = get_cfg(DEFAULT_CFG, overrides=dict(imgsz=DATASET_IMGSZ, task="detect", **mix))
+    ds = build_yolo_dataset(cfg, os.path.join(root, "images", "train"), 4, data, mode="train")
+    loader = build_dataloader(ds, 4, 0, shuffle=True, rank=-1)
+    arrs = {}
+    random.seed(13)
+    np.random.seed(5)
+    for ep in range(3):
+        for i, batch in enumerate(loader):
+            tag = f"mix/e{ep}/b{i}"
+            arrs[f"{tag}/cls"] = batch["cls"].reshape(-1, 1)
+            arrs[f"{tag}/bboxes"] = batch["bboxes"].reshape(-1, 4)
+            arrs[f"{tag}/batch_idx"] = batch["batch_idx"]
+            arrs[f"{tag}/files"] = np.array([os.path.basename(f) for f in batch["im_file"]])
+    npz("data_mix", **arrs)
+    shutil.rmtree(root)
+
+
 def gen_two_stage():
     """Two-stage inference: outputs of the reference script's OWN functions.  double_inference.py is
     a Kaggle script whose import has side effects (creates /kaggle/... folders, opens a log file), so only its function

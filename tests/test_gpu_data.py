@@ -136,71 +136,82 @@ def test_device_flips_equal_host_flips(tmp_path):
             assert torch.equal(a0, a1) and torch.equal(l0, l1)
 
 
-def test_device_mosaic_affine_matches_host_composition(tmp_path):
-    """dy_warp_import_u8 (mosaic of four pool images + affine warp + flips, sampled straight into the fp16 stem input) against a
-    numpy composition of the same thing: the 2s x 2s canvas built by slicing like Mosaic._mosaic4, then one float bilinear
-    sample per output pixel through the inverse affine map with a 114 border.  (The labels of this pipeline are pinned against
-    the reference in tests/test_host_data.py; cv2's fixed-point interpolation is not reproduced.)"""
+def _host_warp(ds, j, aug, S):
+    """numpy composition of one record: the canvas built by slicing like Mosaic._mosaic4 (or the letterboxed image), then one float
+    bilinear sample per output pixel through the inverse (affine or projective) map with a 114 border, rounded to uint8 values."""
+    from ultralytics.data.dataset import letterbox_geometry
+    if aug["mosaic"] is not None:
+        canvas = np.full((2 * S, 2 * S, 3), 114, np.float32)
+        for i, x1a, y1a, x2a, y2a, x1b, y1b in ds.mosaic_layout(j, aug):
+            im = ds.load_image(i)[0]
+            canvas[y1a:y2a, x1a:x2a] = im[y1b:y1b + (y2a - y1a), x1b:x1b + (x2a - x1a)]
+    else:
+        im, _, (h, w) = ds.load_image(j)
+        _, _, _, (top, bottom, left, right) = letterbox_geometry((h, w), (S, S), scaleup=True)
+        canvas = np.full((S, S, 3), 114, np.float32)
+        canvas[top:top + h, left:left + w] = im
+    M = ds.affine_matrix(aug, canvas.shape[1], canvas.shape[0], (S, S))
+    minv = np.linalg.inv(M.astype(np.float64)).astype(np.float32)
+    oy, ox = np.meshgrid(np.arange(S, dtype=np.float32), np.arange(S, dtype=np.float32), indexing="ij")
+    den = minv[2, 0] * ox + minv[2, 1] * oy + minv[2, 2] if ds.perspective else np.float32(1.0)
+    u = (minv[0, 0] * ox + minv[0, 1] * oy + minv[0, 2]) / den
+    v = (minv[1, 0] * ox + minv[1, 1] * oy + minv[1, 2]) / den
+    x0, y0 = np.floor(u).astype(int), np.floor(v).astype(int)
+    ax, ay = (u - np.floor(u))[..., None], (v - np.floor(v))[..., None]
+    padded = np.full((canvas.shape[0] + 4, canvas.shape[1] + 4, 3), 114, np.float32)
+    padded[2:-2, 2:-2] = canvas
+
+    def at(yy, xx):
+        ok = (yy >= -2) & (yy < canvas.shape[0] + 2) & (xx >= -2) & (xx < canvas.shape[1] + 2)
+        res = padded[np.clip(yy + 2, 0, padded.shape[0] - 1), np.clip(xx + 2, 0, padded.shape[1] - 1)]
+        res[~ok] = 114
+        return res
+
+    top_ = at(y0, x0) * (1 - ax) + at(y0, x0 + 1) * ax
+    bot_ = at(y0 + 1, x0) * (1 - ax) + at(y0 + 1, x0 + 1) * ax
+    return np.clip(np.rint(top_ * (1 - ay) + bot_ * ay), 0, 255)
+
+
+@pytest.mark.parametrize("extra", [{}, dict(mixup=0.6, perspective=0.0008, copy_paste=0.5)], ids=["mosaic+affine", "+mixup+perspective"])
+def test_device_mosaic_affine_matches_host_composition(tmp_path, extra):
+    """dy_warp_import_u8 (mosaic of four pool images + affine / perspective warp + MixUp blend + flips, sampled straight into the
+    fp16 stem input) against a numpy composition of the same thing.  (The labels of this pipeline are pinned against the reference
+    in tests/test_host_data.py; cv2's fixed-point interpolation is not reproduced.)"""
     import random
     from types import SimpleNamespace
     from ultralytics.data import build_dataloader, build_yolo_dataset, check_det_dataset
-    from ultralytics.data.dataset import letterbox_geometry
     from ultralytics.hip.engine import Engine
     root = str(tmp_path / "ds")
     write_dataset(root)
     data = check_det_dataset(os.path.join(root, "data.yaml"))
     S = 64
     cfg = SimpleNamespace(imgsz=S, rect=False, cache="hbm", fraction=1.0, fliplr=0.5, flipud=0.25, mosaic=0.7, degrees=8.0, translate=0.1,
-                          scale=0.5, shear=3.0)
+                          scale=0.5, shear=3.0, **extra)
     eng = Engine("cuda:0")
     ds = build_yolo_dataset(cfg, data["train"], 4, data, mode="train", flip_on_device=True)
     ref_ds = build_yolo_dataset(cfg, data["train"], 4, data, mode="train", flip_on_device=True)
     loader = build_dataloader(ds, 4, 2, shuffle=True, device="cuda:0", drop_last=True)
     random.seed(21)
+    np.random.seed(3)
     got = []
     for b in loader:
         assert "warp" in b and b["img"].shape[0] == len(ds)
         got.append((eng.import_warp(b["img"], b["warp"].contiguous(), 8).st.buf.clone(), b["bboxes"].clone()))
     random.seed(21)
+    np.random.seed(3)
     order = build_dataloader(ref_ds, 4, 2, shuffle=True, drop_last=True)._indices()
-    worst, mosaics = 0.0, 0
+    worst, mosaics, mixes = 0.0, 0, 0
     for bi, (act, boxes) in enumerate(got):
         out = (act[..., :3].float().cpu().numpy() * 255).round()
         assert (act[..., 3:] == 0).all()
         for k, j in enumerate(order[bi * 4:(bi + 1) * 4]):
             aug = ref_ds.draw_augment(j)
-            if aug["mosaic"] is not None:
-                mosaics += 1
-                canvas = np.full((2 * S, 2 * S, 3), 114, np.float32)
-                for i, x1a, y1a, x2a, y2a, x1b, y1b in ref_ds.mosaic_layout(j, aug):
-                    im = ref_ds.load_image(i)[0]
-                    canvas[y1a:y2a, x1a:x2a] = im[y1b:y1b + (y2a - y1a), x1b:x1b + (x2a - x1a)]
-                size = (S, S)
-            else:
-                im, _, (h, w) = ref_ds.load_image(j)
-                _, _, _, (top, bottom, left, right) = letterbox_geometry((h, w), (S, S), scaleup=True)
-                canvas = np.full((S, S, 3), 114, np.float32)
-                canvas[top:top + h, left:left + w] = im
-                size = (S, S)
-            M = ref_ds.affine_matrix(aug, canvas.shape[1], canvas.shape[0], size)
-            minv = np.linalg.inv(M.astype(np.float64))[:2].astype(np.float32)
-            oy, ox = np.meshgrid(np.arange(S, dtype=np.float32), np.arange(S, dtype=np.float32), indexing="ij")
-            u = minv[0, 0] * ox + minv[0, 1] * oy + minv[0, 2]
-            v = minv[1, 0] * ox + minv[1, 1] * oy + minv[1, 2]
-            x0, y0 = np.floor(u).astype(int), np.floor(v).astype(int)
-            ax, ay = (u - np.floor(u))[..., None], (v - np.floor(v))[..., None]
-            padded = np.full((canvas.shape[0] + 4, canvas.shape[1] + 4, 3), 114, np.float32)
-            padded[2:-2, 2:-2] = canvas
-
-            def at(yy, xx):
-                ok = (yy >= -2) & (yy < canvas.shape[0] + 2) & (xx >= -2) & (xx < canvas.shape[1] + 2)
-                res = padded[np.clip(yy + 2, 0, padded.shape[0] - 1), np.clip(xx + 2, 0, padded.shape[1] - 1)]
-                res[~ok] = 114
-                return res
-
-            top_ = at(y0, x0) * (1 - ax) + at(y0, x0 + 1) * ax
-            bot_ = at(y0 + 1, x0) * (1 - ax) + at(y0 + 1, x0 + 1) * ax
-            ref = np.clip(np.rint(top_ * (1 - ay) + bot_ * ay), 0, 255)
+            mosaics += aug["mosaic"] is not None
+            ref = _host_warp(ref_ds, j, aug, S)
+            if "mix" in aug:  # MixUp._mix_transform: (img1 * r + img2 * (1 - r)).astype(np.uint8)
+                mixes += 1
+                i2, aug2, r = aug["mix"]
+                ref = np.floor(ref.astype(np.float64) * r + _host_warp(ref_ds, i2, aug2, S).astype(np.float64) * (1 - r))
             if aug["flip"] & 1:
                 ref = ref[:, ::-1]
             if aug["flip"] & 2:
@@ -208,7 +219,7 @@ def test_device_mosaic_affine_matches_host_composition(tmp_path):
             d = np.abs(out[k] - ref)
             worst = max(worst, float((d > 1).mean()))
             assert (d > 1).mean() < 5e-3 and (d > 0).mean() < 0.05, (bi, k, (d > 1).mean(), (d > 0).mean())
-    assert mosaics >= 2
+    assert mosaics >= 2 and (mixes >= 2 or not extra)
 
 
 def test_train_with_device_side_mosaic(tmp_path):
@@ -217,8 +228,8 @@ def test_train_with_device_side_mosaic(tmp_path):
     write_dataset(root)
     y = YOLO("yolov8n-ASF-P2P2.yaml")
     hist = y.train(data=os.path.join(root, "data.yaml"), batch=4, imgsz=64, epochs=3, optimizer="SGD", workers=2, hipgraph=True, val=False,
-                   cache="hbm", mosaic=1.0, degrees=5.0, translate=0.1, scale=0.5, shear=2.0, fliplr=0.5, mixup=0.0, copy_paste=0.0,
-                   hsv_h=0.015, hsv_s=0.7, hsv_v=0.4, perspective=0.0, flipud=0.0, close_mosaic=1)  # the reference's default gains
+                   cache="hbm", mosaic=1.0, degrees=5.0, translate=0.1, scale=0.5, shear=2.0, fliplr=0.5, mixup=0.3, copy_paste=0.3,
+                   hsv_h=0.015, hsv_s=0.7, hsv_v=0.4, perspective=0.0005, flipud=0.0, close_mosaic=1)  # the default gains + MixUp + perspective
     assert y.trainer.plan.warp is not None and np.isfinite(np.asarray(hist, dtype=np.float64)).all()
     assert y.trainer.train_loader.dataset.mosaic == 0.0  # closed for the last epoch, the affine / HSV / flip path went on
     # a batch larger than the dataset is clamped to it (data/build.py:104), and a mosaic's four images' labels fit the plan

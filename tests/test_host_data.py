@@ -163,3 +163,33 @@ def test_data_yaml_errors(tmp_path):
         check_det_dataset(str(p))
     with pytest.raises(FileNotFoundError):
         check_det_dataset(str(tmp_path / "missing.yaml"))
+
+
+def test_mixup_perspective_labels_identical_to_reference(root):
+    """MixUp 0.5 + perspective 5e-4 (+ copy_paste 0.3: a no-op for box-only labels in the reference too) on top of mosaic 0.7, the
+    affine gains and the flips: the nested draw order of the reference's pipeline -- Mosaic and RandomPerspective of the sample,
+    MixUp's probability, its partner index, the partner's own Mosaic / RandomPerspective draws, numpy's beta(32, 32) -- and the
+    perspective divide in the box transform, label for label over three epochs (tests/golden/data_mix.npz)."""
+    import random
+    G = np.load(os.path.join(os.path.dirname(GOLD), "data_mix.npz"))
+    loader = _loader(root, "train", geo=dict(mosaic=0.7, mixup=0.5, copy_paste=0.3, degrees=5.0, translate=0.1, scale=0.5, shear=2.0, perspective=0.0005),
+                     fliplr=0.5, flipud=0.1)
+    ds = loader.dataset
+    random.seed(13)
+    np.random.seed(5)
+    n_boxes = n_mix = 0
+    for ep in range(3):
+        idx = loader._indices()
+        for i in range(len(loader)):
+            chunk = idx[i * 4:(i + 1) * 4]
+            augs = [ds.draw_augment(j) for j in chunk]
+            n_mix += sum("mix" in a for a in augs)
+            batch = ds.collate_fn([ds.get(j, a, pixels=False) for j, a in zip(chunk, augs)])
+            tag = f"mix/e{ep}/b{i}"
+            assert [os.path.basename(f) for f in batch["im_file"]] == list(G[f"{tag}/files"]), tag
+            for k in ("cls", "bboxes", "batch_idx"):
+                ref = torch.from_numpy(G[f"{tag}/{k}"])
+                assert batch[k].shape == ref.shape and torch.equal(batch[k], ref), (tag, k, batch[k][:6], ref[:6])
+            assert batch["warp"].shape == (len(chunk), 96)
+            n_boxes += len(batch["cls"])
+    assert n_boxes > 50 and n_mix >= 5
