@@ -50,8 +50,9 @@ class DetectionTrainer:
             lr_fit = round(0.002 * 5 / (4 + nc), 6)
             name, lr, mom = ("SGD", 0.01, 0.9) if iterations > 10000 else ("AdamW", lr_fit, 0.9)
             self.args.warmup_bias_lr = 0.0
-        if name not in ("SGD", "Adam", "AdamW", "RMSProp", "RAdam", "Adamax", "NAdam"):
-            raise NotImplementedError(f"optimizer '{name}' is not on the HIP path (SGD, Adam, AdamW, Adamax, NAdam, RAdam, RMSProp, auto)")
+        if name not in ("SGD", "Adam", "AdamW", "RMSProp", "RAdam", "Adamax", "NAdam", "SOAP"):
+            raise NotImplementedError(f"Optimizer '{name}' not found in list of available optimizers "
+                                      "[Adam, AdamW, NAdam, RAdam, RMSProp, SGD, SOAP, auto].")
         return name, lr, mom
 
     def setup(self, batches_per_epoch, batch_size, imgsz):
@@ -74,6 +75,7 @@ class DetectionTrainer:
         n_images = self.dataset_len if self.dataset_len is not None else batches_per_epoch * global_bs
         iterations = math.ceil(n_images / max(global_bs, a.nbs)) * a.epochs
         name, self.lr0, self.momentum = self._optimizer_choice(iterations, self.model.model[-1].nc)
+        self.opt_name = name
         self._plan_kw = dict(nmax=getattr(a, "nmax", None) or 16, optimizer=name, world_size=self.world_size, use_graph=bool(a.hipgraph),
                              init_scale=float(a.loss_scale) if a.amp else 1.0, dynamic_scale=bool(a.amp))
         self.plan = StepPlan(self.model, batch_size, imgsz, **self._plan_kw)
@@ -99,7 +101,8 @@ class DetectionTrainer:
             xi = [0, self.nw]
             acc = max(1, int(np.interp(ni, xi, [1, a.nbs / (p.B * self.world_size)]).round()))
             lr = [float(np.interp(ni, xi, [a.warmup_bias_lr if j == 0 else 0.0, self.lr0 * self.lf(epoch)])) for j in range(3)]
-            mom = float(np.interp(ni, xi, [a.warmup_momentum, self.momentum]))
+            if self.opt_name in ("SGD", "RMSProp"):  # reference :791 ``if "momentum" in x``: only these param groups have the key;
+                mom = float(np.interp(ni, xi, [a.warmup_momentum, self.momentum]))  # Adam-family / SOAP betas are never warmed up
         p.set_hyper(lr, mom, [0.0, self.wd, 0.0])
         self._plan_for(batch).forward_backward(batch)  # writes the shared flat gradient buffer; everything below is the main plan's
         if self.accumulate > 1 or acc > 1 or p._micro:

@@ -35,7 +35,10 @@ class StepPlan:
         self.B, self.imgsz, self.nmax = batch_size, (imgsz, imgsz) if isinstance(imgsz, int) else tuple(imgsz), nmax
         self.world_size = world_size
         self.use_graph = use_graph
-        self.mode = {"SGD": 0, "Adam": 1, "AdamW": 2, "RMSProp": 3, "RAdam": 4, "Adamax": 5, "NAdam": 6}[optimizer]
+        self.soap = optimizer == "SOAP"  # host-driven (hip/soap.py); the flat kernel then only keeps EMA / loss scale / counters
+        self.mode = {"SGD": 0, "Adam": 1, "AdamW": 2, "RMSProp": 3, "RAdam": 4, "Adamax": 5, "NAdam": 6, "SOAP": 0}[optimizer]
+        if self.soap and use_graph:
+            use_graph = self.use_graph = False  # eigh / QR are not captured; SOAP steps run eagerly
         self.hyper_host = (C.c_float * 16)()  # read by dy_set_hyper at enqueue time (the values travel as kernel arguments)
         if share is not None:
             if share.model is not model or share.mode != self.mode:
@@ -76,6 +79,9 @@ class StepPlan:
         h = self.hyper_host
         if ema_decay is None:
             ema_decay = 0.9999 * (1 - math.exp(-(self.ema_updates + 1) / 2000))
+        self._hyp = dict(lr=[float(v) for v in lr], momentum=float(momentum), wd=[float(v) for v in wd], max_norm=float(max_norm))
+        if self.soap:  # the parameter update happens on the host side; the kernel runs with zero step size
+            lr, wd = [0.0] * 3, [0.0] * 3
         vals = [*lr, momentum, *wd, ema_decay, max_norm, beta2, eps, 1.0 if self.dynamic_scale else 0.0]
         for i, v in enumerate(vals):
             h[i] = float(v)
@@ -231,9 +237,33 @@ class StepPlan:
             self.eng.call("dy_axpy_f32", self.gsum.data_ptr(), self.rt.flat_g.data_ptr(), 1.0, n)
         self._micro += 1
 
+    def _soap_step(self, grads):
+        """optimizer='SOAP' (reference engine/trainer.py:1156-1165): unscale + global-norm clip like ``optimizer_step`` does, then
+        hip/soap.py over views of the flat parameter buffer.  Synchronises (non-finite gradients skip the step, as GradScaler does)."""
+        rt = self.rt
+        if getattr(self, "_soap", None) is None:
+            from .soap import Soap
+            b0, b1 = rt.group_bounds[0], rt.group_bounds[1]
+            views = []
+            for n, p in self.model.named_parameters():
+                if p.requires_grad:
+                    o = rt.param_off[n]
+                    views.append((n, o, p.numel(), tuple(p.shape), 0 if o < b0 else (1 if o < b1 else 2)))
+            self._soap_views = views
+            self._soap = Soap([(rt.flat_p[o:o + k].view(sh), g) for _, o, k, sh, g in views], beta1=self._hyp["momentum"], beta2=0.95)
+        g = grads[:rt.n_params_flat]
+        if not bool(torch.isfinite(g).all()):
+            return  # the kernel below sees the same non-finite gradients and counts the skip
+        scale = float(self.state[0])
+        norm = float(g.norm()) / scale
+        coef = min(self._hyp["max_norm"] / (norm + 1e-6), 1.0) / scale
+        self._soap.step([g[o:o + k].view(sh) * coef for _, o, k, sh, _ in self._soap_views], self._hyp["lr"], self._hyp["wd"])
+
     def optimizer_step(self):
         rt, eng = self.rt, self.eng
         grads = self.gsum if self._micro else rt.flat_g
+        if self.soap:
+            self._soap_step(grads)
         key = grads.data_ptr()
         if key not in self.rec_opt:
             eng.rec = Recorder()

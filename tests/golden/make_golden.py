@@ -446,6 +446,27 @@ def gen_tal_filler():
     npz("tal_filler", **arrs)
 
 
+def gen_soap():
+    """The reference trainer's SOAP class (engine/trainer.py:54-473), built as build_optimizer builds it (:1156-1165), over a few
+    small tensors for 25 steps of seeded gradients (two QR refreshes of the eigenbases): parameters after steps 1, 2, 11 and 25."""
+    from ultralytics.engine.trainer import SOAP
+    shapes = [((16,), 0), ((16, 8, 3, 3), 1), ((8, 16, 1, 1), 1), ((24, 6), 1), ((8,), 2)]
+    ps = [torch.nn.Parameter(rnd(50 + i, *sh, scale=0.5)) for i, (sh, _) in enumerate(shapes)]
+    groups = [[p for p, (_, g) in zip(ps, shapes) if g == k] for k in range(3)]
+    opt = SOAP(groups[0], lr=0.01, betas=(0.937, 0.95), weight_decay=0.0)
+    opt.add_param_group({"params": groups[1], "weight_decay": 5e-4})
+    opt.add_param_group({"params": groups[2], "weight_decay": 0.0})
+    arrs = {"shapes": np.array([str(sh) for sh, _ in shapes]), "groups": np.array([g for _, g in shapes])}
+    for step in range(1, 26):
+        for i, p in enumerate(ps):
+            p.grad = rnd(1000 + 31 * step + i, *p.shape, scale=1.0) * (1.0 + 0.1 * i) + 0.05 * p.detach()
+        opt.step()
+        if step in (1, 2, 11, 25):
+            for i, p in enumerate(ps):
+                arrs[f"step{step}/p{i}"] = p.detach().clone()
+    npz("soap", **arrs)
+
+
 def gen_init():
     """What a freshly constructed reference model holds after torch.manual_seed(0): per-entry sum and abs-sum of the state dict
     (weights come from the global RNG in construction order; BN buffers carry the side effects of the stride-probe forward)."""

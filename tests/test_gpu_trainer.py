@@ -125,3 +125,22 @@ def test_resume_continues_from_the_saved_optimizer_state(tmp_path):
     assert torch.equal(y3.trainer.plan.rt.flat_p.cpu(), saved["p"]) and torch.equal(y3.trainer.plan.state.cpu(), saved["state"])
     with pytest.raises(ValueError, match="no resumable optimizer state"):
         YOLO(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml")).train(data=src, resume=os.path.join(os.path.dirname(CFG_DIR), "..", "..", "..", "tests", "golden", "ref_ckpt.pt"), **kw)
+
+
+def test_soap_is_selectable_by_name_and_trains():
+    """optimizer='SOAP' (reference engine/trainer.py:1156-1165; the optimizer itself is pinned against the reference's class on
+    the CPU, tests/test_host_logic.py): unscale + clip + SOAP over the flat parameter views, EMA / counters through the kernels."""
+    from ultralytics import YOLO
+    from ultralytics.data import SyntheticDetection
+    src = SyntheticDetection(n_batches=10, batch=4, imgsz=64, boxes_per_image=3, wh=(0.1, 0.4), seed=3)
+    y = YOLO(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"))
+    hist = y.train(data=src, batch=4, imgsz=64, epochs=3, optimizer="SOAP", warmup_epochs=0.0, lr0=0.003, nbs=4, amp=False)
+    plan = y.trainer.plan
+    assert plan.soap and not plan.use_graph and plan._soap is not None
+    taken, skipped, _ = plan.check_progress()
+    assert (taken, skipped) == (30, 0) and all(torch.isfinite(h).all() for h in hist)
+    assert float(sum(hist[-1])) < float(sum(hist[0]))
+    st = plan._soap.state[1]  # a conv weight: Gram matrices per dimension, eigenbases refreshed
+    assert st.step == 29 and st.q is not None and sum(q is not None for q in st.q) == 4
+    with pytest.raises(NotImplementedError, match="not found in list of available optimizers"):
+        YOLO(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml")).train(data=src, batch=4, imgsz=64, epochs=1, optimizer="LAMB")

@@ -188,3 +188,22 @@ def test_fresh_model_equals_a_fresh_reference_model(golden, name):
     a = np.array([float(v.double().abs().sum()) for v in sd.values()])
     np.testing.assert_allclose(s, G[f"{name}/sum"], rtol=1e-6, atol=1e-5)
     np.testing.assert_allclose(a, G[f"{name}/abssum"], rtol=1e-6, atol=1e-5)
+
+
+def test_soap_matches_the_reference_trainers_optimizer(golden):
+    """ultralytics.hip.soap.Soap against the reference trainer's SOAP class (engine/trainer.py:54-473) as build_optimizer
+    configures it: 25 steps of seeded gradients over a bias, two conv weights, a matrix and a norm weight -- parameters after
+    steps 1 (preconditioner seeded, nothing moves), 2, 11 (first QR refresh of the eigenbases) and 25."""
+    from golden.cases import rnd
+    from ultralytics.hip.soap import Soap
+    G = golden("soap")
+    shapes = [((16,), 0), ((16, 8, 3, 3), 1), ((8, 16, 1, 1), 1), ((24, 6), 1), ((8,), 2)]
+    ps = [rnd(50 + i, *sh, scale=0.5) for i, (sh, _) in enumerate(shapes)]
+    opt = Soap([(p, g) for p, (_, g) in zip(ps, shapes)], beta1=0.937, beta2=0.95)
+    for step in range(1, 26):
+        grads = [rnd(1000 + 31 * step + i, *p.shape, scale=1.0) * (1.0 + 0.1 * i) + 0.05 * p for i, p in enumerate(ps)]
+        opt.step(grads, [0.01] * 3, [0.0, 5e-4, 0.0])
+        if step in (1, 2, 11, 25):
+            for i, p in enumerate(ps):
+                ref = G.t(f"step{step}/p{i}")
+                assert float((p - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (step, i, float((p - ref).abs().max()))
