@@ -140,7 +140,8 @@ def test_soap_is_selectable_by_name_and_trains():
     taken, skipped, _ = plan.check_progress()
     assert (taken, skipped) == (30, 0) and all(torch.isfinite(h).all() for h in hist)
     assert float(sum(hist[-1])) < float(sum(hist[0]))
-    st = plan._soap.state[1]  # a conv weight: Gram matrices per dimension, eigenbases refreshed
+    st = plan._soap.state[0]  # model.0.conv.weight: a Gram matrix and an eigenbasis per dimension, refreshed twice by now
     assert st.step == 29 and st.q is not None and sum(q is not None for q in st.q) == 4
+    assert plan._soap.state[1].q == [None]  # its BatchNorm weight: 1-D tensors run plain Adam
     with pytest.raises(NotImplementedError, match="not found in list of available optimizers"):
         YOLO(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml")).train(data=src, batch=4, imgsz=64, epochs=1, optimizer="LAMB")
