@@ -4,6 +4,7 @@
 // nn/modules/conv.py:49-55; eps 1e-3 / momentum 0.03 from utils/torch_utils.py:347-349) and their autograd
 // backward.  Statistics arrive as per-workgroup partial sums written by the conv epilogue, so the raw conv
 // output is never re-read just to be averaged.  HBM-bound: every kernel moves 16 bytes per lane.
+#include <cstdlib>
 #include "common.h"
 #include "dealyolo_hip.h"
 
@@ -178,10 +179,16 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a) {
   if (pix < a.npix) one(pix, *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0));
 }
 
-static inline int ew_blocks(long npix, int C) {
+static inline int ew_blocks(long npix, int C, const char* env, long dflt) {
   const int rows = 256 / (C >> 3);
   long blocks = (npix + (long)rows * 4 - 1) / ((long)rows * 4);
-  if (blocks > 2048) blocks = 2048;  // 8 resident blocks per CU: each thread's coefficient prologue is amortised over >=25 pixels
+  // Block-count caps measured per kernel (tools/ew_bench.py, round 2; env DY_EW_BLOCKS_* overrides them): the forward apply (one
+  // read stream, one write stream) likes many short blocks (8192: 83-88 us against 92 at 2048 on the 105 M-element layers), the
+  // backward apply (two read streams + one write stream) few long ones (512: 120 us against 136 at 2048; 10.5 against 15.7 us on
+  // 6.5 M elements); the backward reduce is flat between 1024 and 2048.  Which pixels a block visits (interleaved over the grid
+  // or one contiguous span per block) made no measurable difference.
+  const long cap = getenv(env) ? atol(getenv(env)) : dflt;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -191,7 +198,7 @@ extern "C" int dy_bn_act_apply(const void* x, int ldx, const void* res, int ldr,
   if ((C & 7) || (ldx & 7) || (ldy & 7) || (res && (ldr & 7))) return DY_ERR_ALIGN;
   if ((C >> 3) > 256) return DY_ERR_ARG;
   ApplyArgs a{(const f16*)x, (const f16*)res, (f16*)y, coef, ldx, ldr, ldy, C, act, npix};
-  DY_ACT_DISPATCH(bn_act_apply_kernel, dim3(ew_blocks(npix, C)), stream, a);
+  DY_ACT_DISPATCH(bn_act_apply_kernel, dim3(ew_blocks(npix, C, "DY_EW_BLOCKS_APPLY", 8192)), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
@@ -211,14 +218,15 @@ template <int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
   const int cpp = a.C >> 3, rows = 256 / cpp, tid = threadIdx.x;
   const int part = tid % cpp, row = tid / cpp, c0 = part * 8;
-  float sg[8], sgx[8], sc[8], sh[8], mean[8], inv[8];
+  // The loop accumulates sum(g) and sum(g * x) on the RAW values; sum(g * xhat) = invstd * (sum(g * x) - mean * sum(g)) is formed
+  // once per thread afterwards.  (Keeping mean / invstd out of the loop takes 16 registers and two VALU operations per element off a
+  // kernel that sits at the VALU / memory balance point: exp + rcp per element.)
+  float sg[8], sgx[8], sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     sg[j] = sgx[j] = 0.f;
     sc[j] = a.coef[c0 + j];
     sh[j] = a.coef[a.C + c0 + j];
-    mean[j] = a.coef[2 * a.C + c0 + j];
-    inv[j] = a.coef[3 * a.C + c0 + j];
   }
   if (row < rows) {
     // two pixels per trip: four 16-byte loads in flight per lane before the first use
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
         const float g0 = (float)dv0[j] * act_grad_t<ACT>(x0 * sc[j] + sh[j]);
         const float g1 = (float)dv1[j] * act_grad_t<ACT>(x1 * sc[j] + sh[j]);
         sg[j] += g0 + g1;
-        sgx[j] += (g0 * (x0 - mean[j]) + g1 * (x1 - mean[j])) * inv[j];
+        sgx[j] += g0 * x0 + g1 * x1;
       }
     }
     if (pix < a.npix) {
@@ -246,9 +254,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
         const float xf = (float)xv[j];
         const float g = (float)dv[j] * act_grad_t<ACT>(xf * sc[j] + sh[j]);
         sg[j] += g;
-        sgx[j] += g * (xf - mean[j]) * inv[j];
+        sgx[j] += g * xf;
       }
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sgx[j] = (sgx[j] - a.coef[2 * a.C + c0 + j] * sg[j]) * a.coef[3 * a.C + c0 + j];
   }
   __shared__ float red[2][256][8 + 1];
 #pragma unroll
@@ -379,7 +389,7 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int lddy, const void* x, int 
   if ((C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7)) return DY_ERR_ALIGN;
   if ((C >> 3) > 256) return DY_ERR_ARG;
   BwdApplyArgs a{(const f16*)dy, (const f16*)x, (f16*)dx, coef, bwdcoef, lddy, ldx, lddx, C, act, frozen_stats, npix};
-  DY_ACT_DISPATCH(bn_act_bwd_apply_kernel, dim3(ew_blocks(npix, C)), stream, a);
+  DY_ACT_DISPATCH(bn_act_bwd_apply_kernel, dim3(ew_blocks(npix, C, "DY_EW_BLOCKS_BAPPLY", 512)), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

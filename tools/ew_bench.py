@@ -11,7 +11,7 @@ from ultralytics.hip.engine import Engine  # noqa: E402
 
 eng = Engine("cuda:0")
 L = eng.L
-shapes = [(1638400, 64), (6553600, 16), (1638400, 32), (409600, 64)]
+shapes = [(1638400, 64), (6553600, 16), (1638400, 32), (409600, 64), (409600, 32), (102400, 64), (102400, 128)]
 
 
 def timeit(fn, reps=20):
@@ -41,3 +41,10 @@ for npix, Cc in shapes:
     t_ba = timeit(lambda: L.dy_bn_act_bwd_apply(dy.data_ptr(), Cc, x.data_ptr(), Cc, y.data_ptr(), Cc, coef.data_ptr(), bw.data_ptr(), npix, Cc, 1, 0, s))
     e = npix * Cc
     print(f"npix={npix} C={Cc}: apply {t_ap*1e3:6.1f} us {4*e/t_ap/1e6:5.0f} GB/s | bwd_reduce {t_rd*1e3:6.1f} us {4*e/t_rd/1e6:5.0f} GB/s | bwd_apply {t_ba*1e3:6.1f} us {6*e/t_ba/1e6:5.0f} GB/s")
+
+# reference point: a plain device-to-device copy of the same element count (2 B read + 2 B write per element)
+for npix, Cc in shapes[:2]:
+    a = torch.randn(npix, Cc, device="cuda").half()
+    b = torch.empty_like(a)
+    t = timeit(lambda: b.copy_(a))
+    print(f"copy npix={npix} C={Cc}: {t*1e3:6.1f} us {4*npix*Cc/t/1e6:5.0f} GB/s")
