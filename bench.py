@@ -161,6 +161,7 @@ def main():
         dt = float(tt)
     ms = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
+    plan.check_progress()  # a step whose optimizer launches do not take effect (counter stuck, everything skipped) is not a number
 
     roof = None
     if rank == 0 and a.probe:
