@@ -158,6 +158,8 @@ class DetectionTrainer:
             for i, batch in enumerate(loader):
                 ni = i + nb * epoch
                 self.train_step(batch, ni, epoch)
+                if ni % 256 == 255:  # long epochs: do not wait for the epoch end to notice steps that do not take effect
+                    self.plan.check_progress()
                 if log_every and (i % log_every == 0):
                     _, items = self.plan.loss_items()
                     tloss = items if tloss is None else (tloss * i + items) / (i + 1)
