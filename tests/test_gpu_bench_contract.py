@@ -1,0 +1,36 @@
+"""-m gpu: the driver's contract with bench.py -- ONE JSON line with the agreed keys, a `roofline` object priced on algorithmic
+bytes with the step-level fraction beside it, a `cpu_baseline` object from the oracle, and a value that follows from the timing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_prints_one_contract_line():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "8", "--imgsz", "320"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "images/s" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "step", "top_conv", "ranking"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["ranking"][0]["kernel"] == r["kernel"] and r["top_conv"]["kernel"].startswith("conv_")
+    assert 0 < r["step"]["frac"] < 1 and r["step"]["algorithmic_bytes_per_image"] == 367.1e6
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "images/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert d["config"]["skipped_steps"] <= 6  # the dynamic loss scale settles within the warm-up + first steps
