@@ -12,7 +12,7 @@ Prints ONE JSON line on rank 0.  Extra objects:
                launch duration, measured live with HIP events on the launch stream, against 8 TB/s HBM; `traffic` = its PMC HBM
                bytes per launch from profiles/; `step` = the whole step priced the same way (images/s x 367 MB / 8 TB/s);
                `top_conv` = the most expensive convolution instantiation, for comparison with earlier rounds;
-  cpu_baseline the CPU oracle (a port of the reference's PyTorch CPU path) timed on the host cores, bs=2, bounded.
+  cpu_baseline the CPU oracle (a port of the reference's PyTorch CPU path) timed on the host cores, bs=16, about 15 s of CPU work.
 --loss ciou|wiou|ciou+nwd|wiou+nwd selects the box loss (reference default: ciou; BASELINE north_star names wiou+nwd).
 """
 import argparse
@@ -61,7 +61,7 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(imgsz, steps=6, warm=2, bs=2):
+def cpu_baseline(imgsz, steps=10, warm=2, bs=16):
     """CPU oracle (port of the reference PyTorch CPU trainer step: forward + loss + autograd backward + SGD + EMA)."""
     from oracle import graph as og, trainer as otr
     g = og.build_graph(og.load_yaml(CFG))

@@ -142,6 +142,7 @@ struct ApplyArgs {
   const float* coef;
   int ldx, ldr, ldy, C, act;
   long npix;
+  int rev;  // walk the pixels from the far end (DY_EW_REVERSE bit 0)
 };
 
 template <int ACT>
@@ -156,7 +157,9 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a) {
     sc[j] = a.coef[c0 + j];
     sh[j] = a.coef[a.C + c0 + j];
   }
+  auto at = [&](long p) { return a.rev ? a.npix - 1 - p : p; };
   auto one = [&](long pix, const half8& xv) {
+    pix = at(pix);
     half8 rv;
     if (a.res) rv = *reinterpret_cast<const half8*>(a.res + pix * a.ldr + c0);
     half8 out;
@@ -171,12 +174,21 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a) {
   const long step = (long)gridDim.x * rows;
   long pix = (long)blockIdx.x * rows + row;
   for (; pix + step < a.npix; pix += 2 * step) {  // two pixels per trip: both loads issue before the first use
-    const half8 x0 = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
-    const half8 x1 = *reinterpret_cast<const half8*>(a.x + (pix + step) * a.ldx + c0);
+    const half8 x0 = *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0);
+    const half8 x1 = *reinterpret_cast<const half8*>(a.x + at(pix + step) * a.ldx + c0);
     one(pix, x0);
     one(pix + step, x1);
   }
-  if (pix < a.npix) one(pix, *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0));
+  if (pix < a.npix) one(pix, *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0));
+}
+
+// Which passes walk their pixels from the far end (bit 0 forward apply, bit 1 backward apply, bit 2 backward reduce).  The backward
+// apply re-reads dY and x right after the reduce pass streamed them front to back; starting at the end, where the most recently
+// fetched lines still sit in L2 / Infinity Cache, measured 14.17 -> 14.11 ms per step (three alternating runs on one box); the other
+// two bits measured nothing.  Element-wise, so the results do not depend on the order.
+static inline int ew_reverse() {
+  static const int rev = getenv("DY_EW_REVERSE") ? atoi(getenv("DY_EW_REVERSE")) : 2;
+  return rev;
 }
 
 static inline int ew_blocks(long npix, int C, const char* env, long dflt) {
@@ -197,7 +209,8 @@ extern "C" int dy_bn_act_apply(const void* x, int ldx, const void* res, int ldr,
                                long npix, int C, int act, hipStream_t stream) {
   if ((C & 7) || (ldx & 7) || (ldy & 7) || (res && (ldr & 7))) return DY_ERR_ALIGN;
   if ((C >> 3) > 256) return DY_ERR_ARG;
-  ApplyArgs a{(const f16*)x, (const f16*)res, (f16*)y, coef, ldx, ldr, ldy, C, act, npix};
+  const int rev = ew_reverse();
+  ApplyArgs a{(const f16*)x, (const f16*)res, (f16*)y, coef, ldx, ldr, ldy, C, act, npix, rev & 1};
   DY_ACT_DISPATCH(bn_act_apply_kernel, dim3(ew_blocks(npix, C, "DY_EW_BLOCKS_APPLY", 8192)), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
@@ -212,6 +225,7 @@ struct BwdRedArgs {
   float* partials;  // [gridDim.x][2][C]
   int lddy, ldx, C, act;
   long npix;
+  int rev;  // DY_EW_REVERSE bit 2
 };
 
 template <int ACT>
@@ -232,11 +246,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
     // two pixels per trip: four 16-byte loads in flight per lane before the first use
     const long step = (long)gridDim.x * rows;
     long pix = (long)blockIdx.x * rows + row;
+    auto at = [&](long p) { return a.rev ? a.npix - 1 - p : p; };
     for (; pix + step < a.npix; pix += 2 * step) {
-      const half8 dv0 = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0);
-      const half8 xv0 = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
-      const half8 dv1 = *reinterpret_cast<const half8*>(a.dy + (pix + step) * a.lddy + c0);
-      const half8 xv1 = *reinterpret_cast<const half8*>(a.x + (pix + step) * a.ldx + c0);
+      const half8 dv0 = *reinterpret_cast<const half8*>(a.dy + at(pix) * a.lddy + c0);
+      const half8 xv0 = *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0);
+      const half8 dv1 = *reinterpret_cast<const half8*>(a.dy + at(pix + step) * a.lddy + c0);
+      const half8 xv1 = *reinterpret_cast<const half8*>(a.x + at(pix + step) * a.ldx + c0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float x0 = (float)xv0[j], x1 = (float)xv1[j];
@@ -247,8 +262,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
       }
     }
     if (pix < a.npix) {
-      const half8 dv = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0);
-      const half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
+      const half8 dv = *reinterpret_cast<const half8*>(a.dy + at(pix) * a.lddy + c0);
+      const half8 xv = *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xf = (float)xv[j];
@@ -287,7 +302,8 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int lddy, const void* x, int
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   if (nparts) *nparts = (int)blocks;
-  BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, partials, lddy, ldx, C, act, npix};
+  const int rev = ew_reverse();
+  BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, partials, lddy, ldx, C, act, npix, (rev >> 2) & 1};
   DY_ACT_DISPATCH(bn_act_bwd_reduce_kernel, dim3((int)blocks), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
@@ -340,6 +356,7 @@ struct BwdApplyArgs {
   const float* bwdcoef;
   int lddy, ldx, lddx, C, act, frozen_stats;
   long npix;
+  int rev;  // DY_EW_REVERSE bit 1
 };
 
 template <int ACT>
@@ -359,7 +376,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BwdApplyArgs a) {
     kb[j] = sc[j] * inv * mgx;
     kc[j] = sc[j] * mg - kb[j] * mean;
   }
+  auto at = [&](long p) { return a.rev ? a.npix - 1 - p : p; };
   auto one = [&](long pix, const half8& dv, const half8& xv) {
+    pix = at(pix);
     half8 out;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -372,15 +391,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BwdApplyArgs a) {
   const long step = (long)gridDim.x * rows;
   long pix = (long)blockIdx.x * rows + row;
   for (; pix + step < a.npix; pix += 2 * step) {
-    const half8 d0 = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0);
-    const half8 x0 = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0);
-    const half8 d1 = *reinterpret_cast<const half8*>(a.dy + (pix + step) * a.lddy + c0);
-    const half8 x1 = *reinterpret_cast<const half8*>(a.x + (pix + step) * a.ldx + c0);
+    const half8 d0 = *reinterpret_cast<const half8*>(a.dy + at(pix) * a.lddy + c0);
+    const half8 x0 = *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0);
+    const half8 d1 = *reinterpret_cast<const half8*>(a.dy + at(pix + step) * a.lddy + c0);
+    const half8 x1 = *reinterpret_cast<const half8*>(a.x + at(pix + step) * a.ldx + c0);
     one(pix, d0, x0);
     one(pix + step, d1, x1);
   }
   if (pix < a.npix)
-    one(pix, *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + c0), *reinterpret_cast<const half8*>(a.x + pix * a.ldx + c0));
+    one(pix, *reinterpret_cast<const half8*>(a.dy + at(pix) * a.lddy + c0), *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0));
 }
 
 extern "C" int dy_bn_act_bwd_apply(const void* dy, int lddy, const void* x, int ldx, void* dx, int lddx,
@@ -388,7 +407,8 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int lddy, const void* x, int 
                                    hipStream_t stream) {
   if ((C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7)) return DY_ERR_ALIGN;
   if ((C >> 3) > 256) return DY_ERR_ARG;
-  BwdApplyArgs a{(const f16*)dy, (const f16*)x, (f16*)dx, coef, bwdcoef, lddy, ldx, lddx, C, act, frozen_stats, npix};
+  const int rev = ew_reverse();
+  BwdApplyArgs a{(const f16*)dy, (const f16*)x, (f16*)dx, coef, bwdcoef, lddy, ldx, lddx, C, act, frozen_stats, npix, (rev >> 1) & 1};
   DY_ACT_DISPATCH(bn_act_bwd_apply_kernel, dim3(ew_blocks(npix, C, "DY_EW_BLOCKS_BAPPLY", 512)), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
