@@ -26,6 +26,7 @@ for p in (ROOT, os.path.join(ROOT, "experiment-yolo_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import ultralytics.hip  # noqa: E402,F401  (first: sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before anything initialises HIP)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import math
 import os
+import random
 import time
 
 import numpy as np
@@ -80,6 +81,8 @@ class DetectionTrainer:
                              init_scale=float(a.loss_scale) if a.amp else 1.0, dynamic_scale=bool(a.amp))
         self.plan = StepPlan(self.model, batch_size, imgsz, **self._plan_kw)
         self.plans = {batch_size: self.plan}  # forward/backward launch lists by batch size (the ragged last batch gets its own)
+        self.arena = None  # multi_scale: one block of HBM under the step-local buffers of every size's launch list (_scaled_plan)
+        self.gs = max(int(self.model.stride.max()), 32)  # reference engine/trainer.py:677: grid size, never below 32
         bl = self.plan.crit.bbox_loss
         bl.use_wiseiou, bl.nwd_loss, bl.iou_ratio = bool(a.wiou), bool(a.nwd), float(a.iou_ratio)
         self.ema = ModelEMA(self.plan)
@@ -104,7 +107,10 @@ class DetectionTrainer:
             if self.opt_name in ("SGD", "RMSProp"):  # reference :791 ``if "momentum" in x``: only these param groups have the key;
                 mom = float(np.interp(ni, xi, [a.warmup_momentum, self.momentum]))  # Adam-family / SOAP betas are never warmed up
         p.set_hyper(lr, mom, [0.0, self.wd, 0.0])
-        self._plan_for(batch).forward_backward(batch)  # writes the shared flat gradient buffer; everything below is the main plan's
+        if a.multi_scale:
+            self._forward_backward_rescaled(batch)
+        else:
+            self._plan_for(batch).forward_backward(batch)  # writes the shared flat gradient buffer; everything below is the main plan's
         if self.accumulate > 1 or acc > 1 or p._micro:
             p.accumulate()
         if ni - self.last_opt_step >= acc:
@@ -124,6 +130,58 @@ class DetectionTrainer:
             fb = self.plans[B] = StepPlan(self.model, B, self.plan.imgsz, share=self.plan, **self._plan_kw)
         return fb
 
+    # ---- multi_scale (reference models/yolo/detect/train.py:60-73) ---------------------------------------------------------------
+    def _forward_backward_rescaled(self, batch):
+        """``preprocess_batch`` with ``multi_scale=True``: every batch is bilinearly re-interpolated to a random multiple of the grid
+        size in [0.5, 1.5] x imgsz before the step.  A recorded launch list has one input size, so each size gets its own list
+        (``input_act`` plans fed through ``x_in``); they all lay their step-local buffers over ONE arena sized for the largest size --
+        the footprint of a multi-scale run is that of its largest step, not the sum over sizes -- and share the optimizer state."""
+        a, gs = self.args, self.gs
+        sz = random.randrange(int(a.imgsz * 0.5), int(a.imgsz * 1.5 + gs)) // gs * gs
+        base = self._plan_for(batch)  # the plan of this batch size at the base size: stages the loader's batch (pixels, flips, HSV, pool)
+        H, W = base.imgsz
+        sf = sz / max(H, W)
+        if sf == 1:
+            return base.forward_backward(batch)
+        ns = tuple(math.ceil(x * sf / gs) * gs for x in (H, W))
+        base.stage(batch)
+        x = base.import_input()  # eager launch: fp16 NHWC, 8 channels (3 used)
+        plan = self._scaled_plan(base, ns)
+        img = torch.nn.functional.interpolate(x.st.buf[..., :3].permute(0, 3, 1, 2).float(), size=ns, mode="bilinear", align_corners=False)
+        plan.x_in[..., :3].copy_(img.permute(0, 2, 3, 1))
+        return plan.forward_backward(batch)
+
+    def _scaled_plan(self, base, ns):
+        from ..hip.engine import Arena
+        key = (base.B, *ns)
+        plan = self.plans.get(key)
+        if plan is not None:
+            return plan
+        kw = dict(self._plan_kw, share=self.plan, input_act=True)
+        if self.arena is None:  # sized once, on the largest size this run can draw, with the main batch size
+            a, gs = self.args, self.gs
+            top = (int(a.imgsz * 1.5 + gs) - 1) // gs * gs
+            big = tuple(math.ceil(x * (top / max(self.plan.imgsz)) / gs) * gs for x in self.plan.imgsz)
+            probe_arena = Arena(0, self.device, measure=True)
+            eng, kept = self.plan.eng, len(self.plan.eng.keep)
+            probe = StepPlan(self.model, self.plan.B, big, arena=probe_arena, **dict(kw, use_graph=False))
+            saved = self.plan.rt.flat_b.clone(), self.plan.crit.scalars.clone()  # the probe step must leave no trace: BatchNorm
+            n0 = self.plan.B  # running statistics and the loss scalars (WIoU running mean) back; gradients are rewritten by the next step
+            dummy = dict(batch_idx=torch.arange(n0, dtype=torch.float32), cls=torch.zeros((n0, 1)), bboxes=torch.full((n0, 4), 0.5))
+            probe.forward_backward(dummy)
+            torch.cuda.synchronize()
+            self.plan.rt.flat_b.copy_(saved[0])
+            self.plan.crit.scalars.copy_(saved[1])
+            need = probe_arena.peak
+            del probe, probe_arena, eng.keep[kept:]  # the engine keeps recorded buffers alive: the probe's list is gone, so are they
+            torch.cuda.empty_cache()
+            self.arena = Arena(need + (64 << 20), self.device)
+            LOGGER.info(f"multi_scale: {self.arena.cap / 2**30:.2f} GiB arena shared by every input size (largest {big[0]}x{big[1]})")
+        plan = self.plans[key] = StepPlan(self.model, base.B, ns, arena=self.arena if self.share_arena else None, **kw)
+        return plan
+
+    share_arena = True  # False: every size keeps its own step-local buffers (what the arena is tested against)
+
     def train(self, loader=None, batch_size=None, imgsz=None, epochs=None, log_every=0):
         """loader: re-iterable of batch dicts (``batch_size`` = its per-rank batch).  Without arguments -- the reference's call shape
         -- trains on ``args.data`` with ``args.batch`` / ``args.imgsz``.  Returns the list of per-epoch mean loss items."""
@@ -134,9 +192,6 @@ class DetectionTrainer:
             return self.train_on_dataset(a.data, a.batch, a.imgsz, log_every=log_every)
         if epochs is not None:
             a.epochs = epochs
-        if a.multi_scale:
-            raise NotImplementedError("multi_scale=True: the recorded launch list has one input size (reference detect/train.py:61-73 "
-                                      "re-interpolates every batch); train at a fixed imgsz")
         nb = len(loader)
         if not getattr(a, "nmax", None):  # per-image label capacity from the first batch, with head-room; exceeded later -> raises
             from ..utils.loss import v8DetectionLoss

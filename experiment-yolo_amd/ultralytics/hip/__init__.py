@@ -7,6 +7,29 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
+
+# hipGraph safety on this ROCm (7.2): with the runtime's "graph packet capture" (AQL packets and kernel arguments pre-built when a
+# graph is instantiated) a burst of ordinary launches between two replays -- ~1,000 of this library's kernels: six eval-mode
+# forwards, or the traces of two other launch lists -- overwrites the captured arguments of an ALREADY INSTANTIATED graph: its
+# next replays compute with garbage (non-finite gradients) while the same launch list issued eagerly is fine (DESIGN.md
+# section 14, profiles/r02_graph_packet_capture.txt).  DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 turns the pre-building off (no measured
+# cost: 14.21 vs 14.23 ms per step) and the corruption does not occur.  The flag is read when HIP initialises, so it is set here,
+# at import; a process that initialised the GPU earlier without it gets no graphs (GRAPH_SAFE, checked by StepPlan).
+_FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+
+
+def _hip_already_up():
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+if os.environ.get(_FLAG) is None and not _hip_already_up():
+    os.environ[_FLAG] = "0"  # inherited by child processes (torch.distributed.run ranks)
+GRAPH_SAFE = os.environ.get(_FLAG) == "0"  # unset + HIP already initialised, or set to something else by the user: no graphs
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DY_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libdealyolo_hip.so"))

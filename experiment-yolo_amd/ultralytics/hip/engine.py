@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import numpy as np
 import torch
 
 from . import (DY_ACT_LEAKY, DY_ACT_NONE, DY_ACT_SILU, DY_EPI_ACCUM, DY_EPI_BIAS, DY_EPI_F32OUT, DY_EPI_SILU,
@@ -41,18 +42,59 @@ def dev_empty(shape, dtype, device):
     return t
 
 
+class Arena:
+    """One block of HBM that several recorded launch lists lay their step-local buffers over (activations, gradient twins,
+    fp32 head logits, weight-gradient slabs, pool arg-max maps): every such buffer is written inside a step before it is read,
+    and only one list runs at a time on the stream, so plans for different input sizes (``multi_scale`` training,
+    engine/trainer.py) can share the footprint of the largest one instead of each holding its own.  Bump allocation, reset at the
+    start of a trace; ``measure=True`` hands out ordinary allocations and only counts (used once, on the largest size)."""
+
+    ALIGN = 256
+
+    def __init__(self, nbytes, device, measure=False):
+        self.device, self.measure = torch.device(device), measure
+        self.buf = None if measure else dev_empty(int(nbytes), torch.uint8, self.device)
+        self.cap, self.off, self.peak = int(nbytes), 0, 0
+
+    def reset(self):
+        self.off = 0
+        if POISON and self.buf is not None:
+            self.buf.fill_(0xFF)
+
+    def take(self, shape, dtype):
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        start = (self.off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.off = start + n
+        self.peak = max(self.peak, self.off)
+        if self.measure:
+            return dev_empty(shape, dtype, self.device)
+        if self.off > self.cap:
+            raise MemoryError(f"step-local buffers need more than the shared arena's {self.cap / 2**30:.2f} GiB "
+                              f"(request of {n / 2**20:.1f} MiB at offset {start / 2**30:.2f} GiB): the arena is sized on the largest input size")
+        return self.buf[start:start + n].view(dtype).view(shape)
+
+
 class Storage:
     """(N,H,W,C) fp16 buffer with an optional gradient twin and a record of which channel ranges of the twin hold data."""
 
     def __init__(self, eng, N, H, W, C, dtype=torch.float16):
         assert C % 8 == 0, f"channel count {C} must be a multiple of 8"
         self.eng, self.N, self.H, self.W, self.C = eng, N, H, W, C
-        self.buf = dev_empty((N, H, W, C), dtype, eng.device)
+        self.buf = eng.transient((N, H, W, C), dtype)
         self.gbuf = None
         self.gwritten = []  # list of (c0, c1) already holding gradient
 
     def act(self, c0=0, C=None):
         return Act(self, c0, self.C - c0 if C is None else C)
+
+    @classmethod
+    def over(cls, eng, t):
+        """Storage over an existing contiguous (N,H,W,C) tensor (a plan's static input)."""
+        assert t.dim() == 4 and t.is_contiguous() and t.shape[3] % 8 == 0
+        st = object.__new__(cls)
+        st.eng, (st.N, st.H, st.W, st.C) = eng, t.shape
+        st.buf, st.gbuf, st.gwritten = t, None, []
+        return st
 
 
 class Act:
@@ -80,7 +122,7 @@ class Act:
     def _gbuf(self):
         st = self.st
         if st.gbuf is None:
-            st.gbuf = dev_empty(st.buf.shape, st.buf.dtype, st.buf.device)
+            st.gbuf = st.eng.transient(tuple(st.buf.shape), st.buf.dtype)
             st.eng.hold(st.gbuf)
         return st.gbuf
 
@@ -242,6 +284,14 @@ class Engine:
             t.fill_(0xFF)
         return t
 
+    arena = None  # set by StepPlan around a trace whose step-local buffers go to a shared Arena
+
+    def transient(self, shape, dtype):
+        """A buffer that is written inside every step before it is read (never carries state from one step to the next)."""
+        if self.arena is not None:
+            return self.arena.take(tuple(shape), dtype)
+        return dev_empty(tuple(shape), dtype, self.device)
+
     def new_storage(self, N, H, W, C, dtype=torch.float16):
         st = Storage(self, N, H, W, C, dtype)
         self.hold(st.buf)
@@ -249,6 +299,11 @@ class Engine:
 
     def new_act(self, N, H, W, C):
         return self.new_storage(N, H, W, C).act()
+
+    def wrap_act(self, t):
+        a = Storage.over(self, t).act()
+        a.needs_grad = False
+        return a
 
     def f32(self, n, fill=None):
         t = dev_empty(n, torch.float32, self.device) if fill is None else torch.full(
@@ -398,7 +453,7 @@ class Engine:
         if self.side_wgrad and self.deferred_wgrad is not None:
             # the weight gradient reads this buffer on the side stream while the main stream moves on to the next layer:
             # it cannot be the shared scratch
-            draw = dev_empty(npix * spec.cout, torch.float16, self.device)
+            draw = self.transient((npix * spec.cout,), torch.float16)
             self.hold(draw)
         else:
             draw = self.scratch("draw", npix * spec.cout * 2)
@@ -415,7 +470,7 @@ class Engine:
         self.L.dy_wgrad_workspace(x.N, x.H, x.W, spec.cin, spec.cout, spec.ks, spec.stride, C.byref(ns), C.byref(se))
         deferred = defer and not accumulate_w and self.deferred_wgrad is not None
         if deferred:
-            slabs = dev_empty(ns.value * se.value, torch.float32, self.device)
+            slabs = self.transient((ns.value * se.value,), torch.float32)
             self.hold(slabs)
             self.deferred_wgrad.append((spec, slabs, ns.value))
             dw = 0
@@ -504,7 +559,7 @@ class Engine:
         return y
 
     def maxpool5(self, x: Act, out: Act):
-        arg = dev_empty(x.npix * x.C, torch.uint8, self.device)
+        arg = self.transient((x.npix * x.C,), torch.uint8)
         self.hold(arg)
         self.call("dy_maxpool5", x.ptr, x.ld, out.ptr, out.ld, arg.data_ptr(), x.N, x.H, x.W, x.C)
         if self.tape is not None:
@@ -654,7 +709,7 @@ class Engine:
     # ---- LDConv (reference nn/modules/conv.py:366-410) -----------------------------------------------------------
     def ldconv(self, sp_p: ConvSpec, sp_c: ConvSpec, pn_i32, Np, stride, x: Act, out: Act | None = None):
         h, w = self.out_hw(sp_p, x)
-        off = dev_empty((x.N, h, w, 2 * Np), torch.float32, self.device)
+        off = self.transient((x.N, h, w, 2 * Np), torch.float32)
         self.hold(off)
         doff = None
         if self.tape is not None:

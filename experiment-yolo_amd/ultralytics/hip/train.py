@@ -22,11 +22,15 @@ from .engine import Recorder
 
 class StepPlan:
     def __init__(self, model, batch_size, imgsz, nmax=16, optimizer="SGD", hyp=None, world_size=1, use_graph=False,
-                 init_scale=65536.0, side_wgrad=None, dynamic_scale=True, share=None):
+                 init_scale=65536.0, side_wgrad=None, dynamic_scale=True, share=None, arena=None, input_act=False):
         """``share``: another StepPlan on the SAME model whose optimizer state this one uses (momentum / Adam moments, EMA, loss
         scale and step counters, hyper-parameters): a plan records ONE batch size, so the ragged last batch of an epoch gets its
-        own forward/backward launch list while accumulate / all_reduce / optimizer_step stay with the main plan."""
+        own forward/backward launch list while accumulate / all_reduce / optimizer_step stay with the main plan.
+        ``arena``: an ``engine.Arena`` this plan lays its step-local buffers over (shared by the plans of a multi-scale run).
+        ``input_act``: the recorded list starts at the stem's fp16 NHWC input ``self.x_in`` (B, H, W, 8; channels 3..7 stay zero),
+        filled by the caller before every ``forward_backward`` -- the multi-scale trainer writes the re-interpolated batch there."""
         self.model = model
+        self.arena = arena
         # weight gradients on a second stream beside the input-gradient chain (env DY_SIDE_WGRAD=0/1 overrides the default)
         self.side_wgrad = bool(int(os.environ.get("DY_SIDE_WGRAD", "0"))) if side_wgrad is None else bool(side_wgrad)
         dev = next(model.parameters()).device
@@ -34,6 +38,13 @@ class StepPlan:
         self.eng = self.rt.eng
         self.B, self.imgsz, self.nmax = batch_size, (imgsz, imgsz) if isinstance(imgsz, int) else tuple(imgsz), nmax
         self.world_size = world_size
+        if use_graph:
+            from . import GRAPH_SAFE
+            if not GRAPH_SAFE and not os.environ.get("DY_ALLOW_UNSAFE_GRAPHS"):
+                raise RuntimeError("hipGraph replay is not safe in this process: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in the "
+                                   "environment when HIP initialised (this ROCm overwrites the kernel arguments of instantiated graphs, "
+                                   "ultralytics/hip/__init__.py).  Export it, or import ultralytics before the first torch.cuda call; "
+                                   "hipgraph=False / use_graph=False runs the same launch lists eagerly.")
         self.use_graph = use_graph
         self.soap = optimizer == "SOAP"  # host-driven (hip/soap.py); the flat kernel then only keeps EMA / loss scale / counters
         self.mode = {"SGD": 0, "Adam": 1, "AdamW": 2, "RMSProp": 3, "RAdam": 4, "Adamax": 5, "NAdam": 6, "SOAP": 0}[optimizer]
@@ -59,7 +70,10 @@ class StepPlan:
             self.state = torch.zeros(8, dtype=torch.float32, device=dev)
             self.state[0] = init_scale
             self.partials = torch.zeros(4096, dtype=torch.float32, device=dev)
-        self.img = torch.zeros((batch_size, 3, *self.imgsz), dtype=torch.float32, device=dev)
+        self.input_act = bool(input_act)
+        self._fmt_fixed = False  # stage(): the first batch decides the input format
+        self.x_in = torch.zeros((batch_size, *self.imgsz, 8), dtype=torch.float16, device=dev) if input_act else None
+        self.img = None if input_act else torch.zeros((batch_size, 3, *self.imgsz), dtype=torch.float32, device=dev)
         self.input_u8 = False  # decided by the first batch: uint8 NHWC (the loader's format) or float NCHW (the public tensor API)
         self.flip = None       # (B,) uint8 flip bits when the first loader batch carries them (flips folded into the import kernel)
         self.pool = self.index = None  # HBM-resident image pool + (B,) int32 slots when the loader keeps the dataset on the device
@@ -93,14 +107,12 @@ class StepPlan:
         eng.rec = Recorder()
         eng.tape = []
         eng.training = True
+        eng.arena = self.arena
+        if self.arena is not None:
+            self.arena.reset()
         try:
             rt.pack_all(transposed=True)
-            if self.warp is not None:
-                x = eng.import_warp(self.pool, self.warp, 8)
-            elif self.pool is not None:
-                x = eng.import_image_u8(self.pool, 8, self.flip, self.index, self.hsv)
-            else:
-                x = eng.import_image_u8(self.img, 8, self.flip, None, self.hsv) if self.input_u8 else eng.import_image(self.img, 8)
+            x = self.import_input()
             ho = model.forward_act(x)
             crit.bind(ho, self.nmax, gscale=self.state[0:1])
             crit.__dict__["_last"] = crit
@@ -114,15 +126,41 @@ class StepPlan:
         finally:
             eng.deferred_wgrad = None
             eng.side_wgrad = False
+            eng.arena = None
             rec, eng.rec, eng.tape = eng.rec, None, None
         self.ho = ho
         return rec
 
     def forward_backward(self, batch):
         """Stage the batch, run fwd+loss+bwd; gradients (scaled by the loss scale) land in rt.flat_g."""
+        if not self.input_act:
+            self.stage(batch)
+        n = self.crit.set_targets(batch, cap=self.B * self.nmax)
+        if n > self.B * self.nmax:
+            raise RuntimeError(f"{n} targets exceed the plan capacity {self.B}x{self.nmax}")
+        self.crit.sync_modes()
+        if self.rec_fb is None:
+            pre = (self.rt.flat_b.clone(), self.crit.scalars.clone()) if self.use_graph else None
+            self.rec_fb = self._trace_fb(batch)
+            if self.use_graph:
+                torch.cuda.synchronize()
+                self.graph_fb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
+                    self.eng.replay(self.rec_fb)
+                self._verify_capture(*pre)
+        elif self.graph_fb is not None:
+            self.graph_fb.replay()
+        else:
+            self.eng.replay(self.rec_fb)
+        return self.crit.scalars
+
+    def stage(self, batch):
+        """Bring the batch's images into the static buffers the import kernel of this plan reads (``img`` / pool records, flip
+        bits, HSV gains); the first call fixes the input format."""
         img = batch["img"]
+        first = not self._fmt_fixed
         u8 = img.dtype == torch.uint8 and img.dim() == 4 and img.shape[-1] == 3 and img.shape[1] != 3  # (B,H,W,3)
-        if self.rec_fb is None and u8 and ("index" in batch or "warp" in batch):  # img is the loader's HBM pool: recorded by pointer
+        if first and u8 and ("index" in batch or "warp" in batch):  # img is the loader's HBM pool: recorded by pointer
             self.pool, self.input_u8 = img, True
             if "warp" in batch:
                 self.warp = torch.zeros((self.B, batch["warp"].shape[1]), dtype=torch.int32, device=img.device)
@@ -134,12 +172,12 @@ class StepPlan:
                 raise KeyError(f"this plan was recorded for batches carrying '{key}' records over one HBM-resident image pool")
             (self.warp if self.warp is not None else self.index).copy_(batch[key], non_blocking=True)
             img = self.img  # nothing to stage
-        if self.rec_fb is None and u8 and self.pool is None:
+        if first and u8 and self.pool is None:
             self.input_u8 = True
             self.img = torch.zeros((self.B, *self.imgsz, 3), dtype=torch.uint8, device=self.img.device)
-        if self.rec_fb is None and u8 and "flip" in batch:
+        if first and u8 and "flip" in batch:
             self.flip = torch.zeros(self.B, dtype=torch.uint8, device=self.img.device)
-        if self.rec_fb is None and u8 and "hsv" in batch and "warp" not in batch:
+        if first and u8 and "hsv" in batch and "warp" not in batch:
             self.hsv = torch.ones((self.B, 3), dtype=torch.float32, device=self.img.device)
         if self.hsv is not None:
             self.hsv.copy_(batch["hsv"], non_blocking=True)
@@ -160,50 +198,57 @@ class StepPlan:
             if tuple(img.shape) != tuple(self.img.shape):
                 raise ValueError(f"batch images {tuple(img.shape)} do not match the plan's {tuple(self.img.shape)}")
             self.img.copy_(img, non_blocking=True)
-        n = self.crit.set_targets(batch, cap=self.B * self.nmax)
-        if n > self.B * self.nmax:
-            raise RuntimeError(f"{n} targets exceed the plan capacity {self.B}x{self.nmax}")
-        self.crit.sync_modes()
-        if self.rec_fb is None:
-            pre = (self.rt.flat_b.clone(), self.crit.scalars.clone()) if self.use_graph else None
-            self.rec_fb = self._trace_fb(batch)
-            if self.use_graph:
-                torch.cuda.synchronize()
-                self.graph_fb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
-                    self.eng.replay(self.rec_fb)
-                self._verify_capture(*pre)
-        elif self.graph_fb is not None:
-            self.graph_fb.replay()
-        else:
-            self.eng.replay(self.rec_fb)
-        return self.crit.scalars
+        self._fmt_fixed = True
+
+    def import_input(self):
+        """The stem input (fp16 NHWC, 8 channels) of the staged batch: the first launch of the recorded list, or -- called
+        eagerly by the multi-scale trainer on the base-size plan -- the image batch to re-interpolate."""
+        eng = self.eng
+        if self.input_act:
+            return eng.wrap_act(self.x_in)
+        if self.warp is not None:
+            return eng.import_warp(self.pool, self.warp, 8)
+        if self.pool is not None:
+            return eng.import_image_u8(self.pool, 8, self.flip, self.index, self.hsv)
+        return eng.import_image_u8(self.img, 8, self.flip, None, self.hsv) if self.input_u8 else eng.import_image(self.img, 8)
 
     def _verify_capture(self, buffers_before, scalars_before):
-        """Replay the freshly captured forward/backward graph once on the traced batch -- from the state the traced step started
-        from (BN running statistics, WIoU running mean), so nothing is applied twice -- and require it to reproduce the traced
-        step.  A capture can come out broken without any error: on this ROCm, device work issued by ANOTHER host thread while a
-        thread-local capture is open produced graphs whose every replay returned non-finite gradients."""
+        """Replay the freshly captured forward/backward graph on the traced batch -- from the state the traced step started from
+        (BN running statistics, WIoU running mean), so nothing is applied twice -- and require it to reproduce the traced step;
+        then once more after a burst of ordinary launches.  A graph can be broken without any error on this ROCm, two ways
+        (DESIGN.md section 14): device work issued by ANOTHER host thread while a thread-local capture is open, and -- with the
+        runtime's graph packet capture on, which hip/__init__.py turns off at import -- ~1,000 ordinary launches of this library
+        between two replays overwriting the arguments of the instantiated graph.  Two eager passes over the recorded list are such
+        a burst: if the flag did not take effect (HIP initialised before the import) the second replay fails HERE, not in epoch 2."""
         want_s, want_g, want_b = self.crit.scalars.clone(), self.rt.flat_g.clone(), self.rt.flat_b.clone()
-        self.rt.flat_b.copy_(buffers_before)
-        self.crit.scalars.copy_(scalars_before)
-        self.graph_fb.replay()
-        torch.cuda.synchronize()
-        got_s, got_g = self.crit.scalars, self.rt.flat_g
-        ds = float((got_s[5:9] - want_s[5:9]).abs().max() / want_s[5:9].abs().max().clamp_min(1e-12))
-        # LDConv's far-sample side pass adds with fp32 atomics: gradients repeat to rounding order only (1e-3); all else is exact.
-        # A traced step that overflowed fp16 (the dynamic loss scale still searching) must overflow again: then only the forward
-        # quantities are compared.
-        if bool(torch.isfinite(want_g).all()):
-            dg = float((got_g - want_g).norm() / want_g.norm().clamp_min(1e-30)) if bool(torch.isfinite(got_g).all()) else float("inf")
-        else:
-            dg = 0.0 if not bool(torch.isfinite(got_g).all()) else float("inf")
-        db = float((self.rt.flat_b - want_b).abs().max() / want_b.abs().max().clamp_min(1e-12))
-        if not (ds <= 1e-5 and dg <= 2e-2 and db <= 1e-5):
-            self.graph_fb = self.rec_fb = None
-            raise RuntimeError("the captured step graph does not reproduce the traced step (loss items off by "
-                               f"{ds:.2e}, gradients by {dg:.2e}, BN statistics by {db:.2e} relative): was another host thread issuing "
-                               "device work during the capture?")
+
+        def replay_and_compare(what):
+            self.rt.flat_b.copy_(buffers_before)
+            self.crit.scalars.copy_(scalars_before)
+            self.graph_fb.replay()
+            torch.cuda.synchronize()
+            got_s, got_g = self.crit.scalars, self.rt.flat_g
+            ds = float((got_s[5:9] - want_s[5:9]).abs().max() / want_s[5:9].abs().max().clamp_min(1e-12))
+            # LDConv's far-sample side pass adds with fp32 atomics: gradients repeat to rounding order only (1e-3); all else is
+            # exact.  A traced step that overflowed fp16 (the dynamic loss scale still searching) must overflow again: then only
+            # the forward quantities are compared.
+            if bool(torch.isfinite(want_g).all()):
+                dg = float((got_g - want_g).norm() / want_g.norm().clamp_min(1e-30)) if bool(torch.isfinite(got_g).all()) else float("inf")
+            else:
+                dg = 0.0 if not bool(torch.isfinite(got_g).all()) else float("inf")
+            db = float((self.rt.flat_b - want_b).abs().max() / want_b.abs().max().clamp_min(1e-12))
+            if not (ds <= 1e-5 and dg <= 2e-2 and db <= 1e-5):
+                self.graph_fb = self.rec_fb = None
+                raise RuntimeError(f"the captured step graph does not reproduce the traced step {what} (loss items off by {ds:.2e}, "
+                                   f"gradients by {dg:.2e}, BN statistics by {db:.2e} relative): was another host thread issuing device "
+                                   "work during the capture, or was HIP initialised before `import ultralytics` could set "
+                                   "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (export it, or import the package before the first torch.cuda call)?")
+
+        replay_and_compare("on its first replay")
+        if os.environ.get("DY_VERIFY_BURST") != "0":  # "0": tools/graph_packet_capture.py, to show the corruption happening later
+            for _ in range(2):
+                self.eng.replay(self.rec_fb)
+            replay_and_compare("after 2 eager passes over the same launch list")
 
     # ---- optimizer ----------------------------------------------------------------------------------------------
     def all_reduce(self):

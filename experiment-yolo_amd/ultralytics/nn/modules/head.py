@@ -7,7 +7,6 @@ import torch
 import torch.nn as nn
 
 from ...hip import DY_ACT_NONE
-from ...hip.engine import dev_empty
 from ...hip.runtime import HipModule
 from .block import DFL
 from .conv import Conv
@@ -90,9 +89,9 @@ class Detect(HipModule):
         eng = rt.eng
         ncp = (self.nc + 7) // 8 * 8
         nb = 4 * self.reg_max
-        boxes = [dev_empty((x.N, x.H, x.W, nb), torch.float32, eng.device) for x in xs]
+        boxes = [eng.transient((x.N, x.H, x.W, nb), torch.float32) for x in xs]
         # the 1x1 class conv writes channels [0, nc): padding channels (nc rounded up to 8) need a defined value only if they exist
-        clss = [dev_empty((x.N, x.H, x.W, ncp), torch.float32, eng.device) if ncp == self.nc else
+        clss = [eng.transient((x.N, x.H, x.W, ncp), torch.float32) if ncp == self.nc else
                 torch.zeros((x.N, x.H, x.W, ncp), dtype=torch.float32, device=eng.device) for x in xs]
         eng.hold(*boxes, *clss)
         ho = HeadOut(boxes, clss, self.nc, [float(s) for s in self.stride])

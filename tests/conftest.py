@@ -10,6 +10,8 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import ultralytics.hip  # noqa: E402,F401  (sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before any test initialises HIP)
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 CFG_DIR = os.path.join(PKG, "ultralytics", "cfg", "models")
 

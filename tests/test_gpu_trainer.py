@@ -145,3 +145,109 @@ def test_soap_is_selectable_by_name_and_trains():
     assert plan._soap.state[1].q == [None]  # its BatchNorm weight: 1-D tensors run plain Adam
     with pytest.raises(NotImplementedError, match="not found in list of available optimizers"):
         YOLO(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml")).train(data=src, batch=4, imgsz=64, epochs=1, optimizer="LAMB")
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
+def test_multi_scale_runs_every_size_over_one_arena(graph):
+    """multi_scale=True (reference models/yolo/detect/train.py:60-73): each batch is re-interpolated to a random multiple of the
+    grid size in [0.5, 1.5] x imgsz.  Every size has its own recorded launch list; all of them lay their step-local buffers over
+    ONE arena.  Checked: the sizes follow the reference's draw, the stem input is the bilinear re-interpolation torch computes, and
+    the run is bit-identical to one whose size plans keep separate buffers (nothing a plan needs survives in the arena across
+    steps, nothing a plan leaves there disturbs another)."""
+    import random
+
+    from ultralytics import YOLO
+    from ultralytics.data import SyntheticDetection
+
+    def run(share):
+        torch.manual_seed(0)
+        y = YOLO(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"))
+        src = SyntheticDetection(n_batches=8, batch=4, imgsz=64, boxes_per_image=3, wh=(0.1, 0.4), seed=3)
+        from ultralytics.engine.trainer import DetectionTrainer
+        DetectionTrainer.share_arena = share
+        try:
+            hist = y.train(data=src, batch=4, imgsz=64, epochs=2, optimizer="SGD", warmup_epochs=0.0, lr0=0.01, nbs=4, hipgraph=graph,
+                           multi_scale=True, amp=False)
+        finally:
+            DetectionTrainer.share_arena = True
+        tr = y.trainer
+        return hist, tr.plan.rt.flat_p.clone(), tr.plan.rt.flat_b.clone(), tr, src
+
+    hist, p1, b1, tr, src = run(True)
+    random.seed(0)  # the trainer seeds Python's generator with seed + 1 + RANK = 0 (reference engine/trainer.py:526), nothing else draws from it
+    want = [random.randrange(32, 96 + 32) // 32 * 32 for _ in range(16)]  # the reference's draw for imgsz 64, grid 32
+    sizes = sorted(k[1] for k in tr.plans if isinstance(k, tuple))
+    assert sizes == sorted(set(want) - {64}) and len(sizes) >= 2, (sizes, want)
+    assert all(torch.isfinite(h).all() for h in hist) and float(tr.plan.state[5]) == 16 and float(tr.plan.state[6]) == 0
+    assert tr.arena is not None and 0 < tr.arena.peak <= tr.arena.cap
+    # the last scaled batch: x_in of its plan against torch's interpolation of the (fp16-rounded) base image
+    last = [b for b in src][-1]
+    k = [s for s in want if s != 64][-1]
+    plan = tr.plans[(4, k, k)]
+    if want[-1] == k:
+        ref = torch.nn.functional.interpolate(last["img"].cuda().half().float(), size=(k, k), mode="bilinear", align_corners=False)
+        got = plan.x_in[..., :3].permute(0, 3, 1, 2).float()
+        assert float((got - ref).abs().max()) <= 1e-3 and float(plan.x_in[..., 3:].abs().max()) == 0.0
+    hist2, p2, b2, tr2, _ = run(False)
+    assert tr2.arena is not None and all(pl.arena is None for pl in tr2.plans.values())
+    assert torch.equal(p1, p2) and torch.equal(b1, b2) and all(torch.equal(a, b) for a, b in zip(hist, hist2))
+    assert all(pl.arena is tr.arena for k, pl in tr.plans.items() if isinstance(k, tuple))
+
+
+def test_a_captured_step_survives_bursts_of_ordinary_launches():
+    """The hipGraph defect of this ROCm (hip/__init__.py, tools/graph_packet_capture.py): with the runtime's graph packet capture on,
+    ~1,000 of this library's launches between two replays corrupt an instantiated graph.  The package turns the feature off at
+    import; here the bursts that corrupted it -- 25 eval-mode forwards (what a validation pass between two epochs is), the traces
+    of three other launch lists -- sit between the replays of a captured training step, which must keep returning exactly what
+    the same launch list returns when issued eagerly."""
+    import numpy as np
+
+    from ultralytics.hip import GRAPH_SAFE
+    from ultralytics.hip.train import StepPlan
+    from ultralytics.nn.tasks import DetectionModel
+    assert GRAPH_SAFE and os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+
+    def batch(B, S, seed):
+        rng = np.random.default_rng(seed)
+        return dict(img=torch.from_numpy(rng.random((B, 3, S, S), dtype=np.float32)), batch_idx=torch.arange(B).repeat_interleave(3).float(),
+                    cls=torch.from_numpy(rng.integers(0, 6, (B * 3, 1)).astype(np.float32)),
+                    bboxes=torch.from_numpy(np.concatenate([rng.random((B * 3, 2)) * 0.6 + 0.2, rng.random((B * 3, 2)) * 0.3 + 0.2], 1).astype(np.float32)))
+
+    torch.manual_seed(0)
+    m = DetectionModel(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"), verbose=False).cuda().train()
+    B, S = 4, 64
+    plan = StepPlan(m, B, S, nmax=8, init_scale=1.0, use_graph=True, dynamic_scale=False)
+    plan.set_hyper([0.0] * 3, 0.9, [0.0] * 3)  # zero step size: the weights stay put, so every replay must give the same numbers
+    b0 = batch(B, S, 0)
+    plan.forward_backward(b0)
+    plan.optimizer_step()
+    torch.cuda.synchronize()
+    want_g, want_s = plan.rt.flat_g.clone(), plan.crit.scalars[5:9].clone()
+    assert torch.isfinite(want_g).all()
+    others = []
+    for burst in range(3):
+        m.eval()
+        with torch.no_grad():
+            for _ in range(25):
+                m(torch.rand(B, 3, S, S, device="cuda"))
+        m.train()
+        o = StepPlan(m, B, 32 * (1 + burst), nmax=8, init_scale=1.0, use_graph=False, dynamic_scale=False, share=plan)
+        o.forward_backward(batch(B, 32 * (1 + burst), 50 + burst))
+        others.append(o)
+        plan.forward_backward(b0)
+        plan.optimizer_step()
+        torch.cuda.synchronize()
+        assert torch.equal(plan.crit.scalars[5:9], want_s) and torch.equal(plan.rt.flat_g, want_g), f"graph replay changed after burst {burst}"
+    plan.check_progress()
+    assert float(plan.state[5]) == 4 and float(plan.state[6]) == 0
+
+
+def test_graphs_are_refused_when_the_runtime_flag_is_not_in_effect():
+    import subprocess
+    import sys
+    code = ("import sys, os\nsys.path.insert(0, %r)\nimport torch\nfrom ultralytics.hip import GRAPH_SAFE\nfrom ultralytics.hip.train import StepPlan\n"
+            "from ultralytics.nn.tasks import DetectionModel\nm = DetectionModel(%r, verbose=False).cuda().train()\nprint('safe', GRAPH_SAFE)\n"
+            "try:\n    StepPlan(m, 2, 64, use_graph=True)\n    print('constructed')\nexcept RuntimeError as e:\n    print('refused:', 'DEBUG_CLR_GRAPH_PACKET_CAPTURE' in str(e))\n"
+            "StepPlan(m, 2, 64, use_graph=False)\nprint('eager ok')\n") % (os.path.join(os.path.dirname(CFG_DIR), "..", ".."), os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1"))
+    assert "safe False" in p.stdout and "refused: True" in p.stdout and "eager ok" in p.stdout and "constructed" not in p.stdout, p.stdout + p.stderr[-800:]

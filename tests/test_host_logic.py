@@ -207,3 +207,15 @@ def test_soap_matches_the_reference_trainers_optimizer(golden):
             for i, p in enumerate(ps):
                 ref = G.t(f"step{step}/p{i}")
                 assert float((p - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (step, i, float((p - ref).abs().max()))
+
+
+def test_importing_the_package_turns_graph_packet_capture_off():
+    """hip/__init__.py: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before HIP initialises (the hipGraph defect of
+    this ROCm); a user's own setting is respected and then decides whether graphs are allowed."""
+    import subprocess
+    import sys
+    from conftest import PKG
+    code = f"import sys, os; sys.path.insert(0, {PKG!r}); import ultralytics.hip as h; print(os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'), h.GRAPH_SAFE)"
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.split() == ["0", "True"]
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1")).stdout.split() == ["1", "False"]
