@@ -6,6 +6,7 @@
 #      SQ_LDS_BANK_CONFLICT + SQ_LDS_IDX_ACTIVE  (counters only with --kernel-trace: gpurun refuses other trace domains with --pmc)
 # usage: tools/collect_profiles.sh [extra bench.py arguments, e.g. --loss wiou+nwd]
 set -e
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0  # the profiler may initialise HIP before Python can set it (ultralytics/hip/__init__.py)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_mfma gpurun_out/prof_lds
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o st --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu "$@" > gpurun_out/prof_stats.log 2>&1
