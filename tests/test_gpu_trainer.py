@@ -251,3 +251,24 @@ def test_graphs_are_refused_when_the_runtime_flag_is_not_in_effect():
             "StepPlan(m, 2, 64, use_graph=False)\nprint('eager ok')\n") % (os.path.join(os.path.dirname(CFG_DIR), "..", ".."), os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1"))
     assert "safe False" in p.stdout and "refused: True" in p.stdout and "eager ok" in p.stdout and "constructed" not in p.stdout, p.stdout + p.stderr[-800:]
+
+
+@pytest.mark.parametrize("cache,aug", [(False, dict(fliplr=0.5, hsv_h=0.015, hsv_s=0.7, hsv_v=0.4)), ("hbm", dict(mosaic=1.0, scale=0.5, translate=0.1, fliplr=0.5))],
+                         ids=["loader-u8-flips-hsv", "hbm-pool-mosaic"])
+def test_multi_scale_from_the_dataset_loader(tmp_path, cache, aug):
+    """multi_scale over the loader's own batch formats: uint8 NHWC pixels with pending flips / HSV gains, and the HBM-resident pool
+    with mosaic + affine records -- the base-size import kernel runs eagerly, its output is re-interpolated into the size plan."""
+    from golden.cases import write_dataset
+    from ultralytics import YOLO
+    root = str(tmp_path / "ds")
+    write_dataset(root)
+    zero = dict(mosaic=0.0, mixup=0.0, copy_paste=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, degrees=0.0, translate=0.0, scale=0.0, shear=0.0,
+                perspective=0.0, flipud=0.0, fliplr=0.0)
+    y = YOLO(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"))
+    hist = y.train(data=os.path.join(root, "data.yaml"), cache=cache, imgsz=64, epochs=3, batch=4, workers=2, optimizer="SGD", val=False,
+                   multi_scale=True, close_mosaic=0, **{**zero, **aug})
+    tr = y.trainer
+    sizes = sorted({k[1] for k in tr.plans if isinstance(k, tuple)})
+    assert len(hist) == 3 and all(torch.isfinite(h).all() for h in hist)
+    assert sizes and set(sizes) <= {32, 96}, sizes  # 64 runs through the ordinary plan
+    assert float(tr.plan.state[5]) + float(tr.plan.state[6]) == tr.plan.opt_calls and float(tr.plan.state[5]) >= tr.plan.opt_calls - 4
