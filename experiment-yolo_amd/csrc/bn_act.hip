@@ -299,7 +299,10 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int lddy, const void* x, int
   const int rows = 256 / cpp;
   long blocks = (npix + (long)rows * 8 - 1) / ((long)rows * 8);
   if (blocks > max_partials) blocks = max_partials;
-  if (blocks > 2048) blocks = 2048;
+  // 1024 blocks (4 per CU): 14.20 / 14.23 ms per step against 14.34 / 14.35 at 2048 and 14.43 at 512 or 1536 (alternating runs on one
+  // box, round 2) -- fewer partial rows for the finalize launch that follows, still enough loads in flight
+  static const long bcap = getenv("DY_EW_BLOCKS_BRED") ? atol(getenv("DY_EW_BLOCKS_BRED")) : 1024;
+  if (blocks > bcap) blocks = bcap;
   if (blocks < 1) blocks = 1;
   if (nparts) *nparts = (int)blocks;
   const int rev = ew_reverse();
