@@ -105,12 +105,12 @@ zero = dict(mosaic=0.0, mixup=0.0, copy_paste=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0
             perspective=0.0, flipud=0.0, fliplr=0.0)
 model = YOLO('yolov8n-ASF-P2P2.yaml')
 hist = model.train(data={os.path.join(root, 'data.yaml')!r}, cache=False, imgsz=64, epochs=2, batch=4, close_mosaic=10, workers=2,
-                   device=DEVICE, optimizer='SGD', project={str(tmp_path / 'runs')!r}, name='exp', val=False, **zero)
+                   device=DEVICE, optimizer='SGD', project={str(tmp_path / 'runs')!r}, name='exp', val=False, **dict(zero, **EXTRA))
 print('RESULT', json.dumps([[float(x) for x in h] for h in hist]), getattr(model, 'ddp_result', None) is not None)
 """
     outs = {}
-    for dev, env in (("'0'", {}), ("'0,1'", {"DY_REHEARSE_ON_ONE_GPU": "1"})):
-        p = subprocess.run([sys.executable, "-c", code.replace("DEVICE", dev)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    for dev, env, extra in (("'0'", {}, "{}"), ("'0,1'", {"DY_REHEARSE_ON_ONE_GPU": "1"}, "{}"), ("'0,1' ", {"DY_REHEARSE_ON_ONE_GPU": "1"}, "dict(multi_scale=True)")):
+        p = subprocess.run([sys.executable, "-c", code.replace("DEVICE", dev).replace("EXTRA", extra)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1]
         outs[dev] = (np.array(eval(line.split(" ", 1)[1].rsplit(" ", 1)[0])), line.endswith("True"), p.stderr)
@@ -119,3 +119,5 @@ print('RESULT', json.dumps([[float(x) for x in h] for h in hist]), getattr(model
     assert ddp[1], "device='0,1' must have gone through the torch.distributed.run re-launch"
     assert ddp[0].shape == (2, 3) and np.isfinite(ddp[0]).all()
     assert "torch.distributed.run" in ddp[2] and "--nproc_per_node=2" in ddp[2]
+    ms = outs["'0,1' "]  # the same re-launch with multi_scale=True: every rank draws its own sizes (seed + 1 + RANK) and traces its own
+    assert ms[1] and ms[0].shape == (2, 3) and np.isfinite(ms[0]).all()  # plans; the step's one collective keeps the ranks in step
