@@ -12,8 +12,12 @@ Prints ONE JSON line on rank 0.  Extra objects:
                launch duration, measured live with HIP events on the launch stream, against 8 TB/s HBM; `traffic` = its PMC HBM
                bytes per launch from profiles/; `step` = the whole step priced the same way (images/s x 367 MB / 8 TB/s);
                `top_conv` = the most expensive convolution instantiation, for comparison with earlier rounds;
-  cpu_baseline the CPU oracle (a port of the reference's PyTorch CPU path) timed on the host cores, bs=16, about 15 s of CPU work.
---loss ciou|wiou|ciou+nwd|wiou+nwd selects the box loss (reference default: ciou; BASELINE north_star names wiou+nwd).
+  cpu_baseline the CPU oracle (a port of the reference's PyTorch CPU path) timed on the host cores in BASELINE.md section 2's protocol
+               (bs=2, median of 8 steps after 2 warm-up); `bs16` = the same at bs=16 (about 25 s of CPU work: the bounded sample).
+--loss ciou|wiou|ciou+nwd|wiou+nwd selects the box loss: the default is the north-star's wiou+nwd; the reference-default ciou rate is
+measured beside it (config.ciou_images_per_s: the same launch list replayed eagerly with the other loss mode).
+--gpus N from a plain `python bench.py` start re-launches itself under torch.distributed.run (one rank per GPU) as a CHILD process
+before anything touches the GPU, like YOLO.train(device='0,1,..') does (reference engine/trainer.py:607-627, utils/dist.py:47-65).
 """
 import argparse
 import json
@@ -62,25 +66,49 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(imgsz, steps=10, warm=2, bs=16):
-    """CPU oracle (port of the reference PyTorch CPU trainer step: forward + loss + autograd backward + SGD + EMA)."""
+def cpu_baseline(imgsz):
+    """CPU oracle (port of the reference PyTorch CPU trainer step: forward + loss + autograd backward + SGD + EMA).
+    `value`: BASELINE.md section 2's protocol (bs=2, median of 8 steps after 2 warm-up steps); `bs16`: 10 steps of bs=16."""
     from oracle import graph as og, trainer as otr
     g = og.build_graph(og.load_yaml(CFG))
-    sd = og.default_init_state(g, 0)
-    ts = otr.TrainState(g, sd, otr.Hyp(), batch_size=bs, nb=8)
     torch.set_num_threads(host_cores())
-    t = []
-    for i in range(warm + steps):
-        batch = synth_batch(100 + i, bs, imgsz, g.nc)
-        t0 = time.perf_counter()
-        otr.train_step(ts, batch)
-        t.append(time.perf_counter() - t0)
-        print(f"[bench] cpu_baseline step {i + 1}/{warm + steps}: {t[-1]:.2f} s ({torch.get_num_threads()} threads)", file=sys.stderr, flush=True)
-        if sum(t) > 90:  # bounded sample: never let the reported baseline stall the run
-            break
-    dt = float(np.median(t[warm:] if len(t) > warm else t))
-    return {"value": bs / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} steps of bs={bs} {imgsz}x{imgsz} after {warm} warm-up (median), fp32, oracle/trainer.py"}
+
+    def run(bs, steps, warm, budget):
+        ts = otr.TrainState(g, og.default_init_state(g, 0), otr.Hyp(), batch_size=bs, nb=8)
+        t = []
+        for i in range(warm + steps):
+            batch = synth_batch(100 + i, bs, imgsz, g.nc)
+            t0 = time.perf_counter()
+            otr.train_step(ts, batch)
+            t.append(time.perf_counter() - t0)
+            print(f"[bench] cpu_baseline bs={bs} step {i + 1}/{warm + steps}: {t[-1]:.2f} s ({torch.get_num_threads()} threads)", file=sys.stderr, flush=True)
+            if sum(t) > budget:  # bounded sample: never let the reported baseline stall the run
+                break
+        return bs / float(np.median(t[warm:] if len(t) > warm else t))
+
+    v2 = run(2, 8, 2, 60)
+    v16 = run(16, 10, 2, 90)
+    return {"value": v2, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"8 steps of bs=2 {imgsz}x{imgsz} after 2 warm-up (median), fp32, oracle/trainer.py -- BASELINE.md section 2's protocol; "
+                      f"bs16 = 10 steps of bs=16 after 2 warm-up (about 25 s of CPU work)",
+            "bs16": v16}
+
+
+def relaunch(a):
+    """--gpus N without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child
+    process -- nothing in this process has touched the GPU yet -- and relay its output (rank 0 prints the JSON line)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(p.stdout)
+    sys.stdout.flush()
+    raise SystemExit(p.returncode)
 
 
 def main():
@@ -94,14 +122,17 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--probe", type=int, default=1, help="time the dominant kernel with HIP events")
     ap.add_argument("--model", default="yolov8n-ASF-P2P2", help="model YAML stem (yolov8n-LD-P2 = BASELINE.json configs[3])")
-    ap.add_argument("--loss", default="ciou", choices=["ciou", "wiou", "ciou+nwd", "wiou+nwd"], help="box loss mode")
+    ap.add_argument("--lr", type=float, default=0.01, help="learning rate of the three parameter groups (timing does not depend on it; "
+                    "tiny test configurations pass a smaller one so that no step overflows)")
+    ap.add_argument("--loss", default="wiou+nwd", choices=["ciou", "wiou", "ciou+nwd", "wiou+nwd"],
+                    help="box loss mode (north-star: wiou+nwd; the reference's cfg default is ciou)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     rehearsal = os.environ.get("DY_REHEARSE_ON_ONE_GPU") == "1"  # N ranks on one GPU over gloo: exercises the N>1 code path only
     if rehearsal:
         local = 0
@@ -133,7 +164,7 @@ def main():
     # at the import kernel instead of with a 315 MB device-to-device staging copy
     plan.img.copy_(batch["img"])
     batch["img"] = plan.img
-    lr, mom, wd = [0.01, 0.01, 0.01], 0.937, [0.0, 0.0005 * a.batch * world / 64 if a.batch * world < 64 else 0.0005, 0.0]
+    lr, mom, wd = [a.lr] * 3, 0.937, [0.0, 0.0005 * a.batch * world / 64 if a.batch * world < 64 else 0.0005, 0.0]
 
     def one_step():
         plan.set_hyper(lr, mom, wd)
@@ -144,6 +175,18 @@ def main():
 
     for _ in range(a.warmup):
         one_step()
+    # The dynamic loss scale starts at 65536 (GradScaler's policy) and halves on every overflow: until the search ends some
+    # optimizer steps are skipped ones.  Keep stepping (untimed) until the skip counter has stood still for three steps, so that
+    # every TIMED step is a full one whatever --warmup was.
+    settle, still, last = 0, 0, float(plan.state[6])
+    while still < 3 and settle < 40:
+        one_step()
+        settle += 1
+        now = float(plan.state[6])
+        still, last = (still + 1, last) if now == last else (0, now)
+    if world > 1:  # every rank leaves the settling loop after the same number of steps (all-reduced gradients overflow together)
+        dist.barrier()
+    skipped_before = float(plan.state[6])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -163,6 +206,28 @@ def main():
     ms = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
     plan.check_progress()  # a step whose optimizer launches do not take effect (counter stuck, everything skipped) is not a number
+    skipped_timed = float(plan.state[6]) - skipped_before
+
+    # the reference-default CIoU loss beside the north-star's WIoU+NWD (or the other way round): same launch list, replayed
+    # eagerly (the loss mode is a by-value launch argument, so it cannot change inside the captured graph)
+    other = "ciou" if a.loss != "ciou" else "wiou+nwd"
+    other_rate = None
+    if world == 1:
+        g_fb, plan.graph_fb = plan.graph_fb, None
+        try:
+            plan.crit.bbox_loss.use_wiseiou, plan.crit.bbox_loss.nwd_loss = other.startswith("wiou"), other.endswith("nwd")
+            for _ in range(3):
+                one_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                one_step()
+            torch.cuda.synchronize()
+            other_rate = a.batch * a.steps / (time.perf_counter() - t1)
+        finally:
+            plan.crit.bbox_loss.use_wiseiou, plan.crit.bbox_loss.nwd_loss = a.loss.startswith("wiou"), a.loss.endswith("nwd")
+            plan.crit.sync_modes()
+            plan.graph_fb = g_fb
 
     roof = None
     if rank == 0 and a.probe:
@@ -200,7 +265,8 @@ def main():
                "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": f"{'DEAL-YOLO-N' if a.model == 'yolov8n-ASF-P2P2' else a.model} ({a.model}.yaml) train step {a.imgsz}x{a.imgsz}, per-GPU batch {a.batch}, "
                                       f"fwd+TAL/{a.loss.upper()}/DFL/BCE loss+bwd+SGD+EMA, BASELINE.json configs[{3 if 'LD' in a.model else 1}]",
-                          "loss_mode": a.loss,
+                          "loss_mode": a.loss, f"{other.replace('+', '_')}_images_per_s": other_rate,
+                          "settle_steps": settle, "skipped_in_timed_steps": skipped_timed,
                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
                           "loss_items_last": [float(x) for x in s[5:8]], "loss_scale": float(plan.state[0]),
                           "skipped_steps": float(plan.state[6]),

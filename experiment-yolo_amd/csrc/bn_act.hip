@@ -145,17 +145,62 @@ struct ApplyArgs {
   int rev;  // walk the pixels from the far end (DY_EW_REVERSE bit 0)
 };
 
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a) {
+// Statistics that arrive in an fp64 accumulator instead of a finished coefficient table (the *_acc entry points): the conv
+// epilogue / the backward reduce ADD their per-workgroup sums into acc[copy][2][C] (copy = blockIdx.x % DY_BN_COPIES, so at most
+// gridDim.x / DY_BN_COPIES adders meet on one address) and the kernel that consumes the statistics sums the copies in its own
+// prologue -- every block for itself, block 0 also leaves the finished values behind (coef / running statistics, or the
+// parameter gradients).  This removes the separate finalize launch (~4.7 us + a launch boundary, 127 times per step) without
+// any cross-workgroup wait.  The partial sums are fp32 values added in fp64: the order of the adds changes the result by
+// at most 2^-53 relative, so after the rounding to fp32 the statistics repeat bit for bit from run to run.
+struct BnAccFwd {
+  const double* acc;  // [DY_BN_COPIES][2][C]: sum, sum of squares
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float* coef_out;    // [4][C] written by block 0 (the backward kernels read it)
+  float count, eps, momentum;
+};
+
+template <int ACT, bool ACC>
+__global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a, BnAccFwd b) {
   // a thread owns one 8-channel granule for the whole launch: scale/shift live in registers
   const int cpp = a.C >> 3, rows = 256 / cpp;
   const int part = threadIdx.x % cpp, row = threadIdx.x / cpp, c0 = part * 8;
+  extern __shared__ float s_coef[];  // ACC: [2][C]
+  if (ACC) {
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < DY_BN_COPIES; ++k) {
+        s1 += b.acc[(size_t)(k * 2 + 0) * a.C + c];
+        s2 += b.acc[(size_t)(k * 2 + 1) * a.C + c];
+      }
+      const double mean = s1 / b.count;
+      double var = s2 / b.count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)b.eps));
+      const float scl = b.gamma[c] * invstd, shf = b.beta[c] - (float)mean * scl;
+      s_coef[c] = scl;
+      s_coef[a.C + c] = shf;
+      if (blockIdx.x == 0) {
+        b.coef_out[c] = scl;
+        b.coef_out[a.C + c] = shf;
+        b.coef_out[2 * a.C + c] = (float)mean;
+        b.coef_out[3 * a.C + c] = invstd;
+        const double unbiased = b.count > 1.f ? var * b.count / (b.count - 1.0) : var;
+        b.running_mean[c] = (1.f - b.momentum) * b.running_mean[c] + b.momentum * (float)mean;
+        b.running_var[c] = (1.f - b.momentum) * b.running_var[c] + b.momentum * (float)unbiased;
+      }
+    }
+    __syncthreads();
+  }
   if (row >= rows) return;
   float sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    sc[j] = a.coef[c0 + j];
-    sh[j] = a.coef[a.C + c0 + j];
+    sc[j] = ACC ? s_coef[c0 + j] : a.coef[c0 + j];
+    sh[j] = ACC ? s_coef[a.C + c0 + j] : a.coef[a.C + c0 + j];
   }
   auto at = [&](long p) { return a.rev ? a.npix - 1 - p : p; };
   auto one = [&](long pix, const half8& xv) {
@@ -211,7 +256,31 @@ extern "C" int dy_bn_act_apply(const void* x, int ldx, const void* res, int ldr,
   if ((C >> 3) > 256) return DY_ERR_ARG;
   const int rev = ew_reverse();
   ApplyArgs a{(const f16*)x, (const f16*)res, (f16*)y, coef, ldx, ldr, ldy, C, act, npix, rev & 1};
-  DY_ACT_DISPATCH(bn_act_apply_kernel, dim3(ew_blocks(npix, C, "DY_EW_BLOCKS_APPLY", 8192)), stream, a);
+  const BnAccFwd b{};
+  const dim3 grid(ew_blocks(npix, C, "DY_EW_BLOCKS_APPLY", 8192));
+  if (act == DY_ACT_SILU) hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_SILU, false>), grid, dim3(256), 0, stream, a, b);
+  else if (act == DY_ACT_LEAKY) hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_LEAKY, false>), grid, dim3(256), 0, stream, a, b);
+  else hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_NONE, false>), grid, dim3(256), 0, stream, a, b);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+extern "C" int dy_bn_act_apply_acc(const void* x, int ldx, const void* res, int ldr, void* y, int ldy, const double* acc,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   float* coef, long npix, int C, int act, float count, float eps, float momentum,
+                                   hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (ldy & 7) || (res && (ldr & 7))) return DY_ERR_ALIGN;
+  if ((C >> 3) > 256 || !acc || !gamma || !beta || !running_mean || !running_var || !coef) return DY_ERR_ARG;
+  const int rev = ew_reverse();
+  ApplyArgs a{(const f16*)x, (const f16*)res, (f16*)y, nullptr, ldx, ldr, ldy, C, act, npix, rev & 1};
+  const BnAccFwd b{acc, gamma, beta, running_mean, running_var, coef, count, eps, momentum};
+  // every block pays the prologue (DY_BN_COPIES x 2 x C doubles from L2 + one fp64 sqrt/divide per channel), so fewer, longer
+  // blocks than the coefficient-table form
+  const dim3 grid(ew_blocks(npix, C, "DY_EW_BLOCKS_APPLY_ACC", 4096));
+  const size_t lds = 2 * (size_t)C * sizeof(float);
+  if (act == DY_ACT_SILU) hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_SILU, true>), grid, dim3(256), lds, stream, a, b);
+  else if (act == DY_ACT_LEAKY) hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_LEAKY, true>), grid, dim3(256), lds, stream, a, b);
+  else hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_NONE, true>), grid, dim3(256), lds, stream, a, b);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
@@ -226,6 +295,7 @@ struct BwdRedArgs {
   int lddy, ldx, C, act;
   long npix;
   int rev;  // DY_EW_REVERSE bit 2
+  double* acc;      // non-null: add the block's sums into acc[blockIdx.x % DY_BN_COPIES][2][C] instead (see BnAccFwd)
 };
 
 template <int ACT>
@@ -286,7 +356,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
     const int which = i / a.C, c = i - which * a.C, pp = c >> 3, j = c & 7;
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += red[which][r * cpp + pp][j];
-    a.partials[((size_t)blockIdx.x * 2 + which) * a.C + c] = s;
+    if (a.acc) unsafeAtomicAdd(&a.acc[((size_t)(blockIdx.x % DY_BN_COPIES) * 2 + which) * a.C + c], (double)s);
+    else a.partials[((size_t)blockIdx.x * 2 + which) * a.C + c] = s;
   }
 }
 
@@ -306,7 +377,24 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int lddy, const void* x, int
   if (blocks < 1) blocks = 1;
   if (nparts) *nparts = (int)blocks;
   const int rev = ew_reverse();
-  BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, partials, lddy, ldx, C, act, npix, (rev >> 2) & 1};
+  BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, partials, lddy, ldx, C, act, npix, (rev >> 2) & 1, nullptr};
+  DY_ACT_DISPATCH(bn_act_bwd_reduce_kernel, dim3((int)blocks), stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+extern "C" int dy_bn_act_bwd_reduce_acc(const void* dy, int lddy, const void* x, int ldx, const float* coef, double* acc,
+                                        long npix, int C, int act, hipStream_t stream) {
+  if ((C & 7) || C > 2048 || (ldx & 7) || (lddy & 7)) return DY_ERR_ALIGN;
+  const int cpp = C >> 3;
+  if (cpp > 256 || !acc) return DY_ERR_ARG;
+  const int rows = 256 / cpp;
+  long blocks = (npix + (long)rows * 8 - 1) / ((long)rows * 8);
+  static const long bcap = getenv("DY_EW_BLOCKS_BRED") ? atol(getenv("DY_EW_BLOCKS_BRED")) : 1024;
+  if (blocks > bcap) blocks = bcap;
+  if (blocks < 1) blocks = 1;
+  const int rev = ew_reverse();
+  BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, nullptr, lddy, ldx, C, act, npix, (rev >> 2) & 1, acc};
   DY_ACT_DISPATCH(bn_act_bwd_reduce_kernel, dim3((int)blocks), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
@@ -360,12 +448,34 @@ struct BwdApplyArgs {
   int lddy, ldx, lddx, C, act, frozen_stats;
   long npix;
   int rev;  // DY_EW_REVERSE bit 1
+  const double* acc;  // non-null: [DY_BN_COPIES][2][C] sums of g and g*xhat from the reduce pass (replaces bwdcoef)
+  float* dgamma;      // with acc: written by block 0
+  float* dbeta;
+  float count;
 };
 
-template <int ACT>
+template <int ACT, bool ACC>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BwdApplyArgs a) {
   const int cpp = a.C >> 3, rows = 256 / cpp;
   const int part = threadIdx.x % cpp, row = threadIdx.x / cpp, c0 = part * 8;
+  extern __shared__ float s_bw[];  // ACC: [2][C] = mean_g, mean_gxhat
+  if (ACC) {
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < DY_BN_COPIES; ++k) {
+        s1 += a.acc[(size_t)(k * 2 + 0) * a.C + c];
+        s2 += a.acc[(size_t)(k * 2 + 1) * a.C + c];
+      }
+      s_bw[c] = (float)(s1 / a.count);
+      s_bw[a.C + c] = (float)(s2 / a.count);
+      if (blockIdx.x == 0) {
+        if (a.dbeta) a.dbeta[c] = (float)s1;
+        if (a.dgamma) a.dgamma[c] = (float)s2;
+      }
+    }
+    __syncthreads();
+  }
   if (row >= rows) return;
   // dx = sc*(g - mean_g - xhat*mean_gx) = sc*g - kb*x - kc  with  kb = sc*invstd*mean_gx,  kc = sc*mean_g - kb*mean
   float sc[8], sh[8], kb[8], kc[8];
@@ -374,8 +484,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BwdApplyArgs a) {
     sc[j] = a.coef[c0 + j];
     sh[j] = a.coef[a.C + c0 + j];
     const float mean = a.coef[2 * a.C + c0 + j], inv = a.coef[3 * a.C + c0 + j];
-    const float mg = a.frozen_stats ? 0.f : a.bwdcoef[c0 + j];
-    const float mgx = a.frozen_stats ? 0.f : a.bwdcoef[a.C + c0 + j];
+    const float mg = ACC ? s_bw[c0 + j] : (a.frozen_stats ? 0.f : a.bwdcoef[c0 + j]);
+    const float mgx = ACC ? s_bw[a.C + c0 + j] : (a.frozen_stats ? 0.f : a.bwdcoef[a.C + c0 + j]);
     kb[j] = sc[j] * inv * mgx;
     kc[j] = sc[j] * mg - kb[j] * mean;
   }
@@ -411,8 +521,29 @@ extern "C" int dy_bn_act_bwd_apply(const void* dy, int lddy, const void* x, int 
   if ((C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7)) return DY_ERR_ALIGN;
   if ((C >> 3) > 256) return DY_ERR_ARG;
   const int rev = ew_reverse();
-  BwdApplyArgs a{(const f16*)dy, (const f16*)x, (f16*)dx, coef, bwdcoef, lddy, ldx, lddx, C, act, frozen_stats, npix, (rev >> 1) & 1};
-  DY_ACT_DISPATCH(bn_act_bwd_apply_kernel, dim3(ew_blocks(npix, C, "DY_EW_BLOCKS_BAPPLY", 512)), stream, a);
+  BwdApplyArgs a{(const f16*)dy, (const f16*)x, (f16*)dx, coef, bwdcoef, lddy, ldx, lddx, C, act, frozen_stats, npix, (rev >> 1) & 1,
+                 nullptr, nullptr, nullptr, 1.f};
+  const dim3 grid(ew_blocks(npix, C, "DY_EW_BLOCKS_BAPPLY", 512));
+  if (act == DY_ACT_SILU) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DY_ACT_SILU, false>), grid, dim3(256), 0, stream, a);
+  else if (act == DY_ACT_LEAKY) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DY_ACT_LEAKY, false>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DY_ACT_NONE, false>), grid, dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+extern "C" int dy_bn_act_bwd_apply_acc(const void* dy, int lddy, const void* x, int ldx, void* dx, int lddx,
+                                       const float* coef, const double* acc, float* dgamma, float* dbeta, long npix, int C,
+                                       int act, float count, hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7)) return DY_ERR_ALIGN;
+  if ((C >> 3) > 256 || !acc) return DY_ERR_ARG;
+  const int rev = ew_reverse();
+  BwdApplyArgs a{(const f16*)dy, (const f16*)x, (f16*)dx, coef, nullptr, lddy, ldx, lddx, C, act, 0, npix, (rev >> 1) & 1,
+                 acc, dgamma, dbeta, count};
+  const dim3 grid(ew_blocks(npix, C, "DY_EW_BLOCKS_BAPPLY", 512));
+  const size_t lds = 2 * (size_t)C * sizeof(float);
+  if (act == DY_ACT_SILU) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DY_ACT_SILU, true>), grid, dim3(256), lds, stream, a);
+  else if (act == DY_ACT_LEAKY) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DY_ACT_LEAKY, true>), grid, dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DY_ACT_NONE, true>), grid, dim3(256), lds, stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

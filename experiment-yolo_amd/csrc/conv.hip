@@ -33,6 +33,19 @@ struct ConvArgs {
   int xcd_map;    // 1: workgroups of one XCD (blockIdx.x % 8) own a contiguous band of tiles, so halo rows meet in one L2
 };
 
+
+// BN partial sums of one workgroup leave through here: a row of the per-workgroup partial table (DY_EPI_STATS), or -- with
+// DY_EPI_STATS_ACC -- an fp64 atomic add into copy blockIdx.x % DY_BN_COPIES of the layer's accumulator, which the consuming
+// kernel sums in its prologue (bn_act.hip, BnAccFwd): no finalize launch between the convolution and its BatchNorm apply.
+static __device__ __forceinline__ void stats_out(const ConvArgs& a, int which, int c, float s) {
+  const int ctot = (a.cout + 15) & ~15;  // rows are round16(cout) wide whatever the cout-group padding
+  if (c >= ctot) return;
+  if (a.epi & DY_EPI_STATS_ACC)
+    unsafeAtomicAdd(reinterpret_cast<double*>(a.partials) + ((size_t)(blockIdx.x % DY_BN_COPIES) * 2 + which) * ctot + c, (double)s);
+  else
+    a.partials[((size_t)blockIdx.x * 2 + which) * ctot + c] = s;
+}
+
 template <int CC, int MT, int KS, int STRIDE, int TROWS>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   constexpr bool FLAT = (KS == 1);
@@ -243,8 +256,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * (16 * MT) + ch];
-      const int ctot = (a.cout + 15) & ~15;  // partial rows are round16(cout) wide whatever the cout-group padding
-      if (blockIdx.y * 16 * MT + ch < ctot) a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + ch] = s;
+      stats_out(a, which, blockIdx.y * 16 * MT + ch, s);
     }
   }
 }
@@ -572,8 +584,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_wlds_kernel(ConvArgs a, int
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) s += red[(w * 2 + which) * (16 * MT) + ch];
-      const int ctot = (a.cout + 15) & ~15;  // partial rows are round16(cout) wide whatever the cout-group padding
-      if (blockIdx.y * 16 * MT + ch < ctot) a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + ch] = s;
+      stats_out(a, which, blockIdx.y * 16 * MT + ch, s);
     }
   }
 }
@@ -1074,8 +1085,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
       float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) sum += red[(w * 2 + which) * (16 * MT) + chn];
-      const int ctot = (a.cout + 15) & ~15;  // partial rows are round16(cout) wide whatever the cout-group padding
-      if (blockIdx.y * 16 * MT + chn < ctot) a.partials[((size_t)blockIdx.x * 2 + which) * ctot + blockIdx.y * 16 * MT + chn] = sum;
+      stats_out(a, which, blockIdx.y * 16 * MT + chn, sum);
     }
   }
 }

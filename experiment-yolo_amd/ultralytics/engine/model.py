@@ -4,6 +4,7 @@ from __future__ import annotations
 import json
 import os
 import subprocess
+import tempfile
 from pathlib import Path
 
 import torch
@@ -118,7 +119,22 @@ class YOLO:
             self.ddp_result = json.load(open(result_file)) if os.path.exists(result_file) else None
         finally:
             ddp_cleanup(file)
-        return None if self.ddp_result is None else self.ddp_result["loss_items"]
+        # reference engine/model.py:612-616: after a DDP run the parent's model is the one the ranks trained (rank 0's checkpoint),
+        # never the untouched copy this process was started with
+        w = None if self.ddp_result is None else self.ddp_result.get("weights")
+        if not w or not os.path.exists(w):
+            raise RuntimeError("the multi-GPU run returned no weights (rank 0 writes <run>/weights/last.pt or a temporary checkpoint)")
+        ck = torch.load(w, map_location="cpu", weights_only=False)
+        names = getattr(self.model, "names", None)
+        self.model = DetectionModel(ck["yaml"], verbose=False)  # the ranks' model: the dataset's class count, the trained weights
+        self.model.load_state_dict(ck["model"], strict=True)
+        if names is not None and len(names) == len(self.model.names):
+            self.model.names = names
+        tmp = w.startswith(os.path.join(tempfile.gettempdir(), "dealyolo_ddp"))
+        self.ckpt_path = None if tmp else w
+        if tmp:  # a hand-over file, not a run artefact
+            os.remove(w)
+        return self.ddp_result["loss_items"]
 
     # ---- predict -------------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -66,6 +66,15 @@ class DetectionTrainer:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world_size, device_id=self.device)
         self.model.to(self.device).train()
         self.model.args = a
+        if self.world_size > 1:
+            # Every rank seeds with seed + 1 + RANK (reference engine/trainer.py:526) and a model built from a YAML after that differs
+            # from rank to rank; the reference relies on DDP's constructor broadcasting rank 0's parameters and buffers
+            # (engine/trainer.py:695).  Same here, on the flat buffers, BEFORE the plan clones them into its EMA.
+            from ..hip.dist import broadcast_buffers
+            rt = self.model._runtime(self.device)
+            broadcast_buffers(rt.flat_p, 0)
+            broadcast_buffers(rt.flat_b, 0)
+            rt.mark_dirty()
         for k, v in self.model.named_parameters():  # always freeze .dfl (engine/trainer.py:670)
             v.requires_grad = ".dfl" not in k
         global_bs = batch_size * self.world_size
@@ -193,11 +202,14 @@ class DetectionTrainer:
         if epochs is not None:
             a.epochs = epochs
         nb = len(loader)
-        if not getattr(a, "nmax", None):  # per-image label capacity from the first batch, with head-room; exceeded later -> raises
-            from ..utils.loss import v8DetectionLoss
-            first = next(iter(loader))
-            a.nmax = max(16, 2 * v8DetectionLoss.capacity_for(first, batch_size))
-            del first
+        if not getattr(a, "nmax", None):  # per-image label capacity of the recorded loss kernels; exceeded later -> raises
+            cap = self._label_capacity(loader)
+            if cap is None:  # an opaque iterable: take it from the first batch, with head-room.  (A dataset-backed loader is NOT
+                from ..utils.loss import v8DetectionLoss  # peeked: starting its producer would consume augmentation draws.)
+                first = next(iter(loader))
+                cap = max(16, 2 * v8DetectionLoss.capacity_for(first, batch_size))
+                del first
+            a.nmax = cap
         self.setup(nb, batch_size, imgsz)
         self.start_epoch = self.resume_training(a.resume) if a.resume else 0
         self.save_dir = self._save_dir()
@@ -223,12 +235,43 @@ class DetectionTrainer:
             self.plan.check_progress()  # raises when optimizer steps are not taking effect (counter stuck, all skipped, scale collapsed)
             hist.append(items if tloss is None else tloss)
             self.epoch = epoch
+            self._check_replicas()
             if self.rank == 0:
                 LOGGER.info(f"epoch {epoch + 1}/{a.epochs}  box/cls/dfl {[round(float(x), 4) for x in hist[-1]]}  "
                             f"{nb * batch_size * self.world_size / (time.time() - t0):.1f} img/s")
                 if self.save_dir is not None:  # reference engine/trainer.py:898-923: last.pt after every epoch
                     self.save_model(self.save_dir / "weights" / "last.pt")
         return hist
+
+    def _check_replicas(self):
+        """Data-parallel replicas must hold identical weights after every optimizer step (same start: setup()'s broadcast; same
+        summed gradients: the step's one all-reduce).  One checksum exchange per epoch makes a divergence an error instead of a
+        silently worse model."""
+        if self.world_size <= 1 or not dist.is_initialized():
+            return
+        rt = self.plan.rt
+        mine = torch.stack([rt.flat_p.double().sum(), rt.flat_p.double().abs().sum()])
+        if dist.get_backend() == "gloo":  # rehearsal: gloo moves host memory
+            mine = mine.cpu()
+        allv = [torch.zeros_like(mine) for _ in range(self.world_size)]
+        dist.all_gather(allv, mine)
+        allv = [v.cpu() for v in allv]
+        if any(not torch.equal(v, allv[0]) for v in allv[1:]):
+            raise RuntimeError(f"data-parallel replicas diverged (parameter checksums per rank: {[v.tolist() for v in allv]})")
+
+    def _label_capacity(self, loader):
+        """Largest number of boxes one training sample can carry, from the dataset's label table: a mosaic holds four images'
+        boxes, MixUp concatenates two samples (reference data/augment.py: Mosaic / MixUp), so up to eight images' boxes meet in
+        one sample.  None for loaders without a label table."""
+        ds = getattr(loader, "dataset", None)
+        labels = getattr(ds, "labels", None)
+        if not labels:
+            return None
+        counts = sorted((len(lb["cls"]) for lb in labels), reverse=True) or [1]
+        per = 4 if getattr(ds, "mosaic", 0.0) else 1
+        if getattr(self.args, "mixup", 0.0):
+            per *= 2
+        return max(8, (sum(counts[:per]) + 7) // 8 * 8)
 
     def _save_dir(self):
         """``project/name`` as in the reference (cfg get_save_dir), created only when one of the two was given explicitly: this
@@ -260,6 +303,10 @@ class DetectionTrainer:
             dst.copy_(f[key])
         if p.adam_v is not None:
             p.adam_v.copy_(f["adam_v"])
+        if p.soap:
+            if "soap" not in opt:
+                raise ValueError(f"{path} was written without the SOAP preconditioner state: a resume would silently restart the optimizer")
+            p.load_soap_state(opt["soap"])
         p.ema_updates, self.last_opt_step = int(ck["updates"]), int(opt["last_opt_step"])
         p.opt_calls = int(f["state"][5]) + int(f["state"][6])
         rt.mark_dirty()
@@ -300,9 +347,8 @@ class DetectionTrainer:
             raise ValueError(f"the training split holds {len(loader.dataset)} images, fewer than one batch of {batch_size}")
         self._epoch_hook = loader.set_epoch
         self.train_loader = loader
-        counts = sorted((len(lb["cls"]) for lb in loader.dataset.labels), reverse=True) or [1]
-        most = sum(counts[:4]) if getattr(loader.dataset, "mosaic", 0.0) else counts[0]  # a mosaic carries four images' boxes
-        self.args.nmax = max(8, (most + 7) // 8 * 8)  # per-image label capacity of the recorded loss kernels
+        # per-image label capacity of the recorded loss kernels: derived from the label table, never below what the user asked for
+        self.args.nmax = max(int(getattr(self.args, "nmax", 0) or 0), self._label_capacity(loader) or 8)
         hist = self.train(loader, batch_size, imgsz, log_every=log_every)  # log_every=1: per-epoch MEAN loss items, as results.csv
         self.metrics = None
         if self.args.val and self.rank == 0:
@@ -327,4 +373,5 @@ class DetectionTrainer:
                     "updates": p.ema_updates, "train_args": vars(self.args), "yaml": self.model.yaml,
                     # what resume needs (reference engine/trainer.py:911 keeps optimizer.state_dict()): the flat optimizer buffers
                     "optimizer": {"mode": p.mode, "param_names": list(rt.param_names), "last_opt_step": self.last_opt_step,
-                                  "flat": {k: v.detach().cpu().clone() for k, v in flat.items()}}}, path)
+                                  "flat": {k: v.detach().cpu().clone() for k, v in flat.items()},
+                                  **({"soap": p.soap_state()} if p.soap else {})}}, path)

@@ -34,7 +34,8 @@ GRAPH_SAFE = os.environ.get(_FLAG) == "0"  # unset + HIP already initialised, or
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DY_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libdealyolo_hip.so"))
 
-DY_EPI_STATS, DY_EPI_BIAS, DY_EPI_SILU, DY_EPI_F32OUT, DY_EPI_ACCUM = 1, 2, 4, 8, 16
+DY_EPI_STATS, DY_EPI_BIAS, DY_EPI_SILU, DY_EPI_F32OUT, DY_EPI_ACCUM, DY_EPI_STATS_ACC = 1, 2, 4, 8, 16, 32
+DY_BN_COPIES = 16  # include/dealyolo_hip.h
 DY_ACT_NONE, DY_ACT_SILU, DY_ACT_LEAKY = 0, 1, 2
 _ERR = {-1: "DY_ERR_ARG (unsupported shape/argument)", -2: "DY_ERR_LAUNCH (HIP launch failed)",
         -3: "DY_ERR_ALIGN (pointer/stride alignment)"}
@@ -82,6 +83,9 @@ SIGNATURES = {
     "dy_bn_finalize": (i32, [vp, i32, f32, vp, i32, f32, vp, i32, f32, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp]),
     "dy_bn_eval_coef": (i32, [vp, vp, vp, vp, vp, i32, f32, vp]),
     "dy_bn_act_apply": (i32, [vp, i32, vp, i32, vp, i32, vp, i64, i32, i32, vp]),
+    "dy_bn_act_apply_acc": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, vp]),
+    "dy_bn_act_bwd_reduce_acc": (i32, [vp, i32, vp, i32, vp, vp, i64, i32, i32, vp]),
+    "dy_bn_act_bwd_apply_acc": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "dy_bn_act_bwd_reduce": (i32, [vp, i32, vp, i32, vp, vp, i32, i64, i32, i32, ip, vp]),
     "dy_bn_bwd_finalize": (i32, [vp, i32, vp, vp, vp, i32, f32, i32, vp]),
     "dy_bn_act_bwd_apply": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, i64, i32, i32, i32, vp]),

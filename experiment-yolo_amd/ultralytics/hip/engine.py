@@ -18,8 +18,8 @@ import os
 import numpy as np
 import torch
 
-from . import (DY_ACT_LEAKY, DY_ACT_NONE, DY_ACT_SILU, DY_EPI_ACCUM, DY_EPI_BIAS, DY_EPI_F32OUT, DY_EPI_SILU,
-               DY_EPI_STATS, check, lib)
+from . import (DY_ACT_LEAKY, DY_ACT_NONE, DY_ACT_SILU, DY_BN_COPIES, DY_EPI_ACCUM, DY_EPI_BIAS, DY_EPI_F32OUT, DY_EPI_SILU,
+               DY_EPI_STATS, DY_EPI_STATS_ACC, check, lib)
 
 BN2D_EPS, BN2D_MOM = 1e-3, 0.03  # reference utils/torch_utils.py:347-349
 BN3D_EPS, BN3D_MOM = 1e-5, 0.1  # nn.BatchNorm3d defaults (ScalSeq), untouched by initialize_weights
@@ -33,6 +33,11 @@ def _ptr(t):
 # 0xFF bytes -- NaN as fp16 / fp32, -1 as an integer -- so that a kernel reading memory nothing wrote shows up as a NaN in
 # the losses / gradients instead of depending on what the caching allocator happened to return.
 POISON = os.environ.get("DY_POISON", "0") == "1"
+
+# BatchNorm statistics without finalize launches (round 3): the conv epilogue / the backward reduce add their per-workgroup sums
+# into fp64 accumulators and the apply kernels sum them in their prologue (csrc/bn_act.hip, BnAccFwd).  DY_BN_ACC=0 restores the
+# three-launch form (partial rows -> dy_bn_finalize -> apply), kept for measurement and for ScalSeq's three-resolution statistics.
+BN_ACC = os.environ.get("DY_BN_ACC", "1") != "0"
 
 
 def dev_empty(shape, dtype, device):
@@ -188,6 +193,7 @@ class ConvSpec:
         self.ld = None  # (N, C_phys, real_cin) for LDConv's (N,1) column conv seen as a 1x1 conv over N*C_phys channels
         self.bn_eps, self.bn_mom = bn_eps, bn_mom
         self.wpack = self.wpack_t = self.coef = self.bwdcoef = None
+        self.acc_f = self.acc_b = None  # fp64 statistic accumulators [DY_BN_COPIES][2][cout] (forward sums, backward sums)
         self.gweight = self.gbias = self.gbn_w = self.gbn_b = None  # fp32 gradient views
 
 
@@ -284,6 +290,34 @@ class Engine:
             t.fill_(0xFF)
         return t
 
+    # ---- fp64 statistic accumulators (BN_ACC): one pool for every BatchNorm of the model, zeroed by ONE launch at the start of a
+    # recorded step (StepPlan) -- or slice by slice before use when a layer is run on its own
+    acc_pool = None
+    acc_used = 0
+    acc_zeroed = False  # True while a trace runs whose launch list began with the pool memset
+
+    def acc_take(self, cout):
+        n = DY_BN_COPIES * 2 * cout
+        if self.acc_pool is None:
+            self.acc_pool = torch.zeros(1 << 20, dtype=torch.float64, device=self.device)  # 8 MB: ~500 layers of 64 channels
+            self.keep.append(self.acc_pool)
+        if self.acc_used + n > self.acc_pool.numel():
+            raise MemoryError("BatchNorm accumulator pool exhausted")
+        v = self.acc_pool[self.acc_used:self.acc_used + n]
+        self.acc_used += n
+        return v
+
+    def zero_acc_pool(self):
+        """Recorded as the first launch of a step: every accumulator of the model back to zero."""
+        if self.acc_pool is not None and self.acc_used:
+            self.call("dy_fill_zero", self.acc_pool.data_ptr(), self.acc_used * 8)
+        self.acc_zeroed = True
+
+    def _acc_ready(self, t):
+        if not self.acc_zeroed:
+            self.call("dy_fill_zero", t.data_ptr(), t.numel() * 8)
+        return t.data_ptr()
+
     arena = None  # set by StepPlan around a trace whose step-local buffers go to a shared Arena
 
     def transient(self, shape, dtype):
@@ -339,6 +373,8 @@ class Engine:
         if spec.bn is not None:
             spec.coef = self.f32(4 * spec.cout)
             spec.bwdcoef = self.f32(2 * spec.cout)
+            if spec.cout % 16 == 0:
+                spec.acc_f, spec.acc_b = self.acc_take(spec.cout), self.acc_take(spec.cout)
         self.keep += [spec.wpack, spec.wpack_t]
 
     def pack(self, spec: ConvSpec, fold_scale=None, transposed=True):
@@ -416,7 +452,15 @@ class Engine:
         assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, spec.cout), (spec.name, (y.N, y.H, y.W, y.C), (x.N, Ho, Wo, spec.cout))
         npix = x.N * Ho * Wo
         bn = spec.bn
-        if self.training:
+        acc = self.training and BN_ACC and spec.acc_f is not None
+        if acc:
+            # statistics through the fp64 accumulator: conv adds, the apply kernel below finishes them in its prologue
+            self._conv_raw(spec, x, raw.ptr, raw.ld, DY_EPI_STATS | DY_EPI_STATS_ACC, self._acc_ready(spec.acc_f))
+            self.call("dy_bn_act_apply_acc", raw.ptr, raw.ld, 0 if res is None else res.ptr, 0 if res is None else res.ld, y.ptr,
+                      y.ld, spec.acc_f.data_ptr(), bn["weight"].data_ptr(), bn["bias"].data_ptr(), bn["running_mean"].data_ptr(),
+                      bn["running_var"].data_ptr(), spec.coef.data_ptr(), npix, spec.cout, spec.act, float(npix), spec.bn_eps,
+                      spec.bn_mom)
+        elif self.training:
             nparts = self.L.dy_conv_num_partials(x.N, x.H, x.W, x.C, spec.cout, spec.ks, spec.stride, 1)
             part = self.scratch("partials", nparts * 2 * ((spec.cout + 15) // 16 * 16) * 4 + 4096)
             self._conv_raw(spec, x, raw.ptr, raw.ld, DY_EPI_STATS, part.data_ptr())
@@ -429,8 +473,9 @@ class Engine:
             self._conv_raw(spec, x, raw.ptr, raw.ld, 0)
             self.call("dy_bn_eval_coef", bn["weight"].data_ptr(), bn["bias"].data_ptr(), bn["running_mean"].data_ptr(),
                       bn["running_var"].data_ptr(), spec.coef.data_ptr(), spec.cout, spec.bn_eps)
-        self.call("dy_bn_act_apply", raw.ptr, raw.ld, 0 if res is None else res.ptr, 0 if res is None else res.ld, y.ptr, y.ld,
-                  spec.coef.data_ptr(), npix, spec.cout, spec.act)
+        if not acc:
+            self.call("dy_bn_act_apply", raw.ptr, raw.ld, 0 if res is None else res.ptr, 0 if res is None else res.ld, y.ptr, y.ld,
+                      spec.coef.data_ptr(), npix, spec.cout, spec.act)
         if self.tape is not None:
             self.tape.append(lambda: self._conv_bn_act_bwd(spec, x, raw, y, res))
         return y
@@ -444,12 +489,17 @@ class Engine:
                 self.call("dy_add", res.gptr, res.ld, y.gptr, y.ld, 0, 0, res.gptr, res.ld, npix, res.C)
             else:
                 self.call("dy_copy_slice", y.gptr, y.ld, res.gptr, res.ld, npix, res.C)
-        part = self.scratch("partials", 2048 * 2 * spec.cout * 4 + 4096)
-        n = C.c_int(0)
-        self.call("dy_bn_act_bwd_reduce", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), part.data_ptr(), 2048, npix,
-                  spec.cout, spec.act, C.byref(n))
-        self.call("dy_bn_bwd_finalize", part.data_ptr(), n.value, spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(),
-                  spec.bwdcoef.data_ptr(), spec.cout, float(npix), 0)
+        acc = BN_ACC and spec.acc_b is not None
+        if acc:
+            self.call("dy_bn_act_bwd_reduce_acc", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), self._acc_ready(spec.acc_b),
+                      npix, spec.cout, spec.act)
+        else:
+            part = self.scratch("partials", 2048 * 2 * spec.cout * 4 + 4096)
+            n = C.c_int(0)
+            self.call("dy_bn_act_bwd_reduce", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), part.data_ptr(), 2048, npix,
+                      spec.cout, spec.act, C.byref(n))
+            self.call("dy_bn_bwd_finalize", part.data_ptr(), n.value, spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(),
+                      spec.bwdcoef.data_ptr(), spec.cout, float(npix), 0)
         if self.side_wgrad and self.deferred_wgrad is not None:
             # the weight gradient reads this buffer on the side stream while the main stream moves on to the next layer:
             # it cannot be the shared scratch
@@ -457,8 +507,12 @@ class Engine:
             self.hold(draw)
         else:
             draw = self.scratch("draw", npix * spec.cout * 2)
-        self.call("dy_bn_act_bwd_apply", y.gptr, y.ld, raw.ptr, raw.ld, draw.data_ptr(), spec.cout, spec.coef.data_ptr(),
-                  spec.bwdcoef.data_ptr(), npix, spec.cout, spec.act, 0)
+        if acc:
+            self.call("dy_bn_act_bwd_apply_acc", y.gptr, y.ld, raw.ptr, raw.ld, draw.data_ptr(), spec.cout, spec.coef.data_ptr(),
+                      spec.acc_b.data_ptr(), spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(), npix, spec.cout, spec.act, float(npix))
+        else:
+            self.call("dy_bn_act_bwd_apply", y.gptr, y.ld, raw.ptr, raw.ld, draw.data_ptr(), spec.cout, spec.coef.data_ptr(),
+                      spec.bwdcoef.data_ptr(), npix, spec.cout, spec.act, 0)
         self._conv_bwd(spec, x, draw.data_ptr(), spec.cout, y.H, y.W)
 
     def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0, defer=True):

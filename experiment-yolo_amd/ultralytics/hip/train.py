@@ -111,6 +111,7 @@ class StepPlan:
         if self.arena is not None:
             self.arena.reset()
         try:
+            eng.zero_acc_pool()
             rt.pack_all(transposed=True)
             x = self.import_input()
             ho = model.forward_act(x)
@@ -126,6 +127,7 @@ class StepPlan:
         finally:
             eng.deferred_wgrad = None
             eng.side_wgrad = False
+            eng.acc_zeroed = False
             eng.arena = None
             rec, eng.rec, eng.tape = eng.rec, None, None
         self.ho = ho
@@ -267,9 +269,6 @@ class StepPlan:
             all_reduce_flat(t, self.world_size)
             rt.flat_b.copy_(t[n:])
 
-    def sync_buffers(self):
-        """Kept for callers of the round-1 API: the buffer exchange now rides on ``all_reduce`` (one collective per step)."""
-
     def accumulate(self):
         """Gradient accumulation across micro-batches (reference engine/trainer.py:812: step only every ``accumulate``
         iterations): fold this micro-step's gradients into the running sum the optimizer will read."""
@@ -286,6 +285,17 @@ class StepPlan:
         """optimizer='SOAP' (reference engine/trainer.py:1156-1165): unscale + global-norm clip like ``optimizer_step`` does, then
         hip/soap.py over views of the flat parameter buffer.  Synchronises (non-finite gradients skip the step, as GradScaler does)."""
         rt = self.rt
+        self._soap_make()
+        g = grads[:rt.n_params_flat]
+        if not bool(torch.isfinite(g).all()):
+            return  # the kernel below sees the same non-finite gradients and counts the skip
+        scale = float(self.state[0])
+        norm = float(g.norm()) / scale
+        coef = min(self._hyp["max_norm"] / (norm + 1e-6), 1.0) / scale
+        self._soap.step([g[o:o + k].view(sh) * coef for _, o, k, sh, _ in self._soap_views], self._hyp["lr"], self._hyp["wd"])
+
+    def _soap_make(self):
+        rt = self.rt
         if getattr(self, "_soap", None) is None:
             from .soap import Soap
             b0, b1 = rt.group_bounds[0], rt.group_bounds[1]
@@ -296,13 +306,42 @@ class StepPlan:
                     views.append((n, o, p.numel(), tuple(p.shape), 0 if o < b0 else (1 if o < b1 else 2)))
             self._soap_views = views
             self._soap = Soap([(rt.flat_p[o:o + k].view(sh), g) for _, o, k, sh, g in views], beta1=self._hyp["momentum"], beta2=0.95)
-        g = grads[:rt.n_params_flat]
-        if not bool(torch.isfinite(g).all()):
-            return  # the kernel below sees the same non-finite gradients and counts the skip
-        scale = float(self.state[0])
-        norm = float(g.norm()) / scale
-        coef = min(self._hyp["max_norm"] / (norm + 1e-6), 1.0) / scale
-        self._soap.step([g[o:o + k].view(sh) * coef for _, o, k, sh, _ in self._soap_views], self._hyp["lr"], self._hyp["wd"])
+            self._soap_apply_pending()
+        return self._soap
+
+    def soap_state(self):
+        """SOAP's per-parameter state (step, moments, Gram matrices, eigenbases) keyed by parameter name, on the host (resume)."""
+        so = getattr(self, "_soap", None)
+        if so is None:
+            return {}
+        out = {}
+        for i, (n, *_r) in enumerate(self._soap_views):
+            st = so.state.get(i)
+            if st is not None:
+                cpu = lambda t: None if t is None else t.detach().cpu().clone()  # noqa: E731
+                out[n] = dict(step=st.step, m=cpu(st.m), v=cpu(st.v), gg=[cpu(t) for t in st.gg], q=None if st.q is None else [cpu(t) for t in st.q])
+        return out
+
+    def load_soap_state(self, saved):
+        """Resume: applied when the optimizer object is built (its betas come from the first ``set_hyper``)."""
+        self._soap_pending = dict(saved)
+        if getattr(self, "_soap", None) is not None:
+            self._soap_apply_pending()
+
+    def _soap_apply_pending(self):
+        saved, self._soap_pending = getattr(self, "_soap_pending", None), None
+        if not saved:
+            return
+        from .soap import _State
+        dev = self.rt.flat_p.device
+        mv = lambda t: None if t is None else t.to(dev)  # noqa: E731
+        for i, (n, o, k, sh, _g) in enumerate(self._soap_views):
+            if n in saved:
+                d = saved[n]
+                st = self._soap.state.get(i) or _State(self.rt.flat_p[o:o + k].view(sh))
+                st.step, st.m, st.v, st.gg = d["step"], mv(d["m"]), mv(d["v"]), [mv(t) for t in d["gg"]]
+                st.q = None if d["q"] is None else [mv(t) for t in d["q"]]
+                self._soap.state[i] = st
 
     def optimizer_step(self):
         rt, eng = self.rt, self.eng
@@ -439,11 +478,13 @@ class StepPlan:
             n, h, w, cout, ld_cin, ld_taps, ld_cphys = args[6:13]
             if L.dy_wgrad_kernel_name(ld_taps * ld_cphys, cout, 1, 1, buf, 128) == 0:
                 return buf.value.decode(), n * h * w * (ld_taps * ld_cphys + (cout + 7) // 8 * 8) * 2
-        tmpl = {"dy_bn_act_apply": ("bn_act_apply_kernel", 9), "dy_bn_act_bwd_reduce": ("bn_act_bwd_reduce_kernel", 9),
-                "dy_bn_act_bwd_apply": ("bn_act_bwd_apply_kernel", 10)}
+        tmpl = {"dy_bn_act_apply": ("bn_act_apply_kernel<{}, false>", 9), "dy_bn_act_apply_acc": ("bn_act_apply_kernel<{}, true>", 14),
+                "dy_bn_act_bwd_reduce": ("bn_act_bwd_reduce_kernel<{}>", 9), "dy_bn_act_bwd_reduce_acc": ("bn_act_bwd_reduce_kernel<{}>", 8),
+                "dy_bn_act_bwd_apply": ("bn_act_bwd_apply_kernel<{}, false>", 10),
+                "dy_bn_act_bwd_apply_acc": ("bn_act_bwd_apply_kernel<{}, true>", 12)}
         if name in tmpl:
             k, i = tmpl[name]
-            return f"{k}<{int(args[i])}>", 0
+            return k.format(int(args[i])), 0
         return name.replace("dy_", "", 1) + " (C-ABI call)", 0
 
     def probe_dominant_kernel(self, batch, reps=10):

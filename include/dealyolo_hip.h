@@ -38,6 +38,10 @@ typedef struct ihipStream_t* hipStream_t;
 #define DY_EPI_SILU 4    /* apply SiLU */
 #define DY_EPI_F32OUT 8  /* y is fp32 (Detect's final 1x1 convs feed the loss in fp32) */
 #define DY_EPI_ACCUM 16  /* y += result (gradient fan-in) */
+#define DY_EPI_STATS_ACC 32 /* with DY_EPI_STATS: `partials` is a double accumulator [DY_BN_COPIES][2][round16(cout)], zeroed by the
+                             * caller, that every workgroup ADDS its sums into (copy = workgroup index % DY_BN_COPIES); consumed by
+                             * dy_bn_act_apply_acc -- no dy_bn_finalize launch */
+#define DY_BN_COPIES 16
 
 #define DY_ACT_NONE 0
 #define DY_ACT_SILU 1
@@ -120,6 +124,18 @@ int dy_bn_eval_coef(const float* gamma, const float* beta, const float* running_
 /* y = act(x*scale+shift) (+ res) */
 int dy_bn_act_apply(const void* x, int ldx, const void* res, int ldr, void* y, int ldy, const float* coef, long npix,
                     int C, int act, hipStream_t stream);
+/* The same three passes WITHOUT the finalize launches (nn/modules/conv.py:49-55 and its autograd backward, as above): the
+ * statistics travel in fp64 accumulators acc[DY_BN_COPIES][2][C] that the producer adds into (dy_conv_forward with
+ * DY_EPI_STATS | DY_EPI_STATS_ACC; dy_bn_act_bwd_reduce_acc) and the consumer sums in its prologue; block 0 of the consumer leaves
+ * coef [4][C] + the running statistics (forward) / dgamma, dbeta (backward) behind.  The caller zeroes acc before the producer. */
+int dy_bn_act_apply_acc(const void* x, int ldx, const void* res, int ldr, void* y, int ldy, const double* acc,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var, float* coef,
+                        long npix, int C, int act, float count, float eps, float momentum, hipStream_t stream);
+int dy_bn_act_bwd_reduce_acc(const void* dy, int lddy, const void* x, int ldx, const float* coef, double* acc, long npix,
+                             int C, int act, hipStream_t stream);
+int dy_bn_act_bwd_apply_acc(const void* dy, int lddy, const void* x, int ldx, void* dx, int lddx, const float* coef,
+                            const double* acc, float* dgamma, float* dbeta, long npix, int C, int act, float count,
+                            hipStream_t stream);
 int dy_bn_act_bwd_reduce(const void* dy, int lddy, const void* x, int ldx, const float* coef, float* partials,
                          int max_partials, long npix, int C, int act, int* nparts, hipStream_t stream);
 /* bwdcoef: [2][C] = mean(g), mean(g*xhat); dgamma/dbeta fp32 (may be NULL) */

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_bench_prints_one_contract_line():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "8", "--imgsz", "320"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "8", "--imgsz", "320", "--lr", "0.0005"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -33,4 +33,22 @@ def test_bench_prints_one_contract_line():
     assert 0 < r["step"]["frac"] < 1 and r["step"]["algorithmic_bytes_per_image"] == 367.1e6
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "images/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
-    assert d["config"]["skipped_steps"] <= 6  # the dynamic loss scale settles within the warm-up + first steps
+    assert d["config"]["skipped_steps"] <= 8 and d["config"]["skipped_in_timed_steps"] == 0  # the loss-scale search ends before the timed steps
+    assert d["config"]["loss_mode"] == "wiou+nwd" and d["config"]["ciou_images_per_s"] > 0 and c["bs16"] > 0
+
+
+def test_bench_gpus_2_from_a_plain_python_start():
+    """`python bench.py --gpus 2` with no launcher around it (what the driver runs on a multi-GPU node): bench.py starts
+    torch.distributed.run itself as a child process before touching the GPU and relays rank 0's line (reference
+    engine/trainer.py:607-627).  Rehearsed here with both ranks on the one GPU over gloo."""
+    env = dict(os.environ, DY_REHEARSE_ON_ONE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
+                        "--imgsz", "320", "--lr", "0.0005", "--no-cpu", "--probe", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["config"]["skipped_in_timed_steps"] == 0

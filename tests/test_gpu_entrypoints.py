@@ -106,6 +106,8 @@ zero = dict(mosaic=0.0, mixup=0.0, copy_paste=0.0, hsv_h=0.0, hsv_s=0.0, hsv_v=0
 model = YOLO('yolov8n-ASF-P2P2.yaml')
 hist = model.train(data={os.path.join(root, 'data.yaml')!r}, cache=False, imgsz=64, epochs=2, batch=4, close_mosaic=10, workers=2,
                    device=DEVICE, optimizer='SGD', project={str(tmp_path / 'runs')!r}, name='exp', val=False, **dict(zero, **EXTRA))
+rm = model.model.state_dict()['model.0.bn.running_mean']  # zero at construction: moved only by training steps
+print('TRAINED', float(rm.abs().sum()) > 0.0, model.trainer is not None)
 print('RESULT', json.dumps([[float(x) for x in h] for h in hist]), getattr(model, 'ddp_result', None) is not None)
 """
     outs = {}
@@ -114,6 +116,9 @@ print('RESULT', json.dumps([[float(x) for x in h] for h in hist]), getattr(model
         assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1]
         outs[dev] = (np.array(eval(line.split(" ", 1)[1].rsplit(" ", 1)[0])), line.endswith("True"), p.stderr)
+        # whichever way the run was launched, the caller's model object holds TRAINED weights afterwards (after the re-launch: rank
+        # 0's checkpoint loaded back, reference engine/model.py:612-616) -- m.val() / m.predict() never see the untouched copy
+        assert [l for l in p.stdout.splitlines() if l.startswith("TRAINED")][-1].split()[1] == "True", p.stdout[-2000:]
     single, ddp = outs["'0'"], outs["'0,1'"]
     assert single[0].shape == (2, 3) and np.isfinite(single[0]).all() and not single[1]
     assert ddp[1], "device='0,1' must have gone through the torch.distributed.run re-launch"

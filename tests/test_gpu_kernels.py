@@ -145,6 +145,76 @@ def test_bn_act_forward_backward(C_, act):
     assert relerr(dx.float().permute(0, 3, 1, 2), xr.grad) < 3e-3
 
 
+@pytest.mark.parametrize("cin,cout,ks,s,H,W,act", [(16, 32, 3, 1, 37, 45, 1), (64, 64, 3, 1, 40, 40, 1), (48, 32, 1, 1, 33, 29, 1),
+                                                    (32, 64, 3, 2, 26, 34, 1), (128, 128, 1, 1, 20, 20, 2), (16, 16, 3, 1, 80, 80, 0)])
+def test_bn_accumulator_path_equals_finalize_path(cin, cout, ks, s, H, W, act):
+    """Round 3: statistics through fp64 accumulators (conv epilogue / backward reduce add, the apply kernels finish them in their
+    prologue; no finalize launches) against the three-launch form on the same data: coefficients, running statistics, outputs,
+    parameter gradients and dX must agree to fp32 rounding of the final division (the sums are the same fp32 partials added in
+    fp64 in another order)."""
+    from ultralytics.hip import DY_BN_COPIES
+    torch.manual_seed(cin + cout + ks + act)
+    eng = _eng()
+    N = 4
+    x = h16(torch.randn(N, cin, H, W))
+    w = h16(torch.randn(cout, cin, ks, ks) / (cin * ks * ks) ** 0.5)
+    sp = _spec(eng, w, None, ks, s)
+    xa = _act(eng, x)
+    Ho, Wo = eng.out_hw(sp, xa)
+    npix = N * Ho * Wo
+    gamma, beta = (torch.rand(cout) + 0.5).cuda(), (torch.randn(cout) * 0.2).cuda()
+    dy = _act(eng, h16(torch.randn(N, cout, Ho, Wo)))
+
+    def fwd_bwd(acc):
+        rm, rv = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
+        coef = torch.zeros(4 * cout, device="cuda")
+        raw = torch.zeros(N, Ho, Wo, cout, dtype=torch.float16, device="cuda")
+        y = torch.zeros_like(raw)
+        dx = torch.zeros_like(raw)
+        dg, db = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda")
+        if acc:
+            af = torch.zeros(DY_BN_COPIES * 2 * cout, dtype=torch.float64, device="cuda")
+            ab = torch.zeros_like(af)
+            eng.call("dy_conv_forward", xa.ptr, xa.ld, sp.wpack.data_ptr(), 0, raw.data_ptr(), cout, af.data_ptr(), N, H, W, xa.C,
+                     cout, ks, s, 1, 0, 0, 1 | 32, None)
+            eng.call("dy_bn_act_apply_acc", raw.data_ptr(), cout, 0, 0, y.data_ptr(), cout, af.data_ptr(), gamma.data_ptr(),
+                     beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), coef.data_ptr(), npix, cout, act, float(npix), 1e-3, 0.03)
+            eng.call("dy_bn_act_bwd_reduce_acc", dy.ptr, dy.ld, raw.data_ptr(), cout, coef.data_ptr(), ab.data_ptr(), npix, cout, act)
+            eng.call("dy_bn_act_bwd_apply_acc", dy.ptr, dy.ld, raw.data_ptr(), cout, dx.data_ptr(), cout, coef.data_ptr(),
+                     ab.data_ptr(), dg.data_ptr(), db.data_ptr(), npix, cout, act, float(npix))
+        else:
+            nparts = eng.L.dy_conv_num_partials(N, H, W, xa.C, cout, ks, s, 1)
+            part = torch.zeros(nparts, 2, cout, device="cuda")
+            eng.call("dy_conv_forward", xa.ptr, xa.ld, sp.wpack.data_ptr(), 0, raw.data_ptr(), cout, part.data_ptr(), N, H, W, xa.C,
+                     cout, ks, s, 1, 0, 0, 1, None)
+            eng.call("dy_bn_finalize", part.data_ptr(), nparts, 1.0, 0, 0, 0.0, 0, 0, 0.0, gamma.data_ptr(), beta.data_ptr(),
+                     rm.data_ptr(), rv.data_ptr(), coef.data_ptr(), cout, float(npix), 1e-3, 0.03, 1)
+            eng.call("dy_bn_act_apply", raw.data_ptr(), cout, 0, 0, y.data_ptr(), cout, coef.data_ptr(), npix, cout, act)
+            parts = torch.zeros(2048 * 2 * cout, device="cuda")
+            n = C.c_int(0)
+            eng.call("dy_bn_act_bwd_reduce", dy.ptr, dy.ld, raw.data_ptr(), cout, coef.data_ptr(), parts.data_ptr(), 2048, npix, cout,
+                     act, C.byref(n))
+            bwd = torch.zeros(2 * cout, device="cuda")
+            eng.call("dy_bn_bwd_finalize", parts.data_ptr(), n.value, dg.data_ptr(), db.data_ptr(), bwd.data_ptr(), cout, float(npix), 0)
+            eng.call("dy_bn_act_bwd_apply", dy.ptr, dy.ld, raw.data_ptr(), cout, dx.data_ptr(), cout, coef.data_ptr(), bwd.data_ptr(),
+                     npix, cout, act, 0)
+        torch.cuda.synchronize()
+        return dict(coef=coef, rm=rm, rv=rv, raw=raw, y=y, dx=dx, dg=dg, db=db)
+
+    a, b = fwd_bwd(True), fwd_bwd(False)
+    assert torch.equal(a["raw"], b["raw"])
+    for k in ("coef", "rm", "rv", "dg", "db"):
+        assert relerr(a[k], b[k]) < 2e-6, k
+    # fp16 outputs: identical except where a last-bit difference of a coefficient crosses an fp16 rounding boundary
+    for k in ("y", "dx"):
+        d = (a[k].float() - b[k].float()).abs()
+        assert float((d > 0).float().mean()) < 1e-3 and relerr(a[k].float(), b[k].float()) < 1e-3, k
+    # and the accumulator path repeats bit for bit (fp32 partials added in fp64: the order of the atomics does not show)
+    a2 = fwd_bwd(True)
+    for k in a:
+        assert torch.equal(a[k], a2[k]), k
+
+
 def test_pool_upsample_add():
     torch.manual_seed(5)
     eng = _eng()

@@ -45,12 +45,21 @@ for name, a, ms in prof:
     elif name in ("dy_bn_act_apply",):
         d = f"npix={a[7]} C={a[8]}"
         by = a[7] * a[8] * 2 * 2
+    elif name == "dy_bn_act_apply_acc":
+        d = f"npix={a[12]} C={a[13]}"
+        by = a[12] * a[13] * 2 * 2
     elif name == "dy_bn_act_bwd_apply":
         d = f"npix={a[8]} C={a[9]}"
         by = a[8] * a[9] * 2 * 3
+    elif name == "dy_bn_act_bwd_apply_acc":
+        d = f"npix={a[10]} C={a[11]}"
+        by = a[10] * a[11] * 2 * 3
     elif name == "dy_bn_act_bwd_reduce":
         d = f"npix={a[7]} C={a[8]}"
         by = a[7] * a[8] * 2 * 2
+    elif name == "dy_bn_act_bwd_reduce_acc":
+        d = f"npix={a[6]} C={a[7]}"
+        by = a[6] * a[7] * 2 * 2
     else:
         d, by = "", 0
     rows.append((ms, name, d, by))
