@@ -94,25 +94,6 @@ extern "C" int dy_bn_eval_coef(const float* gamma, const float* beta, const floa
   return DY_OK;
 }
 
-// compile-time activation: one instantiation per activation instead of a per-element branch; sigmoid through v_exp + v_rcp
-template <int ACT>
-static __device__ __forceinline__ float act_fwd_t(float z) {
-  // forward keeps the correctly rounded division: the 1-ulp v_rcp_f32 variant is as accurate for any single value, but the
-  // perturbation it puts on every activation was enough to flip a task-aligned top-10 choice in the 64x64 golden case
-  // (first-layer gradient 3.7e-2 -> 1.3e-1 off the reference); the backward factor below may use v_rcp_f32
-  if (ACT == DY_ACT_SILU) return z / (1.f + __expf(-z));
-  if (ACT == DY_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
-  return z;
-}
-template <int ACT>
-static __device__ __forceinline__ float act_grad_t(float z) {
-  if (ACT == DY_ACT_SILU) {
-    const float s = __builtin_amdgcn_rcpf(1.f + __expf(-z));
-    return s * (1.f + z * (1.f - s));
-  }
-  if (ACT == DY_ACT_LEAKY) return z > 0.f ? 1.f : 0.1f;
-  return 1.f;
-}
 #define DY_ACT_DISPATCH(KERNEL, grid, stream, args)                                                        \
   do {                                                                                                     \
     if (act == DY_ACT_SILU) hipLaunchKernelGGL(KERNEL<DY_ACT_SILU>, grid, dim3(256), 0, stream, args);      \
@@ -162,7 +143,7 @@ struct BnAccFwd {
   float count, eps, momentum;
 };
 
-template <int ACT, bool ACC>
+template <int ACT, bool ACC, bool FAST = false>
 __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a, BnAccFwd b) {
   // a thread owns one 8-channel granule for the whole launch: scale/shift live in registers
   const int cpp = a.C >> 3, rows = 256 / cpp;
@@ -208,11 +189,23 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a, BnAccFwd
     half8 rv;
     if (a.res) rv = *reinterpret_cast<const half8*>(a.res + pix * a.ldr + c0);
     half8 out;
+    if (FAST) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float z = act_fwd_t<ACT>((float)xv[j] * sc[j] + sh[j]);
-      if (a.res) z += (float)rv[j];
-      out[j] = (f16)z;
+      for (int j = 0; j < 8; j += 2) {
+        f32x2 z = act_fwd2_fast<ACT>(__builtin_elementwise_fma((f32x2){(float)xv[j], (float)xv[j + 1]}, (f32x2){sc[j], sc[j + 1]},
+                                                               (f32x2){sh[j], sh[j + 1]}));
+        if (a.res) z += (f32x2){(float)rv[j], (float)rv[j + 1]};
+        const half2_ oh = __builtin_convertvector(z, half2_);
+        out[j] = oh[0];
+        out[j + 1] = oh[1];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float z = act_fwd_t<ACT>((float)xv[j] * sc[j] + sh[j]);
+        if (a.res) z += (float)rv[j];
+        out[j] = (f16)z;
+      }
     }
     *reinterpret_cast<half8*>(a.y + pix * a.ldy + c0) = out;
   };
@@ -274,11 +267,15 @@ extern "C" int dy_bn_act_apply_acc(const void* x, int ldx, const void* res, int 
   const int rev = ew_reverse();
   ApplyArgs a{(const f16*)x, (const f16*)res, (f16*)y, nullptr, ldx, ldr, ldy, C, act, npix, rev & 1};
   const BnAccFwd b{acc, gamma, beta, running_mean, running_var, coef, count, eps, momentum};
-  // every block pays the prologue (DY_BN_COPIES x 2 x C doubles from L2 + one fp64 sqrt/divide per channel), so fewer, longer
-  // blocks than the coefficient-table form
-  const dim3 grid(ew_blocks(npix, C, "DY_EW_BLOCKS_APPLY_ACC", 4096));
+  // every block pays the prologue (DY_BN_COPIES x 2 x C doubles from L2 + one fp64 sqrt/divide per channel); measured on one box
+  // (round 3, alternating): caps 2048 / 4096 / 8192 -> 13.49 / 13.51 / 13.47 ms per step, i.e. no preference: same cap as before
+  const dim3 grid(ew_blocks(npix, C, "DY_EW_BLOCKS_APPLY_ACC", 8192));
   const size_t lds = 2 * (size_t)C * sizeof(float);
-  if (act == DY_ACT_SILU) hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_SILU, true>), grid, dim3(256), lds, stream, a, b);
+  // SiLU's division written out in packed fp32 (common.h, act_fwd2_fast: Markstein's sequence, the correctly rounded quotient on
+  // this range): 13.00 -> 12.87 ms per step on one box, all parity tests unchanged.  DY_SILU_FAST=0: the compiler's division.
+  static const bool fast = !getenv("DY_SILU_FAST") || atoi(getenv("DY_SILU_FAST"));
+  if (act == DY_ACT_SILU && fast) hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_SILU, true, true>), grid, dim3(256), lds, stream, a, b);
+  else if (act == DY_ACT_SILU) hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_SILU, true>), grid, dim3(256), lds, stream, a, b);
   else if (act == DY_ACT_LEAKY) hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_LEAKY, true>), grid, dim3(256), lds, stream, a, b);
   else hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_NONE, true>), grid, dim3(256), lds, stream, a, b);
   DY_CHECK_LAUNCH();
@@ -304,52 +301,56 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
   const int part = tid % cpp, row = tid / cpp, c0 = part * 8;
   // The loop accumulates sum(g) and sum(g * x) on the RAW values; sum(g * xhat) = invstd * (sum(g * x) - mean * sum(g)) is formed
   // once per thread afterwards.  (Keeping mean / invstd out of the loop takes 16 registers and two VALU operations per element off a
-  // kernel that sits at the VALU / memory balance point: exp + rcp per element.)
-  float sg[8], sgx[8], sc[8], sh[8];
+  // kernel that sits at the VALU / memory balance point: exp + rcp per element.)  Channel pairs: packed fp32 arithmetic.
+  f32x2 sg[4], sgx[4], sc[4], sh[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    sg[j] = sgx[j] = 0.f;
-    sc[j] = a.coef[c0 + j];
-    sh[j] = a.coef[a.C + c0 + j];
+  for (int j = 0; j < 4; ++j) {
+    sg[j] = sgx[j] = (f32x2){0.f, 0.f};
+    sc[j] = (f32x2){a.coef[c0 + 2 * j], a.coef[c0 + 2 * j + 1]};
+    sh[j] = (f32x2){a.coef[a.C + c0 + 2 * j], a.coef[a.C + c0 + 2 * j + 1]};
   }
   if (row < rows) {
     // two pixels per trip: four 16-byte loads in flight per lane before the first use
     const long step = (long)gridDim.x * rows;
     long pix = (long)blockIdx.x * rows + row;
     auto at = [&](long p) { return a.rev ? a.npix - 1 - p : p; };
+    auto pair = [](const half8& v, int j) { return (f32x2){(float)v[2 * j], (float)v[2 * j + 1]}; };
     for (; pix + step < a.npix; pix += 2 * step) {
       const half8 dv0 = *reinterpret_cast<const half8*>(a.dy + at(pix) * a.lddy + c0);
       const half8 xv0 = *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0);
       const half8 dv1 = *reinterpret_cast<const half8*>(a.dy + at(pix + step) * a.lddy + c0);
       const half8 xv1 = *reinterpret_cast<const half8*>(a.x + at(pix + step) * a.ldx + c0);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x0 = (float)xv0[j], x1 = (float)xv1[j];
-        const float g0 = (float)dv0[j] * act_grad_t<ACT>(x0 * sc[j] + sh[j]);
-        const float g1 = (float)dv1[j] * act_grad_t<ACT>(x1 * sc[j] + sh[j]);
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 x0 = pair(xv0, j), x1 = pair(xv1, j);
+        const f32x2 g0 = pair(dv0, j) * act_grad2<ACT>(__builtin_elementwise_fma(x0, sc[j], sh[j]));
+        const f32x2 g1 = pair(dv1, j) * act_grad2<ACT>(__builtin_elementwise_fma(x1, sc[j], sh[j]));
         sg[j] += g0 + g1;
-        sgx[j] += g0 * x0 + g1 * x1;
+        sgx[j] += __builtin_elementwise_fma(g0, x0, g1 * x1);
       }
     }
     if (pix < a.npix) {
       const half8 dv = *reinterpret_cast<const half8*>(a.dy + at(pix) * a.lddy + c0);
       const half8 xv = *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xf = (float)xv[j];
-        const float g = (float)dv[j] * act_grad_t<ACT>(xf * sc[j] + sh[j]);
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 x = pair(xv, j);
+        const f32x2 g = pair(dv, j) * act_grad2<ACT>(__builtin_elementwise_fma(x, sc[j], sh[j]));
         sg[j] += g;
-        sgx[j] += g * xf;
+        sgx[j] += g * x;
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sgx[j] = (sgx[j] - a.coef[2 * a.C + c0 + j] * sg[j]) * a.coef[3 * a.C + c0 + j];
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        sgx[j][k] = (sgx[j][k] - a.coef[2 * a.C + c0 + 2 * j + k] * sg[j][k]) * a.coef[3 * a.C + c0 + 2 * j + k];
   }
   __shared__ float red[2][256][8 + 1];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    red[0][tid][j] = sg[j];
-    red[1][tid][j] = sgx[j];
+    red[0][tid][j] = sg[j >> 1][j & 1];
+    red[1][tid][j] = sgx[j >> 1][j & 1];
   }
   __syncthreads();
   for (int i = tid; i < 2 * a.C; i += 256) {
@@ -492,14 +493,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BwdApplyArgs a) {
   auto at = [&](long p) { return a.rev ? a.npix - 1 - p : p; };
   auto one = [&](long pix, const half8& dv, const half8& xv) {
     pix = at(pix);
-    half8 out;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xf = (float)xv[j];
-      const float g = (float)dv[j] * act_grad_t<ACT>(xf * sc[j] + sh[j]);
-      out[j] = (f16)(sc[j] * g - (kb[j] * xf + kc[j]));
-    }
-    *reinterpret_cast<half8*>(a.dx + pix * a.lddx + c0) = out;
+    *reinterpret_cast<half8*>(a.dx + pix * a.lddx + c0) = bn_bwd_apply8<ACT>(dv, xv, sc, sh, kb, kc);
   };
   const long step = (long)gridDim.x * rows;
   long pix = (long)blockIdx.x * rows + row;

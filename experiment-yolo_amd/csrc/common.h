@@ -38,6 +38,78 @@ static __device__ __forceinline__ float quad16_sum(float v) {
 static __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
 static __device__ __forceinline__ float sigmoid_f(float z) { return 1.f / (1.f + __expf(-z)); }
 
+// ---- BatchNorm + activation element math shared by the element-wise kernels (bn_act.hip) and the kernels that apply it while
+// staging (conv_wgrad.hip): one definition, so a fused pass produces the bits of the stand-alone pass.
+#ifndef DY_ACT_SILU
+#define DY_ACT_NONE 0
+#define DY_ACT_SILU 1
+#define DY_ACT_LEAKY 2
+#endif
+template <int ACT>
+static __device__ __forceinline__ float act_fwd_t(float z) {
+  // forward keeps the correctly rounded division: the 1-ulp v_rcp_f32 variant is as accurate for any single value, but the
+  // perturbation it puts on every activation was enough to flip a task-aligned top-10 choice in the 64x64 golden case
+  // (first-layer gradient 3.7e-2 -> 1.3e-1 off the reference); the backward factor below may use v_rcp_f32
+  if (ACT == DY_ACT_SILU) return z / (1.f + __expf(-z));
+  if (ACT == DY_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
+  return z;
+}
+// forward activation of a PAIR of values with the division written out: q = z / den through v_rcp + one Newton step on the
+// reciprocal + one residual correction of the quotient (Markstein's sequence: the correctly rounded quotient whenever nothing
+// over- or underflows on the way -- den is in [1, 2^126], so nothing does), all in packed fp32; the compiler's own division adds
+// v_div_scale / v_div_fmas / v_div_fixup for ranges that cannot occur here.  Same bits as act_fwd_t for the values that matter,
+// about half the instructions.  The forward apply pass of the accumulator path uses it (DY_SILU_FAST=0 switches back).
+template <int ACT>
+static __device__ __forceinline__ f32x2 act_fwd2_fast(f32x2 z) {
+  if (ACT == DY_ACT_SILU) {
+    f32x2 t = z * (f32x2){-1.4426950408889634f, -1.4426950408889634f};
+    t = (f32x2){fminf(t[0], 126.f), fminf(t[1], 126.f)};  // exp2 stays finite: den = inf would turn the Newton step into 0 * inf
+    const f32x2 one = {1.f, 1.f};
+    const f32x2 den = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + one;
+    f32x2 r = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    r = __builtin_elementwise_fma(__builtin_elementwise_fma(-den, r, one), r, r);
+    const f32x2 q = z * r;
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(-den, q, z), r, q);
+  }
+  if (ACT == DY_ACT_LEAKY) return (f32x2){z[0] > 0.f ? z[0] : 0.1f * z[0], z[1] > 0.f ? z[1] : 0.1f * z[1]};
+  return z;
+}
+// d act / dz for a PAIR of values: everything except v_exp / v_rcp is a 2-wide packed fp32 instruction (v_pk_fma_f32 ...), which
+// is what makes the BatchNorm backward cheap enough to run inside a staging loop.  sigmoid' form: s + z*s*(1-s), s*(1-s) = s - s^2.
+template <int ACT>
+static __device__ __forceinline__ f32x2 act_grad2(f32x2 z) {
+  if (ACT == DY_ACT_SILU) {
+    const f32x2 t = z * (f32x2){-1.4426950408889634f, -1.4426950408889634f};
+    const f32x2 den = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + (f32x2){1.f, 1.f};
+    const f32x2 s = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const f32x2 q = __builtin_elementwise_fma(-s, s, s);
+    return __builtin_elementwise_fma(z, q, s);
+  }
+  if (ACT == DY_ACT_LEAKY) return (f32x2){z[0] > 0.f ? 1.f : 0.1f, z[1] > 0.f ? 1.f : 0.1f};
+  return (f32x2){1.f, 1.f};
+}
+template <int ACT>
+static __device__ __forceinline__ float act_grad_t(float z) {
+  return act_grad2<ACT>((f32x2){z, z})[0];
+}
+// d(raw conv output) of one 8-channel granule: dx = sc*g - (kb*x + kc), g = dy * act'(x*sc + sh)   (bn_act_bwd_apply_kernel)
+template <int ACT>
+static __device__ __forceinline__ half8 bn_bwd_apply8(const half8& dv, const half8& xv, const float* sc, const float* sh,
+                                                      const float* kb, const float* kc) {
+  half8 out;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const f32x2 x = {(float)xv[j], (float)xv[j + 1]}, d = {(float)dv[j], (float)dv[j + 1]};
+    const f32x2 s2 = {sc[j], sc[j + 1]}, h2 = {sh[j], sh[j + 1]}, b2 = {kb[j], kb[j + 1]}, c2 = {kc[j], kc[j + 1]};
+    const f32x2 ad = act_grad2<ACT>(__builtin_elementwise_fma(x, s2, h2));
+    const f32x2 o = __builtin_elementwise_fma(s2 * ad, d, -__builtin_elementwise_fma(b2, x, c2));
+    const half2_ oh = __builtin_convertvector(o, half2_);
+    out[j] = oh[0];
+    out[j + 1] = oh[1];
+  }
+  return out;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 #define DY_CHECK_LAUNCH()                                  \

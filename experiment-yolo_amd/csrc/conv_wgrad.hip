@@ -10,6 +10,7 @@
 #include "dealyolo_hip.h"
 
 typedef short short4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct WgArgs {
   const f16* x;
@@ -22,6 +23,16 @@ struct WgArgs {
   int nci_chunks;     // blockIdx.y = co_chunk * nci_chunks + ci_chunk
   int tiles_x, tiles_y, ntiles;
   long npix;  // FLAT only
+  // BNF kernels: dy is the gradient w.r.t. the ACTIVATED output; the kernel forms d(raw conv output) itself while staging
+  // (BatchNorm + activation backward, bn_act.hip's apply pass) and writes it to draw for the input-gradient pass that follows
+  const f16* raw;       // (N,Ho,Wo,ldraw) raw conv output of the forward pass
+  f16* draw;            // (N,Ho,Wo,ldraw) out: d(raw)
+  const float* coef;    // [4][cout]: scale, shift, mean, invstd
+  const double* acc;    // [DY_BN_COPIES][2][cout] sums of g and g*xhat (dy_bn_act_bwd_reduce_acc)
+  float* dgamma;
+  float* dbeta;
+  int ldraw, cout;
+  float count;
 };
 
 static __device__ __forceinline__ half8 tr_frag(const char* base0, const char* base1) {
@@ -42,13 +53,13 @@ static constexpr __host__ __device__ int wg_th(int ks, int stride, int nci, int 
   return (nci * mtc <= 1) ? 8 : ((nci + mtc <= 4) ? 4 : 2);
 }
 
-template <int KS, int STRIDE, int NCI, int MTC>
+template <int KS, int STRIDE, int NCI, int MTC, int BNF>
 // (256, 2): two workgroups per CU.  Without the second argument hipcc budgets 512 registers per lane (it put the 36 accumulator
 // tiles of the 64x64 3x3 case into AGPRs: 234 + 188), which leaves ONE workgroup per CU whose four waves stage, wait and
 // multiply in lock-step -- 29 % MFMA utilisation.  With two resident workgroups one stages while the other multiplies.
 // (The 64x64-channel 3x3 case needs 144 accumulator registers and cannot: it keeps one workgroup per CU; splitting its input
 // channels over two workgroups to fit was measured slower, 258 vs 224 us.)
-__global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void conv_wgrad_kernel(WgArgs a) {
+__global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void conv_wgrad_kernel(const WgArgs a) {
   constexpr bool FLAT = (KS == 1);
   constexpr int TAPS = KS * KS;
   constexpr int NCOL = NCI * TAPS;          // (ci tile, tap) columns of this workgroup
@@ -69,6 +80,7 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
   __shared__ __attribute__((aligned(16))) char smem[XBYTES + YBYTES];
   char* const sx = smem;
   char* const sy = smem + XBYTES;
+  __shared__ __attribute__((aligned(16))) float sbn[BNF ? 4 * COUT_C : 4];  // BNF: [sc | sh | kb | kc] of this cout chunk
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
   const int qq = p >> 2, pp = p & 3;  // address-supplier role inside the 16-lane group
@@ -86,6 +98,12 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
   constexpr int NGX = HHX * HWX * (CIN_C / 8), NGY = TH * TW * (COUT_C / 8);
   constexpr int NPX = (NGX + 255) / 256, NPY = (NGY + 255) / 256;
   uint4 pfx[NPX], pfy[NPY];
+  uint4 pfr[BNF ? NPY : 1];     // BNF: raw conv output granules beside the dy granules
+  unsigned roff[BNF ? NPY : 1]; // their byte offsets in the (raw / draw) geometry
+  int ncur = 0, nnext = 0;  // BNF, 3x3: image index of the staged / prefetched tile (the draw store needs its descriptor)
+  (void)ncur; (void)nnext;
+  unsigned vnext = 0, vcur = 0, ornext = 0, orcur = 0;  // BNF: validity bits + (raw / draw) tile-origin offset of the prefetched / staged tile
+  (void)pfr; (void)roff; (void)vnext; (void)vcur; (void)ornext; (void)orcur;
   // tile-invariant byte offset of each of this thread's granules from the tile origin (NEVER = granule does not exist:
   // the buffer range check answers it with zeros, as it does for rows above/below the image and pixels past the end)
   constexpr unsigned NEVER = 0x80000000u;
@@ -106,6 +124,38 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
     const bool ok = id < NGY && co0 + part * 8 < a.cout_r8;
     const int ty = FLAT ? 0 : pixel / TW, tx = FLAT ? pixel : pixel - ty * TW;
     yoff[i] = ok ? (unsigned)(((ty * a.Wo + tx) * a.lddy + co0 + part * 8) * 2) : NEVER;
+    if (BNF) roff[i] = ok ? (unsigned)(((ty * a.Wo + tx) * a.ldraw + co0 + part * 8) * 2) : NEVER;
+  }
+  if (BNF) {
+    // BatchNorm backward coefficients of this cout chunk from the reduce pass's fp64 sums (what bn_act_bwd_apply_kernel<.., true>
+    // does in its prologue): dx = sc*g - (kb*x + kc), kb = sc*invstd*mean(g*xhat), kc = sc*mean(g) - kb*mean
+    for (int c = tid; c < COUT_C; c += 256) {
+      const int ch = co0 + c;
+      float sc = 0.f, sh = 0.f, kb = 0.f, kc = 0.f;
+      if (ch < a.cout) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DY_BN_COPIES; ++k) {
+          s1 += a.acc[(size_t)(k * 2 + 0) * a.cout + ch];
+          s2 += a.acc[(size_t)(k * 2 + 1) * a.cout + ch];
+        }
+        const float mg = (float)(s1 / a.count), mgx = (float)(s2 / a.count);
+        sc = a.coef[ch];
+        sh = a.coef[a.cout + ch];
+        const float mean = a.coef[2 * a.cout + ch], inv = a.coef[3 * a.cout + ch];
+        kb = sc * inv * mgx;
+        kc = sc * mg - kb * mean;
+        if (blockIdx.x == 0 && ci_chunk == 0) {
+          if (a.dbeta) a.dbeta[ch] = (float)s1;
+          if (a.dgamma) a.dgamma[ch] = (float)s2;
+        }
+      }
+      sbn[c] = sc;
+      sbn[COUT_C + c] = sh;
+      sbn[2 * COUT_C + c] = kb;
+      sbn[3 * COUT_C + c] = kc;
+    }
+    __syncthreads();
   }
   auto ld16 = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
     const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
@@ -120,6 +170,18 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
       for (int i = 0; i < NPX; ++i) pfx[i] = ld16(rx, xoff[i] + ox);
 #pragma unroll
       for (int i = 0; i < NPY; ++i) pfy[i] = ld16(ry, yoff[i] + oy);
+      if (BNF) {
+        const unsigned nbytes = (unsigned)a.npix * (unsigned)a.ldraw * 2u;
+        const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.raw), 0, (int)nbytes, 0x00020000);
+        ornext = (unsigned)tile * (TH * TW) * a.ldraw * 2u;
+        vnext = 0;
+#pragma unroll
+        for (int i = 0; i < NPY; ++i) {
+          const unsigned off = roff[i] + ornext;
+          pfr[i] = ld16(rr, off);
+          vnext |= (roff[i] != NEVER && off < nbytes) ? (1u << i) : 0u;
+        }
+      }
     } else {
       const int bx = tile % a.tiles_x;
       const int t2 = tile / a.tiles_x;
@@ -149,10 +211,32 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
           pfy[i] = ld16(ry, ox0 + tx < a.Wo ? yoff[i] + oy : NEVER);
         }
       }
+      if (BNF) {
+        const unsigned nbytes = (unsigned)(a.Ho * a.Wo * a.ldraw * 2);
+        const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.raw) + (size_t)n * a.Ho * a.Wo * a.ldraw, 0, (int)nbytes, 0x00020000);
+        ornext = (unsigned)((oy0 * a.Wo + ox0) * a.ldraw * 2);
+        vnext = 0;
+        const bool xfull = ox0 + TW <= a.Wo;
+#pragma unroll
+        for (int i = 0; i < NPY; ++i) {
+          unsigned off = roff[i] == NEVER ? NEVER : roff[i] + ornext;
+          if (!xfull) {
+            const int tx = ((tid + i * 256) / CPGY) % TW;
+            off = ox0 + tx < a.Wo ? off : NEVER;
+          }
+          pfr[i] = ld16(rr, off);
+          vnext |= off < nbytes ? (1u << i) : 0u;
+        }
+        nnext = n;
+      }
     }
   };
 
-  int tile = blockIdx.x;
+
+  // Workgroups are dealt round-robin to the 8 XCDs (one L2 each): with tile = blockIdx.x + k * gridDim.x the vertical neighbours of
+  // a 3x3 tile sit on other XCDs and every halo row of X is fetched into two L2s.  Giving XCD x the x-th eighth of each period's
+  // tiles keeps them together (the map of conv.hip's ping-pong kernel).
+  int tile = (!FLAT && !(gridDim.x & 7)) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (tile < a.ntiles) prefetch(tile);
   for (; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();  // previous tile's fragment reads are done
@@ -161,10 +245,32 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
       const int id = tid + i * 256;
       if (id < NGX) *reinterpret_cast<uint4*>(sx + (id / (CIN_C / 8)) * PSX + (id % (CIN_C / 8)) * 16) = pfx[i];
     }
+    if (BNF) {
+      vcur = vnext; orcur = ornext; ncur = nnext;
+      // d(raw) = BatchNorm + SiLU backward of (dy, raw), formed here in registers: it becomes the A operand in LDS and -- from the
+      // workgroups of Cin chunk 0 -- the tensor the input-gradient pass reads.  Granules the range check zeroed (outside the image,
+      // past the last pixel, absent channels) must stay zero: with dy = raw = 0 the formula gives -kc, not 0.
+      const unsigned nbytes = FLAT ? (unsigned)a.npix * (unsigned)a.ldraw * 2u : (unsigned)(a.Ho * a.Wo * a.ldraw * 2);
+      const auto rd = __builtin_amdgcn_make_buffer_rsrc(FLAT ? a.draw : a.draw + (size_t)ncur * a.Ho * a.Wo * a.ldraw, 0, (int)nbytes, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < NPY; ++i) {
-      const int id = tid + i * 256;
-      if (id < NGY) *reinterpret_cast<uint4*>(sy + (id / (COUT_C / 8)) * PSY + (id % (COUT_C / 8)) * 16) = pfy[i];
+      for (int i = 0; i < NPY; ++i) {
+        const int id = tid + i * 256;
+        const int part = id % CPGY;
+        const bool valid = (vcur >> i) & 1u;
+        const float* cf = sbn + part * 8;
+        union { half8 h; uint4 u; u32x4 v; } o;
+        o.h = bn_bwd_apply8<DY_ACT_SILU>(*reinterpret_cast<const half8*>(&pfy[i]), *reinterpret_cast<const half8*>(&pfr[i]), cf,
+                                         cf + COUT_C, cf + 2 * COUT_C, cf + 3 * COUT_C);
+        if (!valid) o.u = make_uint4(0, 0, 0, 0);
+        if (id < NGY) *reinterpret_cast<uint4*>(sy + (id / (COUT_C / 8)) * PSY + (id % (COUT_C / 8)) * 16) = o.u;
+        if (ci_chunk == 0 && a.draw) __builtin_amdgcn_raw_buffer_store_b128(o.v, rd, (int)(valid ? roff[i] + orcur : NEVER), 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPY; ++i) {
+        const int id = tid + i * 256;
+        if (id < NGY) *reinterpret_cast<uint4*>(sy + (id / (COUT_C / 8)) * PSY + (id % (COUT_C / 8)) * 16) = pfy[i];
+      }
     }
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
@@ -328,7 +434,8 @@ extern "C" int dy_wgrad_reduce_batched(const void* descs_device, int n, int tota
 
 template <int KS, int STRIDE, int NCI, int MTC>
 static int launch_wgrad(const WgArgs& a, int gx, int gy, hipStream_t s) {
-  hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC>), dim3(gx, gy), dim3(256), 0, s, a);
+  if (a.raw) hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC, 1>), dim3(gx, gy), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC, 0>), dim3(gx, gy), dim3(256), 0, s, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
@@ -382,16 +489,19 @@ extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks
   return DY_OK;
 }
 
+struct WgBnHost {  // BatchNorm + SiLU backward folded into the staging of dY (dy_conv_wgrad_bn)
+  const void* raw; void* draw; const float* coef; const double* acc; float* dgamma; float* dbeta; int ldraw; float count;
+};
 static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
                            int cin, int cout, int ks, int stride, int accumulate, int ld_taps, int ld_cphys, int ld_cin,
-                           hipStream_t stream);
+                           hipStream_t stream, const WgBnHost* bn = nullptr);
 
 // host-side: the kernel instantiation dy_conv_wgrad launches for this geometry, spelled as rocprofv3 prints it
 extern "C" int dy_wgrad_kernel_name(int cin, int cout, int ks, int stride, char* out, int cap) {
   if (!out || cap < 8) return DY_ERR_ARG;
   int cp, op, nci, mtc;
   wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc);
-  snprintf(out, cap, "conv_wgrad_kernel<%d, %d, %d, %d>", ks, stride, nci, mtc);
+  snprintf(out, cap, "conv_wgrad_kernel<%d, %d, %d, %d, 0>", ks, stride, nci, mtc);  // ", 1>": the dy_conv_wgrad_bn form
   return DY_OK;
 }
 
@@ -406,9 +516,31 @@ extern "C" int dy_conv_wgrad_ld(const void* x, int ldx, const void* dy, int lddy
                          ld_cin, stream);
 }
 
+// The weight gradient of a Conv (conv + BatchNorm + SiLU, reference nn/modules/conv.py:49-55) given the gradient w.r.t. its
+// ACTIVATED output: the BatchNorm / SiLU backward apply pass (dy_bn_act_bwd_apply_acc) runs inside the kernel, on the dY operand
+// while it is staged, and d(raw conv output) is written once to `draw` (same geometry as `raw`) for the input-gradient pass.
+extern "C" int dy_conv_wgrad_bn(const void* x, int ldx, const void* dy, int lddy, const void* raw, int ldraw, void* draw,
+                                const float* coef, const double* acc, float* dgamma, float* dbeta, float count, float* slabs,
+                                float* dw, int n, int h, int w, int cin, int cout, int ks, int stride, int accumulate,
+                                hipStream_t stream) {
+  // draw == NULL: no input-gradient pass follows (the stem), d(raw) stays in the kernel
+  if (!raw || !coef || !acc || (ldraw & 7) || ((uintptr_t)raw & 15) || ((uintptr_t)draw & 15) || (cout & 15)) return DY_ERR_ARG;
+  const WgBnHost bn{raw, draw, coef, acc, dgamma, dbeta, ldraw, count};
+  return conv_wgrad_impl(x, ldx, dy, lddy, slabs, dw, n, h, w, cin, cout, ks, stride, accumulate, 0, 0, 0, stream, &bn);
+}
+extern "C" int dy_conv_wgrad_ld_bn(const void* x, int ldx, const void* dy, int lddy, const void* raw, int ldraw, void* draw,
+                                   const float* coef, const double* acc, float* dgamma, float* dbeta, float count, float* slabs,
+                                   float* dw, int n, int h, int w, int cout, int ld_cin, int ld_taps, int ld_cphys, int accumulate,
+                                   hipStream_t stream) {
+  if (!raw || !coef || !acc || (ldraw & 7) || ((uintptr_t)raw & 15) || ((uintptr_t)draw & 15) || (cout & 15)) return DY_ERR_ARG;
+  const WgBnHost bn{raw, draw, coef, acc, dgamma, dbeta, ldraw, count};
+  return conv_wgrad_impl(x, ldx, dy, lddy, slabs, dw, n, h, w, ld_taps * ld_cphys, cout, 1, 1, accumulate, ld_taps, ld_cphys, ld_cin,
+                         stream, &bn);
+}
+
 static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
                            int cin, int cout, int ks, int stride, int accumulate, int ld_taps, int ld_cphys, int ld_cin,
-                           hipStream_t stream) {
+                           hipStream_t stream, const WgBnHost* bn) {
   if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || (ks == 1 && stride != 1)) return DY_ERR_ARG;
   if ((ldx & 7) || (lddy & 7) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return DY_ERR_ALIGN;
   // staging uses 32-bit buffer offsets: one image (3x3) or the whole tensor (1x1) must stay below 2 GiB
@@ -423,6 +555,11 @@ static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, flo
   a.Wo = (w + 2 * pad - ks) / stride + 1;
   a.cin_p = cp; a.cout_p = op;
   a.cin_r8 = (cin + 7) / 8 * 8; a.cout_r8 = (cout + 7) / 8 * 8;
+  if (bn) {
+    if ((ks == 1 ? (double)n : 1.0) * a.Ho * a.Wo * bn->ldraw * 2.0 >= 2147483648.0) return DY_ERR_ARG;
+    a.raw = (const f16*)bn->raw; a.draw = (f16*)bn->draw; a.coef = bn->coef; a.acc = bn->acc;
+    a.dgamma = bn->dgamma; a.dbeta = bn->dbeta; a.ldraw = bn->ldraw; a.cout = cout; a.count = bn->count;
+  }
   a.nci_chunks = cp / (16 * nci);
   const int nco_chunks = op / (16 * mtc);
   const int th = wg_th(ks, stride, nci, mtc);

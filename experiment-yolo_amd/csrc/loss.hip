@@ -50,6 +50,7 @@ struct LossCtx {
   int use_wiou, use_nwd;
   float iou_ratio;
   const float* gscale;  // device scalar multiplied into every gradient (loss scale)
+  int prob_scores;      // lv[].cls holds sigmoid probabilities (dy_tal_assign: TaskAlignedAssigner.forward's pd_scores), not logits
 };
 
 static __device__ __forceinline__ void anchor_of(const LossCtx& c, int a, int& l, int& iy, int& ix) {
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void tal_topk_kernel(LossCtx c) {
         float ov = ciou_gt_pred(g, pp);
         ov = ov > 0.f ? ov : 0.f;  // clamp_(0), :125
         const float logit = c.lv[l].cls[(((size_t)b * c.lv[l].H + iy) * c.lv[l].W + ix) * c.ncp + label];
-        const float sc = 1.f / (1.f + expf(-logit));
+        const float sc = c.prob_scores ? logit : 1.f / (1.f + expf(-logit));
         const float o3 = ov * ov * ov;
         metric = sqrtf(sc) * (o3 * o3);  // alpha 0.5, beta 6
       }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void tal_resolve_kernel(LossCtx c) {
       }
       const int label = c.gt_cls[b * c.nmax + j];
       const float logit = c.lv[l].cls[(((size_t)b * c.lv[l].H + iy) * c.lv[l].W + ix) * c.ncp + label];
-      const float sc = 1.f / (1.f + expf(-logit));
+      const float sc = c.prob_scores ? logit : 1.f / (1.f + expf(-logit));
       const float o3 = ov * ov * ov;
       metric = sqrtf(sc) * (o3 * o3);
       atomicMax(&c.pos_align[b * c.nmax + j], __float_as_uint(metric));
@@ -695,6 +696,47 @@ extern "C" int dy_loss_workspace_layout(int B, int A, int nmax, size_t* off_pred
   *off_asg_gt = al(BA * 4);
   al(BA * 4); al(BA * 4);
   *off_tscore = al(BA * 4);
+  return DY_OK;
+}
+
+// TaskAlignedAssigner.forward (reference utils/tal.py:39-88) on its own: the assignment kernels of dy_detection_loss fed with the
+// reference's arguments -- class PROBABILITIES per level, decoded boxes, padded ground truth -- instead of head logits.
+extern "C" int dy_tal_assign(const float* const* scores, const int* H, const int* W, const float* stride, int nl, int B, int nc,
+                             int ncp, int n, const float* pd_boxes_grid, const int* gt_labels, const float* gt_bboxes,
+                             const int* mask_gt, int* asg_gt, float* tscore, void* workspace, hipStream_t stream) {
+  if (nl < 1 || nl > 4 || n < 1 || (ncp & 7) || nc > ncp || !workspace || !asg_gt || !tscore) return DY_ERR_ARG;
+  LossCtx c{};
+  c.nl = nl; c.B = B; c.nc = nc; c.ncp = ncp; c.nmax = n; c.prob_scores = 1;
+  int a0 = 0;
+  for (int l = 0; l < nl; ++l) {
+    c.lv[l] = Level{nullptr, scores[l], nullptr, nullptr, H[l], W[l], a0, stride[l]};
+    a0 += H[l] * W[l];
+  }
+  c.A = a0;
+  char* p = (char*)workspace;
+  auto take = [&](size_t b) { char* r = p; p += (b + 255) / 256 * 256; return r; };
+  const size_t BA = (size_t)B * c.A, BN = (size_t)B * n;
+  take(BN * 16); take(BN * 4); take(BN * 4); take(BA * 16);
+  c.gt_box = const_cast<float*>(gt_bboxes); c.gt_cls = const_cast<int*>(gt_labels); c.gt_valid = const_cast<int*>(mask_gt);
+  c.pred_box = const_cast<float*>(pd_boxes_grid);
+  c.cnt = (int*)take(BA * 4); c.owner = (int*)take(BA * 4);
+  take(BA * 4);
+  c.asg_gt = asg_gt;
+  c.asg_metric = (float*)take(BA * 4); c.asg_ov = (float*)take(BA * 4);
+  take(BA * 4);
+  c.tscore = tscore;
+  c.topk_idx = (int*)take(BN * TOPK * 4); c.pos_align = (unsigned*)take(BN * 4); c.pos_ov = (unsigned*)take(BN * 4);
+  take(16 * 4);
+  c.partials = (float*)take(3 * 4096 * 4);
+  if (hipMemsetAsync(c.cnt, 0, BA * 4, stream) != hipSuccess || hipMemsetAsync(c.pos_align, 0, BN * 4, stream) != hipSuccess ||
+      hipMemsetAsync(c.pos_ov, 0, BN * 4, stream) != hipSuccess)
+    return DY_ERR_LAUNCH;
+  hipLaunchKernelGGL(tal_topk_kernel, dim3((int)BN), dim3(256), 0, stream, c);
+  hipLaunchKernelGGL(tal_scatter_kernel, dim3(cdiv((int)BN * TOPK, 256)), dim3(256), 0, stream, c);
+  const int gridE = (int)((BA + 255) / 256 < 2048 ? (BA + 255) / 256 : 2048);
+  hipLaunchKernelGGL(tal_resolve_kernel, dim3(gridE), dim3(256), 0, stream, c);
+  hipLaunchKernelGGL(tal_scores_kernel, dim3(gridE), dim3(256), 0, stream, c);
+  DY_CHECK_LAUNCH();
   return DY_OK;
 }
 

@@ -155,6 +155,8 @@ class DetectionTrainer:
         ns = tuple(math.ceil(x * sf / gs) * gs for x in (H, W))
         base.stage(batch)
         x = base.import_input()  # eager launch: fp16 NHWC, 8 channels (3 used)
+        if not hasattr(x, "st"):  # fp32 NCHW batches travel as an ImageAct (direct stem): here the imported copy is what is resized
+            x = x.materialize()
         plan = self._scaled_plan(base, ns)
         img = torch.nn.functional.interpolate(x.st.buf[..., :3].permute(0, 3, 1, 2).float(), size=ns, mode="bilinear", align_corners=False)
         plan.x_in[..., :3].copy_(img.permute(0, 2, 3, 1))

@@ -74,6 +74,11 @@ SIGNATURES = {
     "dy_conv_num_partials": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "dy_wgrad_workspace": (i32, [i32, i32, i32, i32, i32, i32, i32, ip, lp]),
     "dy_conv_wgrad": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_stem_grid": (i32, [i32, i32, i32]),
+    "dy_stem_forward": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
+    "dy_stem_wgrad_bn": (i32, [vp, vp, i32, vp, i32, vp, vp, vp, vp, f32, vp, i32, i32, i32, f32, vp]),
+    "dy_conv_wgrad_bn": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_conv_wgrad_ld_bn": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_ldconv_sample": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_ldconv_sample_backward": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_ldconv_sample_backward_gather": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -112,8 +117,11 @@ SIGNATURES = {
     "dy_loss_workspace_bytes": (sz, [i32, i32, i32]),
     "dy_loss_workspace_layout": (i32, [i32, i32, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     "dy_detection_loss": (i32, [C.POINTER(DyLossArgs), vp]),
+    "dy_tal_assign": (i32, [vp, ip, ip, C.POINTER(f32), i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dy_decode_predictions": (i32, [vp, vp, ip, ip, C.POINTER(f32), i32, i32, i32, i32, vp, vp]),
     "dy_nms_candidates": (i32, [vp, i32, i32, i32, f32, i32, vp, i32, vp, vp, vp, vp, i32, vp]),
+    "dy_nms_presort_workspace": (sz, [i32, i32]),
+    "dy_nms_presort": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "dy_soft_nms": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp]),
     "dy_set_hyper": (i32, [vp, vp, vp]),
     "dy_optimizer_step": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, i64, vp, vp, vp, i32, vp]),

@@ -38,6 +38,12 @@ POISON = os.environ.get("DY_POISON", "0") == "1"
 # into fp64 accumulators and the apply kernels sum them in their prologue (csrc/bn_act.hip, BnAccFwd).  DY_BN_ACC=0 restores the
 # three-launch form (partial rows -> dy_bn_finalize -> apply), kept for measurement and for ScalSeq's three-resolution statistics.
 BN_ACC = os.environ.get("DY_BN_ACC", "1") != "0"
+# ... and the backward apply pass folded into the weight-gradient kernel (csrc/conv_wgrad.hip, BNF): the kernel forms d(raw) from
+# (dy, raw) while it stages its dY operand and writes it once for the input-gradient pass.  DY_BN_WGRAD=0: separate apply launch.
+BN_WGRAD = BN_ACC and os.environ.get("DY_BN_WGRAD", "1") != "0"
+# The stem Conv(3 -> 16, k 3, s 2) reads the fp32 NCHW image batch directly (csrc/stem.hip) instead of an imported fp16 copy padded to
+# 8 channels.  DY_STEM_DIRECT=0: import kernel + generic conv / weight-gradient kernels.
+STEM_DIRECT = BN_WGRAD and os.environ.get("DY_STEM_DIRECT", "1") != "0"
 
 
 def dev_empty(shape, dtype, device):
@@ -177,6 +183,23 @@ class Act:
         return 1
 
 
+class ImageAct:
+    """The image batch as the model's first operand WITHOUT an imported copy: a (N,3,H,W) fp32 tensor (x ``mul``) that only the direct
+    stem path (Engine.conv_bn_act -> csrc/stem.hip) consumes; anything else asks for ``materialize()``."""
+    needs_grad = False
+
+    def __init__(self, eng, img, mul=1.0):
+        assert img.dim() == 4 and img.shape[1] == 3 and img.dtype == torch.float32 and img.is_contiguous()
+        self.eng, self.img, self.mul = eng, img, float(mul)
+        self.N, self.C, self.H, self.W = img.shape[0], 3, img.shape[2], img.shape[3]
+        self._act = None
+
+    def materialize(self):
+        if self._act is None:
+            self._act = self.eng.import_image(self.img, 8, self.mul)
+        return self._act
+
+
 class Recorder:
     def __init__(self):
         self.ops = []  # (cfunc, argtuple, name, on_side_stream); cfunc None = fork/join marker
@@ -259,11 +282,11 @@ class Engine:
         if self.rec is not None:
             self.rec.ops.append((None, (), self._JOIN, False))
 
-    def replay(self, rec):
-        """Re-issue a recorded launch list on the CURRENT stream (which may be a capturing stream); side-stream launches and
-        their fork/join points are reproduced (under capture they become parallel branches of the graph)."""
+    def replay(self, rec, lo=0, hi=None):
+        """Re-issue a recorded launch list (or its slice [lo, hi)) on the CURRENT stream (which may be a capturing stream);
+        side-stream launches and their fork/join points are reproduced (under capture they become parallel branches of the graph)."""
         s = self.stream
-        for fn, args, name, side in rec.ops:
+        for fn, args, name, side in (rec.ops if lo == 0 and hi is None else rec.ops[lo:hi]):
             if fn is None:
                 self._sync(name)
                 continue
@@ -296,16 +319,25 @@ class Engine:
     acc_used = 0
     acc_zeroed = False  # True while a trace runs whose launch list began with the pool memset
 
-    def acc_take(self, cout):
+    def acc_take(self, cout, backward=False):
         n = DY_BN_COPIES * 2 * cout
         if self.acc_pool is None:
             self.acc_pool = torch.zeros(1 << 20, dtype=torch.float64, device=self.device)  # 8 MB: ~500 layers of 64 channels
+            self.acc_bwd_mask = torch.zeros(1 << 20, dtype=torch.bool, device=self.device)
             self.keep.append(self.acc_pool)
         if self.acc_used + n > self.acc_pool.numel():
             raise MemoryError("BatchNorm accumulator pool exhausted")
         v = self.acc_pool[self.acc_used:self.acc_used + n]
+        if backward:
+            self.acc_bwd_mask[self.acc_used:self.acc_used + n] = True
         self.acc_used += n
         return v
+
+    def zero_backward_acc(self):
+        """The backward accumulators alone (eager): a backward half that runs on its own -- ``loss.backward()`` after
+        ``model(batch)``, StepPlan.backward_accumulate -- must not add to sums an earlier backward pass left behind."""
+        if self.acc_pool is not None:
+            self.acc_pool.masked_fill_(self.acc_bwd_mask, 0.0)
 
     def zero_acc_pool(self):
         """Recorded as the first launch of a step: every accumulator of the model back to zero."""
@@ -374,7 +406,7 @@ class Engine:
             spec.coef = self.f32(4 * spec.cout)
             spec.bwdcoef = self.f32(2 * spec.cout)
             if spec.cout % 16 == 0:
-                spec.acc_f, spec.acc_b = self.acc_take(spec.cout), self.acc_take(spec.cout)
+                spec.acc_f, spec.acc_b = self.acc_take(spec.cout), self.acc_take(spec.cout, backward=True)
         self.keep += [spec.wpack, spec.wpack_t]
 
     def pack(self, spec: ConvSpec, fold_scale=None, transposed=True):
@@ -445,6 +477,11 @@ class Engine:
     def conv_bn_act(self, spec: ConvSpec, x: Act, out: Act | None = None, res: Act | None = None):
         """Conv.forward (reference nn/modules/conv.py:49-55) with training-mode BatchNorm; optional fused residual
         (Bottleneck.forward, nn/modules/block.py:333-335).  In eval mode BN uses running statistics."""
+        if isinstance(x, ImageAct):
+            if (self.training and STEM_DIRECT and spec.acc_f is not None and (spec.cin, spec.cout, spec.ks, spec.stride) == (3, 16, 3, 2)
+                    and spec.act == DY_ACT_SILU and res is None and spec.ld is None):
+                return self._stem_direct(spec, x, out)
+            x = x.materialize()
         assert x.C == spec.cin_phys, (spec.name, x.C, spec.cin_phys)
         Ho, Wo = self.out_hw(spec, x)
         raw = self.new_act(x.N, Ho, Wo, spec.cout)
@@ -480,6 +517,39 @@ class Engine:
             self.tape.append(lambda: self._conv_bn_act_bwd(spec, x, raw, y, res))
         return y
 
+    def _stem_direct(self, spec, x: ImageAct, out=None):
+        """model.0 from the image batch itself (csrc/stem.hip): forward conv + statistics, the usual apply; backward = the usual
+        reduce, then the weight gradient with the BatchNorm / SiLU backward apply inside (no input gradient exists)."""
+        Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+        bn = spec.bn
+        raw = self.new_act(x.N, Ho, Wo, spec.cout)
+        y = out if out is not None else self.new_act(x.N, Ho, Wo, spec.cout)
+        npix = x.N * Ho * Wo
+        self.call("dy_stem_forward", x.img.data_ptr(), spec.weight.data_ptr(), raw.ptr, raw.ld, self._acc_ready(spec.acc_f), x.N, x.H, x.W, x.mul)
+        self.call("dy_bn_act_apply_acc", raw.ptr, raw.ld, 0, 0, y.ptr, y.ld, spec.acc_f.data_ptr(), bn["weight"].data_ptr(),
+                  bn["bias"].data_ptr(), bn["running_mean"].data_ptr(), bn["running_var"].data_ptr(), spec.coef.data_ptr(), npix, spec.cout,
+                  spec.act, float(npix), spec.bn_eps, spec.bn_mom)
+        if self.tape is not None:
+            def bwd():
+                assert y.grad_ready(), f"gradient of {spec.name} output incomplete"
+                self.call("dy_bn_act_bwd_reduce_acc", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), self._acc_ready(spec.acc_b), npix,
+                          spec.cout, spec.act)
+                ns = self.L.dy_stem_grid(x.N, x.H, x.W)
+                se = 9 * 16 * 16
+                deferred = self.deferred_wgrad is not None
+                slabs = self.transient((ns * se,), torch.float32) if deferred else self.scratch("slabs", ns * se * 4)
+                self.hold(slabs)
+                self.call("dy_stem_wgrad_bn", x.img.data_ptr(), y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), spec.acc_b.data_ptr(),
+                          spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(), float(npix), slabs.data_ptr(), x.N, x.H, x.W, x.mul)
+                if deferred:
+                    self.deferred_wgrad.append((spec, slabs, ns))
+                else:  # reduce now (one descriptor through the batched entry)
+                    keep, self.deferred_wgrad = self.deferred_wgrad, [(spec, slabs, ns)]
+                    self.flush_wgrad()
+                    self.deferred_wgrad = keep
+            self.tape.append(bwd)
+        return y
+
     def _conv_bn_act_bwd(self, spec, x, raw, y, res):
         assert y.grad_ready(), f"gradient of {spec.name} output incomplete"
         npix = y.npix
@@ -507,6 +577,11 @@ class Engine:
             self.hold(draw)
         else:
             draw = self.scratch("draw", npix * spec.cout * 2)
+        if acc and BN_WGRAD and spec.act == DY_ACT_SILU and not self.side_wgrad and raw.ld == spec.cout:
+            # no apply launch: the weight-gradient kernel forms d(raw) while staging and leaves it in ``draw`` for the dgrad
+            bn = (raw, draw, spec.coef.data_ptr(), spec.acc_b.data_ptr(), spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(), float(npix))
+            self._conv_bwd(spec, x, y.gptr, y.ld, y.H, y.W, bn=bn)
+            return
         if acc:
             self.call("dy_bn_act_bwd_apply_acc", y.gptr, y.ld, raw.ptr, raw.ld, draw.data_ptr(), spec.cout, spec.coef.data_ptr(),
                       spec.acc_b.data_ptr(), spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(), npix, spec.cout, spec.act, float(npix))
@@ -515,7 +590,7 @@ class Engine:
                       spec.bwdcoef.data_ptr(), npix, spec.cout, spec.act, 0)
         self._conv_bwd(spec, x, draw.data_ptr(), spec.cout, y.H, y.W)
 
-    def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0, defer=True):
+    def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0, defer=True, bn=None):
         """weight gradient + input gradient of one convolution given d(raw output) (fp16, (N,Ho,Wo,lddy)).
         When the engine is collecting (``self.deferred_wgrad`` is a list: StepPlan's backward trace) the per-workgroup slabs of
         this layer are kept and reduced together with every other layer's by ONE ``dy_wgrad_reduce_batched`` launch at the end
@@ -536,7 +611,17 @@ class Engine:
         side = deferred and self.side_wgrad
         if side:
             self.fork()
-        if spec.ld is not None:
+        if bn is not None:  # dy_ptr is the gradient w.r.t. the ACTIVATED output: BatchNorm + SiLU backward inside the kernel
+            raw, draw, coef, accb, gw, gb, cnt = bn
+            head = (x.ptr, x.ld, dy_ptr, lddy, raw.ptr, raw.ld, draw.data_ptr() if x.needs_grad else 0, coef, accb, gw, gb, cnt,
+                    slabs.data_ptr(), dw, x.N, x.H, x.W)
+            if spec.ld is not None:
+                n, cphys, cin = spec.ld
+                self.call("dy_conv_wgrad_ld_bn", *head, spec.cout, cin, n, cphys, accumulate_w)
+            else:
+                self.call("dy_conv_wgrad_bn", *head, spec.cin, spec.cout, spec.ks, spec.stride, accumulate_w)
+            dy_ptr, lddy = draw.data_ptr(), spec.cout
+        elif spec.ld is not None:
             n, cphys, cin = spec.ld
             self.call("dy_conv_wgrad_ld", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), dw, x.N, x.H, x.W,
                       spec.cout, cin, n, cphys, accumulate_w, side=side)

@@ -119,6 +119,7 @@ class StepPlan:
             crit.__dict__["_last"] = crit
             crit.sync_modes()
             eng.call("dy_detection_loss", C.byref(crit._args))
+            self.fb_split = len(eng.rec.ops)  # [0, fb_split) = forward + loss, the rest = backward (forward_only / backward_accumulate)
             eng.deferred_wgrad = []
             eng.side_wgrad = self.side_wgrad
             for f in reversed(eng.tape):
@@ -155,6 +156,39 @@ class StepPlan:
         else:
             self.eng.replay(self.rec_fb)
         return self.crit.scalars
+
+    # ---- the two halves on their own: ``loss = model(batch); loss.backward()`` (nn/tasks.py, BaseModel.loss) -----------------------
+    def forward_only(self, batch):
+        """Forward + loss of the staged batch (the first half of the recorded list); returns the loss scalars.  The gradients w.r.t.
+        the head outputs are written by the loss kernels at the plan's own loss scale (``state[0]``); nothing else of the backward
+        pass runs."""
+        self.stage(batch)
+        n = self.crit.set_targets(batch, cap=self.B * self.nmax)
+        if n > self.B * self.nmax:
+            raise RuntimeError(f"{n} targets exceed the plan capacity {self.B}x{self.nmax}")
+        self.crit.sync_modes()
+        if self.rec_fb is None:  # first call: the trace runs both halves once; the caller's accumulated gradients are put back
+            keep = self.rt.flat_g.clone()
+            self.rec_fb = self._trace_fb(batch)
+            self.rt.flat_g.copy_(keep)
+        else:
+            self.eng.replay(self.rec_fb, 0, self.fb_split)
+        return self.crit.scalars
+
+    def backward_accumulate(self, grad_out):
+        """The backward half of the recorded list for the forward that ran last, ADDED into the ``.grad`` views with autograd's
+        semantics: ``p.grad += grad_out * dL/dp``.  Internally the pass runs in fp16 at the plan's loss scale; the factor
+        grad_out / scale is applied in fp32 while accumulating.  A non-finite result (fp16 overflow) halves the internal scale for
+        the next call -- GradScaler's policy -- and is handed on as it is (torch.cuda.amp.GradScaler skips such a step)."""
+        g = self.rt.flat_g
+        keep = g.clone()
+        self.eng.zero_backward_acc()  # the recorded list zeroes the statistic accumulators in its FORWARD half only
+        self.eng.replay(self.rec_fb, self.fb_split, None)
+        scale = self.state[0:1]
+        g.mul_(grad_out.reshape(1).to(g.dtype) / scale).add_(keep)
+        if self.dynamic_scale:
+            ok = torch.isfinite(g).all()
+            scale.copy_(torch.where(ok, scale, scale * 0.5))
 
     def stage(self, batch):
         """Bring the batch's images into the static buffers the import kernel of this plan reads (``img`` / pool records, flip
@@ -212,7 +246,10 @@ class StepPlan:
             return eng.import_warp(self.pool, self.warp, 8)
         if self.pool is not None:
             return eng.import_image_u8(self.pool, 8, self.flip, self.index, self.hsv)
-        return eng.import_image_u8(self.img, 8, self.flip, None, self.hsv) if self.input_u8 else eng.import_image(self.img, 8)
+        if self.input_u8:
+            return eng.import_image_u8(self.img, 8, self.flip, None, self.hsv)
+        from .engine import ImageAct  # fp32 NCHW (the trainer's ``batch["img"].float() / 255``): a Conv(3->16, 3, 2) stem reads it directly
+        return ImageAct(eng, self.img)
 
     def _verify_capture(self, buffers_before, scalars_before):
         """Replay the freshly captured forward/backward graph on the traced batch -- from the state the traced step started from
@@ -474,6 +511,24 @@ class StepPlan:
             cin, cout, ks, stride = args[9:13]
             if L.dy_wgrad_kernel_name(cin, cout, ks, stride, buf, 128) == 0:
                 return buf.value.decode(), self.wgrad_algorithmic_bytes(args)
+        if name == "dy_stem_forward":  # (img, w, raw, ldraw, acc, n, h, w, mul): 3 input channels read once, 16 output channels written once
+            n, h, w = args[5:8]
+            return "stem_fwd_kernel", n * h * w * 3 * 2 + n * ((h - 1) // 2 + 1) * ((w - 1) // 2 + 1) * 16 * 2
+        if name == "dy_stem_wgrad_bn":
+            n, h, w = args[11:14]
+            return "stem_wgrad_bn_kernel", n * h * w * 3 * 2 + n * ((h - 1) // 2 + 1) * ((w - 1) // 2 + 1) * 16 * 2
+        if name in ("dy_conv_wgrad_bn", "dy_conv_wgrad_ld_bn"):  # BatchNorm backward apply inside the kernel: d(raw) is written too
+            n, h, w = args[14:17]
+            if name == "dy_conv_wgrad_bn":
+                cin, cout, ks, stride = args[17:21]
+            else:
+                cout, _ld_cin, ld_taps, ld_cphys = args[17:21]
+                cin, ks, stride = ld_taps * ld_cphys, 1, 1
+            if L.dy_wgrad_kernel_name(cin, cout, ks, stride, buf, 128) == 0:
+                pad = ks // 2
+                Ho, Wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+                return (buf.value.decode().replace(", 0>", ", 1>"),
+                        n * h * w * ((cin + 7) // 8 * 8) * 2 + n * Ho * Wo * ((cout + 7) // 8 * 8) * 2)
         if name == "dy_conv_wgrad_ld":
             n, h, w, cout, ld_cin, ld_taps, ld_cphys = args[6:13]
             if L.dy_wgrad_kernel_name(ld_taps * ld_cphys, cout, 1, 1, buf, 128) == 0:

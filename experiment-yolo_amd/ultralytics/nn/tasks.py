@@ -170,6 +170,9 @@ class BaseModel(HipModule):
         eng = self.rt.eng
         plan = self._concat_plan()
         ys, cats = [], {}
+        from ..hip.engine import ImageAct
+        if isinstance(x, ImageAct) and not (type(self.model[0]) is Conv and self.model[0].f == -1 and 0 not in plan):
+            x = x.materialize()  # only a plain Conv stem reads the image batch directly (csrc/stem.hip)
         for m in self.model:
             if m.f != -1:
                 x = ys[m.f] if isinstance(m.f, int) else [x if j == -1 else ys[j] for j in m.f]
@@ -243,9 +246,17 @@ class BaseModel(HipModule):
     def loss(self, batch, preds=None):
         """Reference tasks.py:256-268: lazily build the criterion, ``preds = self.forward(batch["img"]) if preds is None else
         preds``, ``return self.criterion(preds, batch)`` -> (loss.sum()*B, loss_items[box, cls, dfl]).  The forward keeps the raw
-        head outputs on the engine (no NCHW re-formatting); values only -- gradients are produced by ``StepPlan``."""
+        head outputs on the engine (no NCHW re-formatting).
+
+        In training mode with autograd enabled the returned loss carries a ``grad_fn`` -- ONE custom ``torch.autograd.Function``
+        whose backward replays the recorded backward launch list and ACCUMULATES into the ``.grad`` views of the flat gradient
+        buffer -- so the reference's loop shape trains (engine/trainer.py:802-815):
+        ``loss, items = model(batch); scaler.scale(loss).backward(); scaler.step(optimizer)`` with any ``torch.optim`` optimizer
+        over ``model.parameters()``."""
         if not hasattr(self, "criterion"):
             self.criterion = self.init_criterion()
+        if preds is None and self.training and torch.is_grad_enabled():
+            return self._loss_with_grad(batch)
         if preds is None:
             img = batch["img"]
             dev = next(self.parameters()).device
@@ -260,8 +271,52 @@ class BaseModel(HipModule):
                 preds = self.forward_act(rt.to_act(img.to(dev)))
         return self.criterion(preds, batch)
 
+    def _loss_with_grad(self, batch):
+        from ..hip.train import StepPlan
+        img = batch["img"]
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("the HIP hot path runs on the GPU only: move the model with .cuda() first (no CPU fallback)")
+        u8 = img.dtype == torch.uint8 and img.shape[-1] == 3 and img.shape[1] != 3
+        B, (H, W) = img.shape[0], (img.shape[1:3] if u8 else img.shape[2:4])
+        nmax = self.criterion.capacity_for(batch, B)
+        plans = self.__dict__.setdefault("_ag_plans", {})
+        key = (B, int(H), int(W), u8, dev)
+        plan = plans.get(key)
+        if plan is None or plan.nmax < nmax or plan.rt is not self.__dict__.get("rt"):
+            # one recorded launch list per input geometry; fp16 backward at an internal loss scale that follows GradScaler's policy
+            first = next((p for p in plans.values() if p.rt is self.__dict__.get("rt")), None)  # optimizer-side state is shared
+            plan = plans[key] = StepPlan(self, B, (int(H), int(W)), nmax=max(16, 2 * nmax), use_graph=False, init_scale=1024.0, share=first)
+        if img.dtype == torch.uint8 and not u8:
+            batch = dict(batch, img=img.float() / 255)
+        s = plan.forward_only({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()})
+        anchor = self.__dict__.get("_ag_anchor")
+        if anchor is None or anchor.device != dev:
+            anchor = self.__dict__["_ag_anchor"] = torch.zeros(1, device=dev, requires_grad=True)
+        return _PlanLoss.apply(anchor, plan, s[8].clone()), s[5:8].clone()
+
     def init_criterion(self):
         raise NotImplementedError
+
+
+class _PlanLoss(torch.autograd.Function):
+    """grad_fn of the loss ``BaseModel.loss`` returns in training mode: its backward IS the recorded backward launch list of the
+    step plan whose forward produced the value (reference: autograd through v8DetectionLoss and every module, engine/trainer.py:810)."""
+
+    @staticmethod
+    def forward(ctx, anchor, plan, value):
+        ctx.plan = plan
+        ctx.serial = plan.fwd_serial = getattr(plan, "fwd_serial", 0) + 1
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan = ctx.plan
+        if ctx.serial != plan.fwd_serial:
+            raise RuntimeError("backward() of a loss whose forward activations have been overwritten by a later model(batch) call "
+                               "(one forward / backward pair at a time per input geometry)")
+        plan.backward_accumulate(grad_out)
+        return None, None, None
 
 
 class DetectionModel(BaseModel):

@@ -149,15 +149,13 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     candidates(cbox, csc, ccl, cap)
     if int(counts.max()) > max_nms:
         # utils/ops.py:395-396 ``x[x[:, 4].argsort(descending=True)[:max_nms]]``: keep the max_nms most confident, in descending
-        # order.  The reference's argsort is unstable -- the order of EQUAL confidences is unspecified there; here ties keep their
-        # candidate (anchor-major) order.  Host plumbing through torch.sort, outside any timed path.
-        for b in range(B):
-            n = int(counts[b])
-            if n > max_nms:
-                idx = torch.sort(csc[b, :n], descending=True, stable=True).indices[:max_nms]
-                cbox[b, :max_nms], csc[b, :max_nms], ccl[b, :max_nms] = cbox[b, idx], csc[b, idx], ccl[b, idx]
-                cnt[b] = max_nms
-        counts = cnt.cpu()
+        # order (dy_nms_presort: radix select + ordered compaction + bitonic sort, one workgroup per image).  The reference's argsort
+        # is unstable -- the order of EQUAL confidences is unspecified there; here ties keep their candidate (anchor-major) order.
+        obox, osc, ocl = dev_empty((B, max_nms, 4), torch.float32, dev), dev_empty((B, max_nms), torch.float32, dev), dev_empty((B, max_nms), torch.float32, dev)
+        ws = dev_empty(L.dy_nms_presort_workspace(B, max_nms), torch.uint8, dev)
+        check(L.dy_nms_presort(cbox.data_ptr(), csc.data_ptr(), ccl.data_ptr(), cnt.data_ptr(), B, cap, max_nms, obox.data_ptr(),
+                               osc.data_ptr(), ocl.data_ptr(), ws.data_ptr(), st), "dy_nms_presort")
+        cbox, csc, ccl, cap = obox, osc, ocl, max_nms
     oa, ob, keep = (dev_empty((B, cap), torch.int32, dev) for _ in range(3))
     nk = torch.zeros(B, dtype=torch.int32, device=dev)
     check(L.dy_soft_nms(cbox.data_ptr(), csc.data_ptr(), ccl.data_ptr(), cnt.data_ptr(), oa.data_ptr(), ob.data_ptr(), keep.data_ptr(),

@@ -81,6 +81,29 @@ int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int strid
 int dy_wgrad_kernel_name(int cin, int cout, int ks, int stride, char* out, int cap);
 int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
                   int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream);
+/* Weight gradient of a Conv (conv + BatchNorm + SiLU, nn/modules/conv.py:49-55) from the gradient w.r.t. its ACTIVATED output
+ * (autograd: silu_backward + native_batch_norm_backward + the weight half of convolution_backward in one kernel): the
+ * BatchNorm / SiLU backward apply pass runs on the dY operand while it is staged -- coef [4][cout] from the forward, acc
+ * [DY_BN_COPIES][2][cout] from dy_bn_act_bwd_reduce_acc -- and d(raw conv output) is written to draw (N,Ho,Wo,ldraw; the geometry
+ * of raw) for the input-gradient pass; dgamma / dbeta (may be NULL) receive the BatchNorm parameter gradients.  cout % 16 == 0. */
+int dy_conv_wgrad_bn(const void* x, int ldx, const void* dy, int lddy, const void* raw, int ldraw, void* draw, const float* coef,
+                     const double* acc, float* dgamma, float* dbeta, float count, float* slabs, float* dw, int n, int h, int w,
+                     int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream);
+int dy_conv_wgrad_ld_bn(const void* x, int ldx, const void* dy, int lddy, const void* raw, int ldraw, void* draw,
+                        const float* coef, const double* acc, float* dgamma, float* dbeta, float count, float* slabs, float* dw,
+                        int n, int h, int w, int cout, int ld_cin, int ld_taps, int ld_cphys, int accumulate, hipStream_t stream);
+/* The stem Conv(3 -> 16, k 3, s 2, p 1) of the model YAMLs (nn/modules/conv.py:41-55 as model.0) read straight from the image
+ * batch the trainer hands the model (models/yolo/detect/train.py:57-59: fp32 NCHW, img * mul): no import pass, no padded copy.
+ * dy_stem_forward writes the raw conv output (N,Ho,Wo,ldraw) fp16 and ADDS the BatchNorm sums into acc [DY_BN_COPIES][2][16]
+ * (then dy_bn_act_apply_acc as for any Conv).  dy_stem_wgrad_bn: weight gradient with the BatchNorm / SiLU backward apply inside
+ * (as dy_conv_wgrad_bn; no d(raw) output -- the image needs no gradient): slabs [dy_stem_grid()][9][16][16] fp32 for
+ * dy_wgrad_reduce_batched (descriptor: cin 3, cout 16, ks 3, stride 2). */
+int dy_stem_grid(int n, int h, int w);
+int dy_stem_forward(const float* img_nchw, const float* weight, void* raw, int ldraw, double* acc, int n, int h, int w, float mul,
+                    hipStream_t stream);
+int dy_stem_wgrad_bn(const float* img_nchw, const void* dy, int lddy, const void* raw, int ldraw, const float* coef,
+                     const double* acc, float* dgamma, float* dbeta, float count, float* slabs, int n, int h, int w, float mul,
+                     hipStream_t stream);
 /* dw == NULL in dy_conv_wgrad / dy_conv_wgrad_ld defers the slab reduction: the caller keeps that layer's slabs alive, fills one
  * descriptor per layer (host side, sizeof = dy_wgrad_reduce_desc_bytes(); returns the layer's block count, first_block = the
  * exclusive prefix sum of those counts) and reduces every layer of the backward pass in ONE launch. */
@@ -221,6 +244,14 @@ size_t dy_loss_workspace_bytes(int B, int A, int nmax);
  * (B,A f32) inside the workspace after a call -- used by the parity tests */
 int dy_loss_workspace_layout(int B, int A, int nmax, size_t* off_pred_box, size_t* off_asg_gt, size_t* off_tscore);
 int dy_detection_loss(const DyLossArgs* args, hipStream_t stream);
+/* TaskAlignedAssigner.forward utils/tal.py:39-88 as a call of its own (topk 10, alpha 0.5, beta 6.0: what v8DetectionLoss builds,
+ * utils/loss.py:311): scores[l] (B,H,W,ncp) class PROBABILITIES (pd_scores re-laid per level), pd_boxes_grid (B,A,4) xyxy in grid
+ * units (pd_bboxes / stride), gt_labels (B,n) int32, gt_bboxes (B,n,4) xyxy pixels, mask_gt (B,n) int32.  Out: asg_gt (B,A) int32,
+ * the assigned gt slot or -1 (fg_mask / target_gt_idx), tscore (B,A) = the normalised alignment metric at the assigned class
+ * (target_scores).  workspace: dy_loss_workspace_bytes(B, A, n) bytes. */
+int dy_tal_assign(const float* const* scores, const int* H, const int* W, const float* stride, int nl, int B, int nc, int ncp,
+                  int n, const float* pd_boxes_grid, const int* gt_labels, const float* gt_bboxes, const int* mask_gt, int* asg_gt,
+                  float* tscore, void* workspace, hipStream_t stream);
 
 /* ---- Detect inference decode nn/modules/head.py:50-74 (+ DFL nn/modules/block.py:52-55, dist2bbox utils/tal.py:310-318)
  *      -> y (B, 4+nc, A) fp32 [xywh pixels, sigmoid class scores] ------------------------------------------------- */
@@ -229,6 +260,13 @@ int dy_decode_predictions(const float* const* box, const float* const* cls, cons
 /* ---- ops.non_max_suppression utils/ops.py:292-427: candidate extraction (:344-392, order-preserving) ... */
 int dy_nms_candidates(const float* pred, int B, int nc, int A, float conf, int multi_label, const int* classes,
                       int n_classes, float* cbox, float* cscore, float* ccls, int* ccount, int cap, hipStream_t stream);
+/* ---- ... the candidate cap utils/ops.py:395-396 ``x = x[x[:, 4].argsort(descending=True)[:max_nms]]``: per image with more than
+ *      max_nms candidates the max_nms most confident ones in descending confidence (ties in candidate order: the reference's
+ *      unstable argsort leaves them unspecified); other images are copied through.  Outputs (B,max_nms,4) / (B,max_nms); count is
+ *      clamped in place.  workspace: dy_nms_presort_workspace(B, max_nms) bytes. */
+size_t dy_nms_presort_workspace(int B, int max_nms);
+int dy_nms_presort(const float* cbox, const float* cscore, const float* ccls, int* count, int B, int cap, int max_nms, float* obox,
+                   float* oscore, float* ocls, void* workspace, hipStream_t stream);
 /* ---- ... and ops.soft_nms utils/ops.py:260-290 with bbox_iou_for_nms :162-199 (sequential semantics kept; scores are
  *      decayed in place; keep/nkeep receive the kept candidate indices per image) ---------------------------------- */
 int dy_soft_nms(const float* boxes, float* scores, const float* cls, const int* count, int* order_a, int* order_b,

@@ -203,6 +203,26 @@ def test_bn_accumulator_path_equals_finalize_path(cin, cout, ks, s, H, W, act):
 
     a, b = fwd_bwd(True), fwd_bwd(False)
     assert torch.equal(a["raw"], b["raw"])
+    # the backward apply pass folded into the weight-gradient kernel (dy_conv_wgrad_bn): d(raw) bit for bit what the stand-alone
+    # pass writes, the same weight / input gradients as that pass followed by dy_conv_wgrad, and the BatchNorm parameter gradients
+    from types import SimpleNamespace as NS
+    af = torch.zeros(DY_BN_COPIES * 2 * cout, dtype=torch.float64, device="cuda")
+    eng.call("dy_bn_act_bwd_reduce_acc", dy.ptr, dy.ld, a["raw"].data_ptr(), cout, a["coef"].data_ptr(), af.data_ptr(), npix, cout, act)
+    if act == 1:
+        xa.needs_grad = True
+        ref_dx = a["dx"].clone()
+        eng._conv_bwd(sp, xa, ref_dx.data_ptr(), cout, Ho, Wo)
+        torch.cuda.synchronize()
+        gw_ref, gx_ref = sp.gweight.clone(), xa.st.gbuf.clone()
+        sp.gweight.zero_(); xa.st.gbuf.zero_(); xa.st.gwritten.clear()
+        draw = torch.full((N, Ho, Wo, cout), float("nan"), dtype=torch.float16, device="cuda")
+        dg, db = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda")
+        eng._conv_bwd(sp, xa, dy.ptr, dy.ld, Ho, Wo, bn=(NS(ptr=a["raw"].data_ptr(), ld=cout), draw, a["coef"].data_ptr(), af.data_ptr(),
+                                                       dg.data_ptr(), db.data_ptr(), float(npix)))
+        torch.cuda.synchronize()
+        assert torch.equal(draw, ref_dx), float((draw.float() - ref_dx.float()).abs().max())
+        assert torch.equal(sp.gweight, gw_ref) and torch.equal(xa.st.gbuf, gx_ref)
+        assert torch.equal(dg, a["dg"]) and torch.equal(db, a["db"])
     for k in ("coef", "rm", "rv", "dg", "db"):
         assert relerr(a[k], b[k]) < 2e-6, k
     # fp16 outputs: identical except where a last-bit difference of a coefficient crosses an fp16 rounding boundary
@@ -356,3 +376,60 @@ def test_flat_optimizer_step_matches_torch_optim(name):
         ref = torch.cat([q.detach() for q in ref_p])
         assert relerr(p, ref) < 2e-5, (name, step)
     assert float(state[5]) == 8 and float(state[6]) == 0
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (3, 70, 50), (1, 640, 640)])
+def test_direct_stem_equals_import_plus_generic_conv(N, H, W):
+    """model.0 = Conv(3 -> 16, k 3, s 2) read straight from the fp32 NCHW image batch (csrc/stem.hip: dy_stem_forward /
+    dy_stem_wgrad_bn) against the three-launch form it replaces (import to fp16 NHWC8 + generic conv + generic fused weight
+    gradient): raw output, BatchNorm sums, weight and BatchNorm parameter gradients."""
+    from ultralytics.hip import DY_BN_COPIES
+    torch.manual_seed(N * 1000 + H)
+    eng = _eng()
+    img = torch.rand(N, 3, H, W).cuda()
+    w = h16(torch.randn(16, 3, 3, 3) / 27 ** 0.5)
+    sp = _spec(eng, w, None, 3, 2)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    npix = N * Ho * Wo
+    xa = eng.import_image(img, 8, 1.0)
+    gamma, beta = (torch.rand(16) + 0.5).cuda(), (torch.randn(16) * 0.2).cuda()
+    dy = _act(eng, h16(torch.randn(N, 16, Ho, Wo)))
+
+    def run(direct):
+        raw = torch.zeros(N, Ho, Wo, 16, dtype=torch.float16, device="cuda")
+        y = torch.zeros_like(raw)
+        af = torch.zeros(DY_BN_COPIES * 2 * 16, dtype=torch.float64, device="cuda")
+        ab = torch.zeros_like(af)
+        rm, rv, coef = torch.zeros(16, device="cuda"), torch.ones(16, device="cuda"), torch.zeros(64, device="cuda")
+        dg, db = torch.zeros(16, device="cuda"), torch.zeros(16, device="cuda")
+        if direct:
+            eng.call("dy_stem_forward", img.data_ptr(), sp.weight.data_ptr(), raw.data_ptr(), 16, af.data_ptr(), N, H, W, 1.0)
+        else:
+            eng.call("dy_conv_forward", xa.ptr, xa.ld, sp.wpack.data_ptr(), 0, raw.data_ptr(), 16, af.data_ptr(), N, H, W, xa.C, 16, 3, 2, 1,
+                     0, 0, 1 | 32, None)
+        eng.call("dy_bn_act_apply_acc", raw.data_ptr(), 16, 0, 0, y.data_ptr(), 16, af.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                 rm.data_ptr(), rv.data_ptr(), coef.data_ptr(), npix, 16, 1, float(npix), 1e-3, 0.03)
+        eng.call("dy_bn_act_bwd_reduce_acc", dy.ptr, dy.ld, raw.data_ptr(), 16, coef.data_ptr(), ab.data_ptr(), npix, 16, 1)
+        sp.gweight.zero_()
+        if direct:
+            ns = eng.L.dy_stem_grid(N, H, W)
+            slabs = torch.full((ns * 9 * 16 * 16,), float("nan"), device="cuda")
+            eng.call("dy_stem_wgrad_bn", img.data_ptr(), dy.ptr, dy.ld, raw.data_ptr(), 16, coef.data_ptr(), ab.data_ptr(), dg.data_ptr(),
+                     db.data_ptr(), float(npix), slabs.data_ptr(), N, H, W, 1.0)
+            eng.deferred_wgrad = [(sp, slabs, ns)]
+            eng.flush_wgrad()
+        else:
+            from types import SimpleNamespace as NS
+            xa.needs_grad = False
+            eng._conv_bwd(sp, xa, dy.ptr, dy.ld, Ho, Wo, bn=(NS(ptr=raw.data_ptr(), ld=16), raw, coef.data_ptr(), ab.data_ptr(), dg.data_ptr(),
+                                                           db.data_ptr(), float(npix)))
+        torch.cuda.synchronize()
+        sums = af.view(DY_BN_COPIES, 2, 16).sum(0)
+        return dict(raw=raw.float(), sums=sums, y=y.float(), gw=sp.gweight.clone(), dg=dg, db=db)
+
+    a, b = run(True), run(False)
+    ref = F.conv2d(img.half().float().cpu(), w, None, 2, 1).permute(0, 2, 3, 1)
+    assert relerr(a["raw"], ref) < 1e-3 and relerr(b["raw"], ref) < 1e-3
+    assert relerr(a["raw"], b["raw"]) < 1e-3 and float((a["raw"] != b["raw"]).float().mean()) < 2e-2   # summation order only
+    assert relerr(a["sums"], b["sums"]) < 1e-5
+    assert relerr(a["gw"], b["gw"]) < 2e-3 and relerr(a["dg"], b["dg"]) < 2e-3 and relerr(a["db"], b["db"]) < 2e-3

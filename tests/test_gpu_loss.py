@@ -81,6 +81,47 @@ def test_loss_vs_golden(golden, case, mode):
         _ = (A, ws)
 
 
+@pytest.mark.parametrize("case", list(loss_cases()))
+def test_task_aligned_assigner_forward(golden, case):
+    """``ultralytics.utils.tal.TaskAlignedAssigner(topk=10, num_classes=nc, alpha=0.5, beta=6.0)(pd_scores, pd_bboxes, anc_points,
+    gt_labels, gt_bboxes, mask_gt)`` -- the reference's own call (utils/loss.py:311, :391-398; utils/tal.py:39-88) -- against the
+    reference's assignment in the loss fixture and, tensor by tensor, against the oracle's restatement on the same inputs."""
+    from oracle import loss as ol
+    from ultralytics.utils.tal import TaskAlignedAssigner, make_anchors
+    G = golden("loss")
+    feats = [G.t(f"{case}/feat{l}") for l in range(3)]
+    strides = torch.tensor([4.0, 8.0, 16.0])
+    nc, bs = 6, feats[0].shape[0]
+    cat = torch.cat([f.reshape(bs, nc + 64, -1) for f in feats], 2)
+    pred_distri, pred_scores = cat.split((64, nc), 1)
+    pred_scores, pred_distri = pred_scores.permute(0, 2, 1).contiguous(), pred_distri.permute(0, 2, 1).contiguous()
+    anchors, st = make_anchors(feats, strides)
+    imgsz = torch.tensor(feats[0].shape[2:], dtype=torch.float32) * strides[0]
+    batch = {k: G.t(f"{case}/{k}") for k in ("batch_idx", "cls", "bboxes")}
+    targets = ol.pack_targets(batch, bs, imgsz[[1, 0, 1, 0]])
+    gt_labels, gt_bboxes = targets.split((1, 4), 2)
+    mask_gt = gt_bboxes.sum(2, keepdim=True).gt(0).float()
+    d = pred_distri.view(bs, -1, 4, 16).softmax(3).matmul(torch.arange(16, dtype=torch.float32))
+    lt, rb = d.chunk(2, -1)
+    pred_bboxes = torch.cat((anchors - lt, anchors + rb), -1)
+    args = (pred_scores.sigmoid(), pred_bboxes * st, anchors * st, gt_labels, gt_bboxes, mask_gt)
+    ref = ol.tal_assign(*args, nc)
+    got = TaskAlignedAssigner(topk=10, num_classes=nc, alpha=0.5, beta=6.0)(*[a.cuda() for a in args])
+    torch.cuda.synchronize()
+    labels, boxes, scores, fg, tgi = [t.cpu() for t in got]
+    if gt_bboxes.shape[1]:
+        assert fg.dtype == torch.bool
+    fg = fg.bool()  # the reference's empty-target branch (utils/tal.py:59-67) returns float zeros for fg_mask / target_gt_idx
+    tgi = tgi.long()
+    assert torch.equal(fg, G.t(f"{case}/fg_mask").bool()) and torch.equal(fg, ref.fg_mask)
+    assert torch.equal(tgi[fg], G.t(f"{case}/target_gt_idx").long()[fg]) and torch.equal(tgi, ref.target_gt_idx)
+    assert torch.equal(labels.long(), ref.target_labels.long()) and torch.equal(boxes, ref.target_bboxes)
+    assert scores.shape == ref.target_scores.shape and relerr(scores, ref.target_scores) < 1e-5
+    assert relerr(scores, G.t(f"{case}/target_scores")) < 1e-5
+    with pytest.raises(NotImplementedError):
+        TaskAlignedAssigner(topk=13, num_classes=nc)(*[a.cuda() for a in args])
+
+
 def test_reference_preds_protocol_and_model_batch_call(golden):
     """The criterion takes the reference's ``preds`` (list of (B, no, H, W) maps, or the eval-mode (y, feats) tuple; reference
     utils/loss.py:356-368) and ``model(batch_dict)`` runs forward + loss like BaseModel.loss (nn/tasks.py:256-268)."""

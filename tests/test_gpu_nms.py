@@ -58,3 +58,32 @@ def test_decode_and_eval_paths(golden):
     reff = G.t(f"{name}/y_eval_fused")
     assert relerr(yf[:, :4].cpu(), reff[:, :4]) < 2e-2 and relerr(yf[:, 4:].cpu(), reff[:, 4:]) < 2e-2
     assert sum(p.numel() for p in m.parameters()) == int(G[f"{name}/n_params_fused"])
+
+
+@pytest.mark.parametrize("max_nms", [300, 1000, 30000])
+def test_candidate_cap_presort_kernel(max_nms):
+    """``x = x[x[:, 4].argsort(descending=True)[:max_nms]]`` (reference utils/ops.py:395-396) as dy_nms_presort: for every image with
+    more than max_nms candidates the max_nms most confident ones in descending confidence, ties in candidate order (= a STABLE
+    descending sort; the reference's unstable argsort leaves the order of equal confidences open), other images untouched.
+    Confidences are drawn from a few hundred distinct values, so ties straddle the cut."""
+    from ultralytics.hip import check, lib
+    torch.manual_seed(max_nms)
+    L = lib()
+    B = 5
+    counts = [max_nms * 3 + 17, max_nms, max_nms + 1, 7, max_nms * 2]
+    cap = max(counts)
+    sc = (torch.randint(1, 400, (B, cap)).float() / 400).cuda()          # many exact ties
+    sc[4] = torch.rand(cap).cuda() * 0.9 + 0.05                           # and one image without
+    bx = torch.rand(B, cap, 4).cuda()
+    cl = torch.randint(0, 6, (B, cap)).float().cuda()
+    cnt = torch.tensor(counts, dtype=torch.int32).cuda()
+    ob, osc, ocl = torch.full((B, max_nms, 4), -1.0).cuda(), torch.full((B, max_nms), -1.0).cuda(), torch.full((B, max_nms), -1.0).cuda()
+    ws = torch.empty(L.dy_nms_presort_workspace(B, max_nms), dtype=torch.uint8, device="cuda")
+    check(L.dy_nms_presort(bx.data_ptr(), sc.data_ptr(), cl.data_ptr(), cnt.data_ptr(), B, cap, max_nms, ob.data_ptr(), osc.data_ptr(),
+                           ocl.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "dy_nms_presort")
+    torch.cuda.synchronize()
+    assert cnt.tolist() == [min(c, max_nms) for c in counts]
+    for b, n in enumerate(counts):
+        k = min(n, max_nms)
+        idx = torch.sort(sc[b, :n], descending=True, stable=True).indices[:k] if n > max_nms else torch.arange(k, device="cuda")
+        assert torch.equal(osc[b, :k], sc[b, idx]) and torch.equal(ocl[b, :k], cl[b, idx]) and torch.equal(ob[b, :k], bx[b, idx]), b

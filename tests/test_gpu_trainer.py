@@ -272,3 +272,65 @@ def test_multi_scale_from_the_dataset_loader(tmp_path, cache, aug):
     assert len(hist) == 3 and all(torch.isfinite(h).all() for h in hist)
     assert sizes and set(sizes) <= {32, 96}, sizes  # 64 runs through the ordinary plan
     assert float(tr.plan.state[5]) + float(tr.plan.state[6]) == tr.plan.opt_calls and float(tr.plan.state[5]) >= tr.plan.opt_calls - 4
+
+
+def test_reference_loop_shape_trains_through_autograd():
+    """The reference's hot loop as written (engine/trainer.py:802-815): ``loss, items = model(batch); loss.backward();
+    optimizer.step()`` with a plain ``torch.optim.SGD`` over ``model.parameters()`` -- the loss carries ONE custom autograd Function
+    whose backward replays the recorded launch list -- against the same three steps taken by ``StepPlan`` (flat optimizer kernel):
+    weights to 1e-6.  Also: ``.backward()`` ACCUMULATES into ``.grad`` (two backward calls double it), GradScaler-style scaled losses
+    scale the gradients, and a stale loss refuses to back-propagate."""
+    from ultralytics.nn.tasks import DetectionModel
+    from ultralytics.hip.train import StepPlan
+    cfg = os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml")
+    batch = dict(img=torch.rand(2, 3, 64, 64), batch_idx=torch.tensor([0., 0., 1.]), cls=torch.tensor([[1.], [2.], [3.]]),
+                 bboxes=torch.tensor([[.5, .5, .3, .3], [.3, .6, .2, .2], [.6, .4, .4, .3]]))
+    torch.manual_seed(0)
+    ma = DetectionModel(cfg, verbose=False).cuda().train()
+    torch.manual_seed(0)
+    mb = DetectionModel(cfg, verbose=False).cuda().train()
+    for m in (ma, mb):
+        for k, v in m.named_parameters():
+            v.requires_grad = ".dfl" not in k
+    lr, mom = 0.01, 0.9
+    # A: the reference loop with torch.optim.SGD (nesterov, as build_optimizer does) + the trainer's clip at 10
+    params = [p for p in ma.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=lr, momentum=mom, nesterov=True)
+    losses_a = []
+    for _ in range(3):
+        loss, items = ma(batch)
+        assert loss.requires_grad and loss.grad_fn is not None and items.shape == (3,)
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, max_norm=10.0)
+        opt.step()
+        losses_a.append(float(loss))
+    # B: StepPlan (its gradients are those of loss.sum() * B, exactly what model(batch) returns)
+    plan = StepPlan(mb, 2, 64, nmax=16, optimizer="SGD", use_graph=False, init_scale=1024.0, dynamic_scale=False)
+    losses_b = []
+    for _ in range(3):
+        plan.set_hyper([lr] * 3, mom, [0.0] * 3, max_norm=10.0)
+        plan.forward_backward(batch)
+        plan.optimizer_step()
+        losses_b.append(plan.loss_items()[0])
+    torch.cuda.synchronize()
+    assert max(abs(a - b) / abs(b) for a, b in zip(losses_a, losses_b)) < 1e-5, (losses_a, losses_b)
+    pa, pb = ma._runtime("cuda:0").flat_p, mb._runtime("cuda:0").flat_p
+    assert float((pa - pb).abs().max() / pb.abs().max()) < 1e-6
+    assert losses_a[-1] != losses_a[0]
+    # accumulate semantics and scaled losses
+    opt.zero_grad(set_to_none=False)
+    loss, _ = ma(batch)
+    loss.backward()
+    g1 = ma._runtime("cuda:0").flat_g.clone()
+    loss, _ = ma(batch)
+    (loss * 8.0).backward()
+    g2 = ma._runtime("cuda:0").flat_g.clone()
+    assert float((g2 - 9.0 * g1).abs().max() / g1.abs().max()) < 2e-3  # same weights, same batch: g + 8 g
+    stale, _ = ma(batch)
+    ma(batch)
+    with pytest.raises(RuntimeError, match="overwritten by a later"):
+        stale.backward()
+    with torch.no_grad():  # values only
+        v, _ = ma(batch)
+    assert not v.requires_grad

@@ -36,6 +36,11 @@ for name, a, ms in prof:
         d = f"{cin}->{cout} k{ks} s{s} @{h}x{w}"
         p = ks // 2
         by = n * h * w * cin * 2 + n * ((h + 2 * p - ks) // s + 1) * ((w + 2 * p - ks) // s + 1) * cout * 2
+    elif name == "dy_conv_wgrad_bn":  # reads x, dy, raw; writes d(raw)
+        n, h, w, cin, cout, ks, s = a[14:21]
+        d = f"{cin}->{cout} k{ks} s{s} @{h}x{w}"
+        p = ks // 2
+        by = n * h * w * cin * 2 + 3 * n * ((h + 2 * p - ks) // s + 1) * ((w + 2 * p - ks) // s + 1) * cout * 2
     elif name == "dy_ldconv_sample_backward":
         d = f"C={a[15]} Np={a[16]} s{a[17]} {a[11]}x{a[12]}->{a[13]}x{a[14]} n={a[10]} dx={'y' if a[7] else 'n'}"
         by = a[10] * a[13] * a[14] * a[16] * a[15] * 2
