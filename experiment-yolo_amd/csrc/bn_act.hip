@@ -293,9 +293,11 @@ struct BwdRedArgs {
   long npix;
   int rev;  // DY_EW_REVERSE bit 2
   double* acc;      // non-null: add the block's sums into acc[blockIdx.x % DY_BN_COPIES][2][C] instead (see BnAccFwd)
+  f16* rg;          // RES: gradient of the residual operand (Bottleneck shortcut, y = act(bn(conv)) + res): rg (+)= dy on the way
+  int ldrg, rg_acc;
 };
 
-template <int ACT>
+template <int ACT, bool RES = false>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
   const int cpp = a.C >> 3, rows = 256 / cpp, tid = threadIdx.x;
   const int part = tid % cpp, row = tid / cpp, c0 = part * 8;
@@ -315,11 +317,26 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
     long pix = (long)blockIdx.x * rows + row;
     auto at = [&](long p) { return a.rev ? a.npix - 1 - p : p; };
     auto pair = [](const half8& v, int j) { return (f32x2){(float)v[2 * j], (float)v[2 * j + 1]}; };
+    // the shortcut's gradient is dy itself: written (first writer) or added (fan-in) here instead of by a launch of its own
+    auto pass_on = [&](long p, const half8& dv) {
+      f16* dst = a.rg + at(p) * a.ldrg + c0;
+      half8 o = dv;
+      if (a.rg_acc) {
+        const half8 old = *reinterpret_cast<const half8*>(dst);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)old[j] + (float)dv[j]);
+      }
+      *reinterpret_cast<half8*>(dst) = o;
+    };
     for (; pix + step < a.npix; pix += 2 * step) {
       const half8 dv0 = *reinterpret_cast<const half8*>(a.dy + at(pix) * a.lddy + c0);
       const half8 xv0 = *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0);
       const half8 dv1 = *reinterpret_cast<const half8*>(a.dy + at(pix + step) * a.lddy + c0);
       const half8 xv1 = *reinterpret_cast<const half8*>(a.x + at(pix + step) * a.ldx + c0);
+      if (RES) {
+        pass_on(pix, dv0);
+        pass_on(pix + step, dv1);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x2 x0 = pair(xv0, j), x1 = pair(xv1, j);
@@ -332,6 +349,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
     if (pix < a.npix) {
       const half8 dv = *reinterpret_cast<const half8*>(a.dy + at(pix) * a.lddy + c0);
       const half8 xv = *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0);
+      if (RES) pass_on(pix, dv);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x2 x = pair(xv, j);
@@ -378,15 +396,15 @@ extern "C" int dy_bn_act_bwd_reduce(const void* dy, int lddy, const void* x, int
   if (blocks < 1) blocks = 1;
   if (nparts) *nparts = (int)blocks;
   const int rev = ew_reverse();
-  BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, partials, lddy, ldx, C, act, npix, (rev >> 2) & 1, nullptr};
+  BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, partials, lddy, ldx, C, act, npix, (rev >> 2) & 1, nullptr, nullptr, 0, 0};
   DY_ACT_DISPATCH(bn_act_bwd_reduce_kernel, dim3((int)blocks), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
 
 extern "C" int dy_bn_act_bwd_reduce_acc(const void* dy, int lddy, const void* x, int ldx, const float* coef, double* acc,
-                                        long npix, int C, int act, hipStream_t stream) {
-  if ((C & 7) || C > 2048 || (ldx & 7) || (lddy & 7)) return DY_ERR_ALIGN;
+                                        long npix, int C, int act, void* res_grad, int ldrg, int res_accumulate, hipStream_t stream) {
+  if ((C & 7) || C > 2048 || (ldx & 7) || (lddy & 7) || (res_grad && ((ldrg & 7) || ((uintptr_t)res_grad & 15)))) return DY_ERR_ALIGN;
   const int cpp = C >> 3;
   if (cpp > 256 || !acc) return DY_ERR_ARG;
   const int rows = 256 / cpp;
@@ -395,8 +413,11 @@ extern "C" int dy_bn_act_bwd_reduce_acc(const void* dy, int lddy, const void* x,
   if (blocks > bcap) blocks = bcap;
   if (blocks < 1) blocks = 1;
   const int rev = ew_reverse();
-  BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, nullptr, lddy, ldx, C, act, npix, (rev >> 2) & 1, acc};
-  DY_ACT_DISPATCH(bn_act_bwd_reduce_kernel, dim3((int)blocks), stream, a);
+  BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, nullptr, lddy, ldx, C, act, npix, (rev >> 2) & 1, acc, (f16*)res_grad, ldrg, res_accumulate};
+  if (res_grad && act == DY_ACT_SILU) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DY_ACT_SILU, true>), dim3((int)blocks), dim3(256), 0, stream, a);
+  else if (res_grad && act == DY_ACT_LEAKY) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DY_ACT_LEAKY, true>), dim3((int)blocks), dim3(256), 0, stream, a);
+  else if (res_grad) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DY_ACT_NONE, true>), dim3((int)blocks), dim3(256), 0, stream, a);
+  else DY_ACT_DISPATCH(bn_act_bwd_reduce_kernel, dim3((int)blocks), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
   __shared__ __attribute__((aligned(16))) char smem[XBYTES + YBYTES];
   char* const sx = smem;
   char* const sy = smem + XBYTES;
-  __shared__ __attribute__((aligned(16))) float sbn[BNF ? 4 * COUT_C : 4];  // BNF: [sc | sh | kb | kc] of this cout chunk
+  __shared__ __attribute__((aligned(16))) float sbn[BNF == 1 ? 4 * COUT_C : (BNF == 2 ? 256 * 8 : 4)];  // BNF 1: [sc | sh | kb | kc] of this cout chunk; 2: bias-sum scratch
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // BNF 2: sum over pixels of this thread's dY granule (its channel part is fixed)
+  (void)bsum;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
   const int qq = p >> 2, pp = p & 3;  // address-supplier role inside the 16-lane group
@@ -98,8 +100,8 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
   constexpr int NGX = HHX * HWX * (CIN_C / 8), NGY = TH * TW * (COUT_C / 8);
   constexpr int NPX = (NGX + 255) / 256, NPY = (NGY + 255) / 256;
   uint4 pfx[NPX], pfy[NPY];
-  uint4 pfr[BNF ? NPY : 1];     // BNF: raw conv output granules beside the dy granules
-  unsigned roff[BNF ? NPY : 1]; // their byte offsets in the (raw / draw) geometry
+  uint4 pfr[BNF == 1 ? NPY : 1];     // BNF: raw conv output granules beside the dy granules
+  unsigned roff[BNF == 1 ? NPY : 1]; // their byte offsets in the (raw / draw) geometry
   int ncur = 0, nnext = 0;  // BNF, 3x3: image index of the staged / prefetched tile (the draw store needs its descriptor)
   (void)ncur; (void)nnext;
   unsigned vnext = 0, vcur = 0, ornext = 0, orcur = 0;  // BNF: validity bits + (raw / draw) tile-origin offset of the prefetched / staged tile
@@ -124,9 +126,9 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
     const bool ok = id < NGY && co0 + part * 8 < a.cout_r8;
     const int ty = FLAT ? 0 : pixel / TW, tx = FLAT ? pixel : pixel - ty * TW;
     yoff[i] = ok ? (unsigned)(((ty * a.Wo + tx) * a.lddy + co0 + part * 8) * 2) : NEVER;
-    if (BNF) roff[i] = ok ? (unsigned)(((ty * a.Wo + tx) * a.ldraw + co0 + part * 8) * 2) : NEVER;
+    if (BNF == 1) roff[i] = ok ? (unsigned)(((ty * a.Wo + tx) * a.ldraw + co0 + part * 8) * 2) : NEVER;
   }
-  if (BNF) {
+  if (BNF == 1) {
     // BatchNorm backward coefficients of this cout chunk from the reduce pass's fp64 sums (what bn_act_bwd_apply_kernel<.., true>
     // does in its prologue): dx = sc*g - (kb*x + kc), kb = sc*invstd*mean(g*xhat), kc = sc*mean(g) - kb*mean
     for (int c = tid; c < COUT_C; c += 256) {
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
       for (int i = 0; i < NPX; ++i) pfx[i] = ld16(rx, xoff[i] + ox);
 #pragma unroll
       for (int i = 0; i < NPY; ++i) pfy[i] = ld16(ry, yoff[i] + oy);
-      if (BNF) {
+      if (BNF == 1) {
         const unsigned nbytes = (unsigned)a.npix * (unsigned)a.ldraw * 2u;
         const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.raw), 0, (int)nbytes, 0x00020000);
         ornext = (unsigned)tile * (TH * TW) * a.ldraw * 2u;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
           pfy[i] = ld16(ry, ox0 + tx < a.Wo ? yoff[i] + oy : NEVER);
         }
       }
-      if (BNF) {
+      if (BNF == 1) {
         const unsigned nbytes = (unsigned)(a.Ho * a.Wo * a.ldraw * 2);
         const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.raw) + (size_t)n * a.Ho * a.Wo * a.ldraw, 0, (int)nbytes, 0x00020000);
         ornext = (unsigned)((oy0 * a.Wo + ox0) * a.ldraw * 2);
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
       const int id = tid + i * 256;
       if (id < NGX) *reinterpret_cast<uint4*>(sx + (id / (CIN_C / 8)) * PSX + (id % (CIN_C / 8)) * 16) = pfx[i];
     }
-    if (BNF) {
+    if (BNF == 1) {
       vcur = vnext; orcur = ornext; ncur = nnext;
       // d(raw) = BatchNorm + SiLU backward of (dy, raw), formed here in registers: it becomes the A operand in LDS and -- from the
       // workgroups of Cin chunk 0 -- the tensor the input-gradient pass reads.  Granules the range check zeroed (outside the image,
@@ -270,6 +272,11 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
       for (int i = 0; i < NPY; ++i) {
         const int id = tid + i * 256;
         if (id < NGY) *reinterpret_cast<uint4*>(sy + (id / (COUT_C / 8)) * PSY + (id % (COUT_C / 8)) * 16) = pfy[i];
+        if (BNF == 2 && id < NGY) {  // bias gradient = sum of dY over the pixels: taken while the granule passes (zeros outside the map)
+          const half8 v = *reinterpret_cast<const half8*>(&pfy[i]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[j] += (float)v[j];
+        }
       }
     }
     __syncthreads();
@@ -325,6 +332,18 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
     }
   }
 
+  if (BNF == 2 && ci_chunk == 0) {  // (256 % CPGY == 0 is the launcher's condition: a thread's channel part never changes)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sbn[tid * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < COUT_C && co0 + tid < a.cout) {
+      const int part = tid >> 3, j = tid & 7;
+      float t = 0.f;
+      for (int k = part; k < 256; k += CPGY) t += sbn[k * 8 + j];
+      unsafeAtomicAdd(const_cast<double*>(a.acc) + (size_t)(blockIdx.x % DY_BN_COPIES) * a.cout + co0 + tid, (double)t);
+    }
+  }
   // ---- one slab per workgroup: [tap][cout_p][cin_p] fp32 (16 lanes -> 64 contiguous bytes)
   float* slab = a.slabs + (size_t)blockIdx.x * TAPS * a.cout_p * a.cin_p;
 #pragma unroll
@@ -397,7 +416,9 @@ struct WgReduceDesc {
   const float* slabs;
   float* dw;
   int nslabs, cout, cin, taps, cout_p, cin_p, accumulate, ld_taps, ld_cphys, ld_cin;
-  int first_block, pad_;
+  int first_block, bias_c;      // bias_c > 0: dbias[c] = sum over the DY_BN_COPIES copies of bias_acc (dy_conv_wgrad_bias)
+  const double* bias_acc;
+  float* dbias;
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgReduceDesc* descs, int n) {
   int lo = 0, hi = n - 1;
@@ -407,6 +428,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgReduc
     else hi = mid - 1;
   }
   const WgReduceDesc d = descs[lo];
+  if (d.bias_c > 0 && (int)blockIdx.x == d.first_block && (int)threadIdx.x < d.bias_c) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < DY_BN_COPIES; ++k) t += d.bias_acc[(size_t)k * d.bias_c + threadIdx.x];
+    d.dbias[threadIdx.x] = (float)t;
+  }
   wgrad_reduce_block(blockIdx.x - d.first_block, d.slabs, d.nslabs, d.dw, d.cout, d.cin, d.taps, d.cout_p, d.cin_p, d.accumulate,
                      d.ld_taps, d.ld_cphys, d.ld_cin);
 }
@@ -422,8 +449,15 @@ extern "C" int dy_wgrad_reduce_desc_fill(void* desc, const float* slabs, int nsl
   wgrad_geometry(cin_eff, cout, ld_taps ? 1 : ks, ld_taps ? 1 : stride, &cp, &op, &nci, &mtc);
   const int taps = ld_taps ? 1 : ks * ks;
   WgReduceDesc* d = reinterpret_cast<WgReduceDesc*>(desc);
-  *d = WgReduceDesc{slabs, dw, nslabs, cout, cin_eff, taps, op, cp, accumulate, ld_taps, ld_cphys, ld_cin, first_block, 0};
+  *d = WgReduceDesc{slabs, dw, nslabs, cout, cin_eff, taps, op, cp, accumulate, ld_taps, ld_cphys, ld_cin, first_block, 0, nullptr, nullptr};
   return cdiv(taps * op * cp, 64);
+}
+// a descriptor whose layer ran dy_conv_wgrad_bias: the same reduction launch also finishes that layer's bias gradient
+extern "C" int dy_wgrad_reduce_desc_bias(void* desc, const double* bias_acc, float* dbias, int c) {
+  if (!desc || !bias_acc || !dbias || c < 1 || c > 256) return DY_ERR_ARG;
+  WgReduceDesc* d = reinterpret_cast<WgReduceDesc*>(desc);
+  d->bias_acc = bias_acc; d->dbias = dbias; d->bias_c = c;
+  return DY_OK;
 }
 extern "C" int dy_wgrad_reduce_batched(const void* descs_device, int n, int total_blocks, hipStream_t stream) {
   if (n <= 0 || total_blocks <= 0 || !descs_device) return DY_ERR_ARG;
@@ -435,6 +469,8 @@ extern "C" int dy_wgrad_reduce_batched(const void* descs_device, int n, int tota
 template <int KS, int STRIDE, int NCI, int MTC>
 static int launch_wgrad(const WgArgs& a, int gx, int gy, hipStream_t s) {
   if (a.raw) hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC, 1>), dim3(gx, gy), dim3(256), 0, s, a);
+  else if (a.acc && MTC != 3) hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC, 2>), dim3(gx, gy), dim3(256), 0, s, a);
+  else if (a.acc) return DY_ERR_ARG;
   else hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC, 0>), dim3(gx, gy), dim3(256), 0, s, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
@@ -528,6 +564,15 @@ extern "C" int dy_conv_wgrad_bn(const void* x, int ldx, const void* dy, int lddy
   const WgBnHost bn{raw, draw, coef, acc, dgamma, dbeta, ldraw, count};
   return conv_wgrad_impl(x, ldx, dy, lddy, slabs, dw, n, h, w, cin, cout, ks, stride, accumulate, 0, 0, 0, stream, &bn);
 }
+// Weight gradient of a conv WITH BIAS (Detect's final nn.Conv2d, LDConv.p_conv: reference nn/modules/head.py:38-42, conv.py:356):
+// the bias gradient -- the sum of dY over the pixels -- is taken from the dY granules while they are staged and added into
+// bias_acc [DY_BN_COPIES][cout8] (fp64, zeroed by the caller); dy_wgrad_reduce_batched finishes it (dy_wgrad_reduce_desc_bias).
+extern "C" int dy_conv_wgrad_bias(const void* x, int ldx, const void* dy, int lddy, double* bias_acc, float* slabs, float* dw, int n,
+                                  int h, int w, int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream) {
+  if (!bias_acc) return DY_ERR_ARG;
+  const WgBnHost bn{nullptr, nullptr, nullptr, bias_acc, nullptr, nullptr, 0, 1.f};
+  return conv_wgrad_impl(x, ldx, dy, lddy, slabs, dw, n, h, w, cin, cout, ks, stride, accumulate, 0, 0, 0, stream, &bn);
+}
 extern "C" int dy_conv_wgrad_ld_bn(const void* x, int ldx, const void* dy, int lddy, const void* raw, int ldraw, void* draw,
                                    const float* coef, const double* acc, float* dgamma, float* dbeta, float count, float* slabs,
                                    float* dw, int n, int h, int w, int cout, int ld_cin, int ld_taps, int ld_cphys, int accumulate,
@@ -558,7 +603,8 @@ static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, flo
   if (bn) {
     if ((ks == 1 ? (double)n : 1.0) * a.Ho * a.Wo * bn->ldraw * 2.0 >= 2147483648.0) return DY_ERR_ARG;
     a.raw = (const f16*)bn->raw; a.draw = (f16*)bn->draw; a.coef = bn->coef; a.acc = bn->acc;
-    a.dgamma = bn->dgamma; a.dbeta = bn->dbeta; a.ldraw = bn->ldraw; a.cout = cout; a.count = bn->count;
+    a.dgamma = bn->dgamma; a.dbeta = bn->dbeta; a.ldraw = bn->ldraw; a.count = bn->count;
+    a.cout = bn->raw ? cout : (cout + 7) / 8 * 8;  // bias sums: one slot per physical channel of dY
   }
   a.nci_chunks = cp / (16 * nci);
   const int nco_chunks = op / (16 * mtc);

@@ -6,9 +6,10 @@
 // generic weight gradient", which moved 735 MB through the import kernel and read a 420 MB padded tensor twice for 3 real
 // channels.  Here the fp32 NCHW planes are read once per pass (315 MB), staged as fp16 in LDS.
 //
-// K = 3 * 9 = 27 (padded to 32): one MFMA k-step.  Forward: plain FMAs, one output pixel per thread (432 per pixel: 36 us of vector
-// time over the whole batch, under the ~100 us the memory traffic takes).  Weight gradient: reduction over pixels on MFMA
-// (v_mfma_f32_16x16x32_f16, A = d(raw)^T, B = im2col patch values), two N-tiles (k index 0..15, 16..31) per 32 pixels.
+// K = 3 * 9 = 27.  Forward: v_mfma_f32_16x16x16_f16 over K groups of (channel, row) x 4 columns, so a lane's operand is one 8-byte LDS
+// read (a first version with plain FMAs -- 432 per pixel, weights broadcast from LDS -- took 292 us against 277 us for the import +
+// generic conv it replaces).  Weight gradient: reduction over pixels on v_mfma_f32_16x16x32_f16, A = d(raw)^T, B = im2col patch
+// values, two N-tiles (k index 0..15, 16..31) per 32 pixels.
 #include "common.h"
 #include "dealyolo_hip.h"
 
@@ -33,31 +34,62 @@ struct StemArgs {
   float mul, count;
 };
 
-// stage the (17 x 65) x 3 input patch of one tile as fp16, zero outside the image
+// stage the (17 x 65) x 3 input patch of one tile as fp16, zero outside the image: one patch row per wave and trip (a coalesced
+// 256-byte load), no integer division
 static __device__ __forceinline__ void stem_stage(const StemArgs& a, f16 (*s_in)[STEM_IH][STEM_IP], int n, int oy0, int ox0) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
-  for (int e = threadIdx.x; e < 3 * STEM_IH * STEM_IW; e += 256) {
-    const int c = e / (STEM_IH * STEM_IW), r = e - c * (STEM_IH * STEM_IW);
-    const int y = r / STEM_IW, x = r - y * STEM_IW;
-    const int iy = iy0 + y, ix = ix0 + x;
-    float v = 0.f;
-    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = a.img[(((size_t)n * 3 + c) * a.H + iy) * a.W + ix] * a.mul;
-    s_in[c][y][x] = (f16)v;
+  const float* img = a.img + (size_t)n * 3 * a.H * a.W;
+#pragma unroll 1
+  for (int r0 = 0; r0 < 3 * STEM_IH; r0 += 4 * 4) {   // four rows per wave in flight
+    float v[4], ve[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * 4 + wave;
+      const int c = (r >= STEM_IH) + (r >= 2 * STEM_IH), y = r - c * STEM_IH, iy = iy0 + y, ix = ix0 + lane;
+      const bool rowok = r < 3 * STEM_IH && (unsigned)iy < (unsigned)a.H;
+      const float* row = img + ((size_t)c * a.H + (rowok ? iy : 0)) * a.W;
+      v[u] = (rowok && (unsigned)ix < (unsigned)a.W) ? row[ix] : 0.f;
+      ve[u] = (rowok && lane == 0 && ix0 + 64 < a.W) ? row[ix0 + 64] : 0.f;  // the 65th column
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * 4 + wave;
+      if (r < 3 * STEM_IH) {
+        const int c = (r >= STEM_IH) + (r >= 2 * STEM_IH), y = r - c * STEM_IH;
+        s_in[c][y][lane] = (f16)(v[u] * a.mul);
+        if (lane == 0) s_in[c][y][64] = (f16)(ve[u] * a.mul);
+      }
+    }
   }
 }
 
+typedef _Float16 half4_ __attribute__((ext_vector_type(4)));
+typedef uint2 __attribute__((aligned(4))) uint2_a4;
+
+// Forward on MFMA 16x16x16 (f16): K is laid out in groups of four, group g = c*3 + ky holding kx = 0..3 (kx = 3 is padding with a zero
+// weight), so one lane's four K values are four CONSECUTIVE halfs of a staged input row: one 8-byte LDS read per MFMA.  Nine groups
+// = three MFMAs per 16 pixels.  A = weights (rows = cout), B = patches (columns = pixels): a lane ends up with 4 consecutive
+// channels of one pixel.
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
-  __shared__ f16 s_in[3][STEM_IH][STEM_IP];
-  __shared__ __attribute__((aligned(16))) float s_w[27][STEM_CO];  // [k = c*9 + ky*3 + kx][cout], rounded to fp16 like every packed weight
+  __shared__ __attribute__((aligned(16))) f16 s_in[3][STEM_IH][STEM_IP];
   __shared__ float s_red[4][2][STEM_CO];
-  const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
-  for (int e = tid; e < 27 * STEM_CO; e += 256) {
-    const int k = e / STEM_CO, co = e - k * STEM_CO;
-    s_w[k][co] = (float)(f16)a.w[co * 27 + k];
-  }
-  float s1[STEM_CO], s2[STEM_CO];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
+  half4_ af[3];
+  int goff[3];  // LDS half offset of this lane's K group (clamped to the last real one: its weights are zero beyond)
 #pragma unroll
-  for (int j = 0; j < STEM_CO; ++j) s1[j] = s2[j] = 0.f;
+  for (int ks = 0; ks < 3; ++ks) {
+    const int g = ks * 4 + q, gc = g < 9 ? g : 8, c = gc / 3, ky = gc - c * 3;
+    goff[ks] = (c * STEM_IH + ky) * STEM_IP;
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) af[ks][kx] = (g < 9 && kx < 3) ? (f16)a.w[p * 27 + c * 9 + ky * 3 + kx] : (f16)0.f;
+  }
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  const f16* s_flat = &s_in[0][0][0];
+  // the padding slot kx = 3 of the last pixel reads column 65, which the staging never writes: its weight is zero, but 0 x (whatever
+  // bits LDS holds) is NaN when those bits are a NaN -- the pad columns are zeroed once
+  for (int e = tid; e < 3 * STEM_IH * (STEM_IP - STEM_IW); e += 256)
+    (&s_in[0][0][0])[(e / (STEM_IP - STEM_IW)) * STEM_IP + STEM_IW + e % (STEM_IP - STEM_IW)] = (f16)0.f;
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int bx = tile % a.tiles_x, t2 = tile / a.tiles_x;
     const int by = t2 % a.tiles_y, n = t2 / a.tiles_y;
@@ -65,48 +97,35 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
     __syncthreads();
     stem_stage(a, s_in, n, oy0, ox0);
     __syncthreads();
-    float o[STEM_CO];
 #pragma unroll
-    for (int j = 0; j < STEM_CO; ++j) o[j] = 0.f;
+    for (int nt = 0; nt < 4; ++nt) {  // wave w owns tile rows 2w, 2w+1: four 16-pixel N-tiles
+      const int ty = wave * 2 + (nt >> 1), px = (nt & 1) * 16 + p;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const float v = (float)s_in[c][2 * ty + ky][2 * tx + kx];
-          const float* wk = s_w[c * 9 + ky * 3 + kx];
-#pragma unroll
-          for (int j = 0; j < STEM_CO; j += 4) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wk + j);
-            o[j] = fmaf(v, w4[0], o[j]);
-            o[j + 1] = fmaf(v, w4[1], o[j + 1]);
-            o[j + 2] = fmaf(v, w4[2], o[j + 2]);
-            o[j + 3] = fmaf(v, w4[3], o[j + 3]);
-          }
-        }
-    const int oy = oy0 + ty, ox = ox0 + tx;
-    if (oy < a.Ho && ox < a.Wo) {
-      union { half8 h[2]; uint4 u[2]; } pk;
-#pragma unroll
-      for (int j = 0; j < STEM_CO; ++j) {
-        pk.h[j >> 3][j & 7] = (f16)o[j];
-        s1[j] += o[j];  // statistics from the fp32 values, as the ping-pong conv epilogue takes them
-        s2[j] += o[j] * o[j];
+      for (int ks = 0; ks < 3; ++ks) {
+        union { uint2 u; half4_ h; } bf;
+        const uint2_a4* src = reinterpret_cast<const uint2_a4*>(s_flat + goff[ks] + (2 * ty) * STEM_IP + 2 * px);  // 4-byte aligned
+        bf.u.x = src->x;
+        bf.u.y = src->y;
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(af[ks], bf.h, acc, 0, 0, 0);
       }
-      uint4* dst = reinterpret_cast<uint4*>(a.raw + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.ldraw);
-      dst[0] = pk.u[0];
-      dst[1] = pk.u[1];
+      const int oy = oy0 + ty, ox = ox0 + px;
+      if (oy < a.Ho && ox < a.Wo) {
+        union { half4_ h; uint2 u; } o;
+        o.h = __builtin_convertvector(acc, half4_);
+        *reinterpret_cast<uint2*>(a.raw + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.ldraw + q * 4) = o.u;
+        s1 += acc;  // statistics from the fp32 values, as the ping-pong conv epilogue takes them
+        s2 += acc * acc;
+      }
     }
   }
-  // per-workgroup sums -> one fp64 atomic add per (sum, channel) into copy blockIdx.x % DY_BN_COPIES
-  const int wave = tid >> 6, lane = tid & 63;
+  // lane (p, q) holds channels q*4 .. q*4+3: sum over the 16 pixels lanes, then over the waves, one fp64 atomic per (sum, channel)
 #pragma unroll
-  for (int j = 0; j < STEM_CO; ++j) {
-    const float r1 = wave_sum(s1[j]), r2 = wave_sum(s2[j]);
-    if (lane == 0) {
-      s_red[wave][0][j] = r1;
-      s_red[wave][1][j] = r2;
+  for (int r = 0; r < 4; ++r) {
+    const float r1 = quad16_sum(s1[r]), r2 = quad16_sum(s2[r]);
+    if (p == 0) {
+      s_red[wave][0][q * 4 + r] = r1;
+      s_red[wave][1][q * 4 + r] = r2;
     }
   }
   __syncthreads();
@@ -117,10 +136,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
   }
 }
 
-// dW[co][c][ky][kx] = sum_pix d(raw)[pix][co] * img[c][2*oy+ky-1][2*ox+kx-1], d(raw) formed from (dy, raw) on the way
+// dW[co][c][ky][kx] = sum_pix d(raw)[pix][co] * img[c][2*oy+ky-1][2*ox+kx-1], d(raw) formed from (dy, raw) on the way.
+// MFMA 16x16x32 with K = 32 pixels of one tile row: A = d(raw)^T from a channel-major LDS image (one 16-byte read), B = patch values
+// of k index kk = c*9 + ky*3 + kx (two N-tiles: kk 0..15, 16..31; 27..31 padding), eight 2-byte reads two halfs apart.
+#define STEM_DP (STEM_TH * STEM_TW + 8)   // pitch of the channel-major d(raw) image in halfs
 __global__ __launch_bounds__(256) void stem_wgrad_bn_kernel(StemArgs a) {
-  __shared__ f16 s_in[3][STEM_IH][STEM_IP];
-  __shared__ __attribute__((aligned(16))) f16 s_d[STEM_TH * STEM_TW][STEM_CO + 8];  // d(raw) of the tile, pixel-major (+16 B pad)
+  __shared__ __attribute__((aligned(16))) f16 s_in[3][STEM_IH][STEM_IP];
+  __shared__ __attribute__((aligned(16))) f16 s_d[STEM_CO][STEM_DP];
   __shared__ float s_bn[4][STEM_CO];
   __shared__ float s_acc[4][2][16][16];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
@@ -144,12 +166,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_bn_kernel(StemArgs a) {
     }
   }
   f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-  // this lane's B rows: k index kk = nt*16 + p -> (tap, c) with kk = tap*3 + c; rows 27..31 are padding
+  for (int e = tid; e < 3 * STEM_IH * (STEM_IP - STEM_IW); e += 256)  // pad columns of the staged patch: never read here, kept defined
+    (&s_in[0][0][0])[(e / (STEM_IP - STEM_IW)) * STEM_IP + STEM_IW + e % (STEM_IP - STEM_IW)] = (f16)0.f;
   int boff[2];
   bool bok[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
-    const int kk = nt * 16 + p, tap = kk / 3, c = kk - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+    const int kk = nt * 16 + p, c = kk / 9, r = kk - c * 9, ky = r / 3, kx = r - ky * 3;
     bok[nt] = kk < 27;
     boff[nt] = bok[nt] ? (c * STEM_IH + ky) * STEM_IP + kx : 0;
   }
@@ -159,32 +182,31 @@ __global__ __launch_bounds__(256) void stem_wgrad_bn_kernel(StemArgs a) {
     const int by = t2 % a.tiles_y, n = t2 / a.tiles_y;
     const int oy0 = by * STEM_TH, ox0 = bx * STEM_TW;
     __syncthreads();
+    // d(raw) of this thread's pixel (two 8-channel granules): the loads go first, the patch staging runs under them
+    const int ty = tid >> 5, tx = tid & 31, oy = oy0 + ty, ox = ox0 + tx;
+    const bool pv = oy < a.Ho && ox < a.Wo;
+    const size_t pix = pv ? ((size_t)n * a.Ho + oy) * a.Wo + ox : 0;
+    const half8 d0 = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy), d1 = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + 8);
+    const half8 r0 = *reinterpret_cast<const half8*>(a.raw + pix * a.ldraw), r1 = *reinterpret_cast<const half8*>(a.raw + pix * a.ldraw + 8);
     stem_stage(a, s_in, n, oy0, ox0);
-    {  // d(raw) of this thread's pixel (two 8-channel granules); pixels outside the map contribute zero
-      const int ty = tid >> 5, tx = tid & 31, oy = oy0 + ty, ox = ox0 + tx;
-      union { half8 h; uint4 u; } o0, o1;
-      o0.u = o1.u = make_uint4(0, 0, 0, 0);
-      if (oy < a.Ho && ox < a.Wo) {
-        const size_t pix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
-        const half8 d0 = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy), d1 = *reinterpret_cast<const half8*>(a.dy + pix * a.lddy + 8);
-        const half8 r0 = *reinterpret_cast<const half8*>(a.raw + pix * a.ldraw), r1 = *reinterpret_cast<const half8*>(a.raw + pix * a.ldraw + 8);
-        o0.h = bn_bwd_apply8<DY_ACT_SILU>(d0, r0, s_bn[0], s_bn[1], s_bn[2], s_bn[3]);
-        o1.h = bn_bwd_apply8<DY_ACT_SILU>(d1, r1, s_bn[0] + 8, s_bn[1] + 8, s_bn[2] + 8, s_bn[3] + 8);
+    {
+      half8 o0 = bn_bwd_apply8<DY_ACT_SILU>(d0, r0, s_bn[0], s_bn[1], s_bn[2], s_bn[3]);
+      half8 o1 = bn_bwd_apply8<DY_ACT_SILU>(d1, r1, s_bn[0] + 8, s_bn[1] + 8, s_bn[2] + 8, s_bn[3] + 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {  // pixels outside the map contribute zero
+        s_d[j][tid] = pv ? o0[j] : (f16)0.f;
+        s_d[8 + j][tid] = pv ? o1[j] : (f16)0.f;
       }
-      *reinterpret_cast<uint4*>(&s_d[tid][0]) = o0.u;
-      *reinterpret_cast<uint4*>(&s_d[tid][8]) = o1.u;
     }
     __syncthreads();
-    // wave w owns tile rows 2w, 2w+1 (64 pixels = two 32-pixel k-steps)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ty = wave * 2 + ks, pix0 = ty * STEM_TW + q * 8;
-      half8 af, bf[2];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) af[j] = s_d[pix0 + j][p];
+    for (int ks = 0; ks < 2; ++ks) {  // wave w owns tile rows 2w, 2w+1 (64 pixels = two 32-pixel k-steps)
+      const int row = wave * 2 + ks, pix0 = row * STEM_TW + q * 8;
+      const half8 af = *reinterpret_cast<const half8*>(&s_d[p][pix0]);
+      half8 bf[2];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const f16* b = s_in_flat + boff[nt] + (2 * ty) * STEM_IP + 2 * (q * 8);
+        const f16* b = s_in_flat + boff[nt] + (2 * row) * STEM_IP + 2 * (q * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) bf[nt][j] = bok[nt] ? b[2 * j] : (f16)0.f;
       }
@@ -201,7 +223,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_bn_kernel(StemArgs a) {
   // slab [tap][cout 16][cin 16]: entries with cin >= 3 are never read by the reduction
   float* slab = a.slabs + (size_t)blockIdx.x * 9 * 16 * 16;
   for (int e = tid; e < 27 * STEM_CO; e += 256) {
-    const int kk = e / STEM_CO, co = e - kk * STEM_CO, tap = kk / 3, c = kk - tap * 3, nt = kk >> 4, col = kk & 15;
+    const int kk = e / STEM_CO, co = e - kk * STEM_CO, c = kk / 9, tap = kk - c * 9, nt = kk >> 4, col = kk & 15;
     const float s = (s_acc[0][nt][co][col] + s_acc[1][nt][co][col]) + (s_acc[2][nt][co][col] + s_acc[3][nt][co][col]);
     slab[((size_t)tap * 16 + co) * 16 + c] = s;
   }

@@ -77,6 +77,8 @@ SIGNATURES = {
     "dy_stem_grid": (i32, [i32, i32, i32]),
     "dy_stem_forward": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
     "dy_stem_wgrad_bn": (i32, [vp, vp, i32, vp, i32, vp, vp, vp, vp, f32, vp, i32, i32, i32, f32, vp]),
+    "dy_conv_wgrad_bias": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_wgrad_reduce_desc_bias": (i32, [vp, vp, vp, i32]),
     "dy_conv_wgrad_bn": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_conv_wgrad_ld_bn": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_ldconv_sample": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -89,7 +91,7 @@ SIGNATURES = {
     "dy_bn_eval_coef": (i32, [vp, vp, vp, vp, vp, i32, f32, vp]),
     "dy_bn_act_apply": (i32, [vp, i32, vp, i32, vp, i32, vp, i64, i32, i32, vp]),
     "dy_bn_act_apply_acc": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, vp]),
-    "dy_bn_act_bwd_reduce_acc": (i32, [vp, i32, vp, i32, vp, vp, i64, i32, i32, vp]),
+    "dy_bn_act_bwd_reduce_acc": (i32, [vp, i32, vp, i32, vp, vp, i64, i32, i32, vp, i32, i32, vp]),
     "dy_bn_act_bwd_apply_acc": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "dy_bn_act_bwd_reduce": (i32, [vp, i32, vp, i32, vp, vp, i32, i64, i32, i32, ip, vp]),
     "dy_bn_bwd_finalize": (i32, [vp, i32, vp, vp, vp, i32, f32, i32, vp]),

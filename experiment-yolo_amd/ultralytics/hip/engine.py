@@ -44,6 +44,12 @@ BN_WGRAD = BN_ACC and os.environ.get("DY_BN_WGRAD", "1") != "0"
 # The stem Conv(3 -> 16, k 3, s 2) reads the fp32 NCHW image batch directly (csrc/stem.hip) instead of an imported fp16 copy padded to
 # 8 channels.  DY_STEM_DIRECT=0: import kernel + generic conv / weight-gradient kernels.
 STEM_DIRECT = BN_WGRAD and os.environ.get("DY_STEM_DIRECT", "1") != "0"
+# The gradient of a Bottleneck shortcut (= dy) stored / added by the backward reduce pass while dy streams through it, instead of by
+# a dy_add / dy_copy_slice launch.  DY_BN_RES=0: separate launch.
+BN_RES = BN_ACC and os.environ.get("DY_BN_RES", "1") != "0"
+# Bias gradients (Detect's final convs, LDConv.p_conv) summed inside the weight-gradient kernel and finished by the batched slab
+# reduction, instead of a reduce + finalize launch pair per layer.  DY_BIAS_WGRAD=0: the launch pair.
+BIAS_WGRAD = BN_ACC and os.environ.get("DY_BIAS_WGRAD", "1") != "0"
 
 
 def dev_empty(shape, dtype, device):
@@ -217,6 +223,7 @@ class ConvSpec:
         self.bn_eps, self.bn_mom = bn_eps, bn_mom
         self.wpack = self.wpack_t = self.coef = self.bwdcoef = None
         self.acc_f = self.acc_b = None  # fp64 statistic accumulators [DY_BN_COPIES][2][cout] (forward sums, backward sums)
+        self.acc_bias = None            # convs with bias: [DY_BN_COPIES][round8(cout)] sums of dY (bias gradient)
         self.gweight = self.gbias = self.gbn_w = self.gbn_b = None  # fp32 gradient views
 
 
@@ -407,6 +414,10 @@ class Engine:
             spec.bwdcoef = self.f32(2 * spec.cout)
             if spec.cout % 16 == 0:
                 spec.acc_f, spec.acc_b = self.acc_take(spec.cout), self.acc_take(spec.cout, backward=True)
+        elif spec.bias is not None:
+            cot = (spec.cout + 15) // 16
+            if not (spec.ks == 1 and cot % 3 == 0 and cot % 4 != 0):  # 48- / 96-channel outputs: the three-tile kernel has no bias sums
+                spec.acc_bias = self.acc_take((spec.cout + 7) // 8 * 8, backward=True)
         self.keep += [spec.wpack, spec.wpack_t]
 
     def pack(self, spec: ConvSpec, fold_scale=None, transposed=True):
@@ -533,7 +544,7 @@ class Engine:
             def bwd():
                 assert y.grad_ready(), f"gradient of {spec.name} output incomplete"
                 self.call("dy_bn_act_bwd_reduce_acc", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), self._acc_ready(spec.acc_b), npix,
-                          spec.cout, spec.act)
+                          spec.cout, spec.act, 0, 0, 0)
                 ns = self.L.dy_stem_grid(x.N, x.H, x.W)
                 se = 9 * 16 * 16
                 deferred = self.deferred_wgrad is not None
@@ -553,16 +564,19 @@ class Engine:
     def _conv_bn_act_bwd(self, spec, x, raw, y, res):
         assert y.grad_ready(), f"gradient of {spec.name} output incomplete"
         npix = y.npix
+        acc = BN_ACC and spec.acc_b is not None
+        rg = (0, 0, 0)
         if res is not None and res.needs_grad:
-            acc = res.grad_target()
-            if acc:
+            racc = res.grad_target()
+            if acc and BN_RES and res.C == spec.cout:  # the shortcut's gradient (= dy) rides on the reduce pass below
+                rg = (res.gptr, res.ld, racc)
+            elif racc:
                 self.call("dy_add", res.gptr, res.ld, y.gptr, y.ld, 0, 0, res.gptr, res.ld, npix, res.C)
             else:
                 self.call("dy_copy_slice", y.gptr, y.ld, res.gptr, res.ld, npix, res.C)
-        acc = BN_ACC and spec.acc_b is not None
         if acc:
             self.call("dy_bn_act_bwd_reduce_acc", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), self._acc_ready(spec.acc_b),
-                      npix, spec.cout, spec.act)
+                      npix, spec.cout, spec.act, *rg)
         else:
             part = self.scratch("partials", 2048 * 2 * spec.cout * 4 + 4096)
             n = C.c_int(0)
@@ -590,7 +604,7 @@ class Engine:
                       spec.bwdcoef.data_ptr(), npix, spec.cout, spec.act, 0)
         self._conv_bwd(spec, x, draw.data_ptr(), spec.cout, y.H, y.W)
 
-    def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0, defer=True, bn=None):
+    def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0, defer=True, bn=None, bias_acc=None):
         """weight gradient + input gradient of one convolution given d(raw output) (fp16, (N,Ho,Wo,lddy)).
         When the engine is collecting (``self.deferred_wgrad`` is a list: StepPlan's backward trace) the per-workgroup slabs of
         this layer are kept and reduced together with every other layer's by ONE ``dy_wgrad_reduce_batched`` launch at the end
@@ -601,7 +615,7 @@ class Engine:
         if deferred:
             slabs = self.transient((ns.value * se.value,), torch.float32)
             self.hold(slabs)
-            self.deferred_wgrad.append((spec, slabs, ns.value))
+            self.deferred_wgrad.append((spec, slabs, ns.value) if bias_acc is None else (spec, slabs, ns.value, bias_acc))
             dw = 0
         else:
             slabs = self.scratch("slabs", ns.value * se.value * 4)
@@ -621,6 +635,10 @@ class Engine:
             else:
                 self.call("dy_conv_wgrad_bn", *head, spec.cin, spec.cout, spec.ks, spec.stride, accumulate_w)
             dy_ptr, lddy = draw.data_ptr(), spec.cout
+        elif bias_acc is not None:
+            assert deferred
+            self.call("dy_conv_wgrad_bias", x.ptr, x.ld, dy_ptr, lddy, self._acc_ready(bias_acc), slabs.data_ptr(), dw, x.N, x.H, x.W,
+                      spec.cin, spec.cout, spec.ks, spec.stride, accumulate_w)
         elif spec.ld is not None:
             n, cphys, cin = spec.ld
             self.call("dy_conv_wgrad_ld", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), dw, x.N, x.H, x.W,
@@ -645,12 +663,15 @@ class Engine:
         sz = self.L.dy_wgrad_reduce_desc_bytes()
         host = (C.c_char * (sz * len(items)))()
         blocks = 0
-        for i, (spec, slabs, ns) in enumerate(items):
+        for i, (spec, slabs, ns, *bias) in enumerate(items):
             ld = spec.ld or (0, 0, 0)
             nb = self.L.dy_wgrad_reduce_desc_fill(C.byref(host, i * sz), slabs.data_ptr(), ns, spec.gweight.data_ptr(), spec.cin, spec.cout,
                                                   spec.ks, spec.stride, 0, ld[0], ld[1], ld[2], blocks)
             if nb < 0:
                 raise RuntimeError(f"dy_wgrad_reduce_desc_fill failed for {spec.name}")
+            if bias:  # this layer's weight-gradient kernel also summed dY: the reduction launch writes the bias gradient
+                check(self.L.dy_wgrad_reduce_desc_bias(C.byref(host, i * sz), bias[0].data_ptr(), spec.gbias.data_ptr(), (spec.cout + 7) // 8 * 8),
+                      "dy_wgrad_reduce_desc_bias")
             blocks += nb
         dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(self.device)
         self.keep.append(dev)
@@ -676,6 +697,11 @@ class Engine:
     def _conv_bias_bwd(self, spec, x, dy_ptr_fn, accumulate=0, defer=True):
         dyp, ld = dy_ptr_fn()
         Ho, Wo = self.out_hw(spec, x)
+        if (BIAS_WGRAD and defer and not accumulate and self.deferred_wgrad is not None and spec.acc_bias is not None and spec.ld is None
+                and not self.side_wgrad):
+            # the bias gradient rides on the weight-gradient kernel (sum of dY while it is staged) and the batched slab reduction
+            self._conv_bwd(spec, x, dyp, ld, Ho, Wo, bias_acc=spec.acc_bias)
+            return
         npix = x.N * Ho * Wo
         cp = spec.cout_phys
         part = self.scratch("partials", 2048 * 2 * cp * 4 + 4096)

@@ -534,9 +534,11 @@ class StepPlan:
             if L.dy_wgrad_kernel_name(ld_taps * ld_cphys, cout, 1, 1, buf, 128) == 0:
                 return buf.value.decode(), n * h * w * (ld_taps * ld_cphys + (cout + 7) // 8 * 8) * 2
         tmpl = {"dy_bn_act_apply": ("bn_act_apply_kernel<{}, false>", 9), "dy_bn_act_apply_acc": ("bn_act_apply_kernel<{}, true>", 14),
-                "dy_bn_act_bwd_reduce": ("bn_act_bwd_reduce_kernel<{}>", 9), "dy_bn_act_bwd_reduce_acc": ("bn_act_bwd_reduce_kernel<{}>", 8),
+                "dy_bn_act_bwd_reduce": ("bn_act_bwd_reduce_kernel<{}, false>", 9),
                 "dy_bn_act_bwd_apply": ("bn_act_bwd_apply_kernel<{}, false>", 10),
                 "dy_bn_act_bwd_apply_acc": ("bn_act_bwd_apply_kernel<{}, true>", 12)}
+        if name == "dy_bn_act_bwd_reduce_acc":  # <activation, shortcut gradient passed on>
+            return f"bn_act_bwd_reduce_kernel<{int(args[8])}, {'true' if args[9] else 'false'}>", 0
         if name in tmpl:
             k, i = tmpl[name]
             return k.format(int(args[i])), 0

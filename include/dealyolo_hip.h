@@ -104,6 +104,13 @@ int dy_stem_forward(const float* img_nchw, const float* weight, void* raw, int l
 int dy_stem_wgrad_bn(const float* img_nchw, const void* dy, int lddy, const void* raw, int ldraw, const float* coef,
                      const double* acc, float* dgamma, float* dbeta, float count, float* slabs, int n, int h, int w, float mul,
                      hipStream_t stream);
+/* Weight gradient of a conv with bias (Detect's final nn.Conv2d nn/modules/head.py:38-42, LDConv.p_conv nn/modules/conv.py:356) that also
+ * takes the bias gradient -- the sum of dY over the pixels -- from the dY granules it stages: added into bias_acc
+ * [DY_BN_COPIES][round8(cout)] (fp64, zeroed by the caller), finished by dy_wgrad_reduce_batched for descriptors marked with
+ * dy_wgrad_reduce_desc_bias(desc, bias_acc, dbias, round8(cout)).  Not for 48- / 96-channel outputs (DY_ERR_ARG). */
+int dy_conv_wgrad_bias(const void* x, int ldx, const void* dy, int lddy, double* bias_acc, float* slabs, float* dw, int n, int h, int w,
+                       int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream);
+int dy_wgrad_reduce_desc_bias(void* desc, const double* bias_acc, float* dbias, int c);
 /* dw == NULL in dy_conv_wgrad / dy_conv_wgrad_ld defers the slab reduction: the caller keeps that layer's slabs alive, fills one
  * descriptor per layer (host side, sizeof = dy_wgrad_reduce_desc_bytes(); returns the layer's block count, first_block = the
  * exclusive prefix sum of those counts) and reduces every layer of the backward pass in ONE launch. */
@@ -154,8 +161,10 @@ int dy_bn_act_apply(const void* x, int ldx, const void* res, int ldr, void* y, i
 int dy_bn_act_apply_acc(const void* x, int ldx, const void* res, int ldr, void* y, int ldy, const double* acc,
                         const float* gamma, const float* beta, float* running_mean, float* running_var, float* coef,
                         long npix, int C, int act, float count, float eps, float momentum, hipStream_t stream);
+/* res_grad (may be NULL): gradient of a residual operand added after the activation (Bottleneck shortcut, nn/modules/block.py:333-335)
+ * -- it equals dy, and is stored (res_accumulate 0) or added (1) while dy streams through, instead of by a pass of its own */
 int dy_bn_act_bwd_reduce_acc(const void* dy, int lddy, const void* x, int ldx, const float* coef, double* acc, long npix,
-                             int C, int act, hipStream_t stream);
+                             int C, int act, void* res_grad, int ldrg, int res_accumulate, hipStream_t stream);
 int dy_bn_act_bwd_apply_acc(const void* dy, int lddy, const void* x, int ldx, void* dx, int lddx, const float* coef,
                             const double* acc, float* dgamma, float* dbeta, long npix, int C, int act, float count,
                             hipStream_t stream);

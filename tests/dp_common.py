@@ -6,7 +6,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = os.path.join(ROOT, "experiment-yolo_amd", "ultralytics", "cfg", "models", "yolov8n-ASF-P2P2.yaml")
-STEPS = [1, 2, 1]  # micro-batches accumulated before each optimizer step
+STEPS = [int(v) for v in os.environ.get("DY_TEST_DP_STEPS", "1,2,1").split(",")]  # micro-batches accumulated before each optimizer step
 
 
 def build_model():

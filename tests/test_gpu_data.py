@@ -89,17 +89,26 @@ def test_plan_recorded_for_u8_batches_equals_the_float_plan():
     n = 12
     lab = dict(batch_idx=torch.arange(B).repeat_interleave(3).float(), cls=torch.randint(0, 6, (n, 1), generator=g).float(),
                bboxes=torch.cat([torch.rand(n, 2, generator=g) * 0.6 + 0.2, torch.rand(n, 2, generator=g) * 0.2 + 0.05], 1))
+    from ultralytics.hip import engine as E
     out = []
-    for fmt in ("u8", "f32"):
-        torch.manual_seed(0)
-        m = DetectionModel("yolov8n-ASF-P2P2.yaml", verbose=False).cuda().train()
-        plan = StepPlan(m, B, S, nmax=8, optimizer="SGD", use_graph=False)
-        batch = {k: v.cuda() for k, v in lab.items()}
-        batch["img"] = img.cuda() if fmt == "u8" else (img.permute(0, 3, 1, 2).float() / 255).cuda()
-        plan.forward_backward(batch)
-        torch.cuda.synchronize()
-        out.append((plan.crit.scalars.clone(), plan.rt.flat_g.clone()))
+    for fmt in ("u8", "f32", "f32-direct"):
+        # a float batch reaches the stem through the import kernel (same bits as the uint8 route) or -- the default -- is read by
+        # the direct stem kernels (csrc/stem.hip): the same sums in another order, i.e. fp16 rounding noise on the stem output
+        direct, E.STEM_DIRECT = E.STEM_DIRECT, fmt == "f32-direct" and E.STEM_DIRECT
+        try:
+            torch.manual_seed(0)
+            m = DetectionModel("yolov8n-ASF-P2P2.yaml", verbose=False).cuda().train()
+            plan = StepPlan(m, B, S, nmax=8, optimizer="SGD", use_graph=False, init_scale=1024.0)
+            batch = {k: v.cuda() for k, v in lab.items()}
+            batch["img"] = img.cuda() if fmt == "u8" else (img.permute(0, 3, 1, 2).float() / 255).cuda()
+            plan.forward_backward(batch)
+            torch.cuda.synchronize()
+            out.append((plan.crit.scalars.clone(), plan.rt.flat_g.clone()))
+        finally:
+            E.STEM_DIRECT = direct
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert float((out[2][0][5:9] - out[0][0][5:9]).abs().max() / out[0][0][5:9].abs().max()) < 2e-3       # loss items
+    assert float((out[2][1] - out[0][1]).norm() / out[0][1].norm()) < 3e-2                                   # gradients
     with pytest.raises(TypeError):  # the recorded launch list reads ONE input format (this plan: float NCHW -> fine; u8 plan: not)
         plan_u8 = StepPlan(m, B, S, nmax=8, optimizer="SGD", use_graph=False)
         lab_d = {k: v.cuda() for k, v in lab.items()}

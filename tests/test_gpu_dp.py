@@ -40,9 +40,19 @@ def _emulate(world, b):
     return rt.flat_p.cpu(), rt.flat_b.cpu(), plan.ema.cpu()
 
 
-def test_two_rank_step_equals_the_single_process_emulation(tmp_path):
+@pytest.mark.parametrize("steps", ["1,1,1", "1,2,1"])
+def test_two_rank_step_equals_the_single_process_emulation(tmp_path, steps, monkeypatch):
+    """steps = micro-batches per optimizer step.  Without accumulation the two ranks' sum g0 + g1 has ONE order: the replicas must
+    equal the emulation bit for bit.  With an accumulating step the rank-wise sum (a + b) + (c + d) and the emulation's chain
+    ((a + b) + c) + d differ by fp32 rounding (measured 4e-9 on the weights right after such a step); the step that follows runs on
+    fp16 activations, which turn that into isolated last-bit flips: 5e-10 ... 1.5e-6 depending on the trajectory (round 3: the same
+    schedule gave 5e-10 with the imported stem input and 1.5e-6 with the direct stem, 4e-9 for '2,1' either way)."""
+    import dp_common
     world, b = 2, 2
     port = 29500 + os.getpid() % 2000
+    monkeypatch.setenv("DY_TEST_DP_STEPS", steps)
+    monkeypatch.setattr(dp_common, "STEPS", [int(v) for v in steps.split(",")])
+    monkeypatch.setattr(sys.modules[__name__], "STEPS", dp_common.STEPS)
     env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -56,4 +66,6 @@ def test_two_rank_step_equals_the_single_process_emulation(tmp_path):
     db = float((ranks[0]["b"] - bufs).abs().max() / bufs.abs().max())
     de = float((ranks[0]["ema"] - ema).abs().max() / ema.abs().max())
     print(f"2 ranks vs emulation: weights {dp:.2e}, buffers {db:.2e}, EMA {de:.2e} (relative to the largest entry)")
-    assert dp < 1e-6 and db < 1e-6 and de < 1e-6
+    if "2" not in steps:
+        assert dp == 0.0 and db == 0.0 and de == 0.0
+    assert dp < 1e-5 and db < 5e-5 and de < 1e-5

@@ -179,7 +179,7 @@ def test_bn_accumulator_path_equals_finalize_path(cin, cout, ks, s, H, W, act):
                      cout, ks, s, 1, 0, 0, 1 | 32, None)
             eng.call("dy_bn_act_apply_acc", raw.data_ptr(), cout, 0, 0, y.data_ptr(), cout, af.data_ptr(), gamma.data_ptr(),
                      beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), coef.data_ptr(), npix, cout, act, float(npix), 1e-3, 0.03)
-            eng.call("dy_bn_act_bwd_reduce_acc", dy.ptr, dy.ld, raw.data_ptr(), cout, coef.data_ptr(), ab.data_ptr(), npix, cout, act)
+            eng.call("dy_bn_act_bwd_reduce_acc", dy.ptr, dy.ld, raw.data_ptr(), cout, coef.data_ptr(), ab.data_ptr(), npix, cout, act, 0, 0, 0)
             eng.call("dy_bn_act_bwd_apply_acc", dy.ptr, dy.ld, raw.data_ptr(), cout, dx.data_ptr(), cout, coef.data_ptr(),
                      ab.data_ptr(), dg.data_ptr(), db.data_ptr(), npix, cout, act, float(npix))
         else:
@@ -207,7 +207,7 @@ def test_bn_accumulator_path_equals_finalize_path(cin, cout, ks, s, H, W, act):
     # pass writes, the same weight / input gradients as that pass followed by dy_conv_wgrad, and the BatchNorm parameter gradients
     from types import SimpleNamespace as NS
     af = torch.zeros(DY_BN_COPIES * 2 * cout, dtype=torch.float64, device="cuda")
-    eng.call("dy_bn_act_bwd_reduce_acc", dy.ptr, dy.ld, a["raw"].data_ptr(), cout, a["coef"].data_ptr(), af.data_ptr(), npix, cout, act)
+    eng.call("dy_bn_act_bwd_reduce_acc", dy.ptr, dy.ld, a["raw"].data_ptr(), cout, a["coef"].data_ptr(), af.data_ptr(), npix, cout, act, 0, 0, 0)
     if act == 1:
         xa.needs_grad = True
         ref_dx = a["dx"].clone()
@@ -409,7 +409,7 @@ def test_direct_stem_equals_import_plus_generic_conv(N, H, W):
                      0, 0, 1 | 32, None)
         eng.call("dy_bn_act_apply_acc", raw.data_ptr(), 16, 0, 0, y.data_ptr(), 16, af.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                  rm.data_ptr(), rv.data_ptr(), coef.data_ptr(), npix, 16, 1, float(npix), 1e-3, 0.03)
-        eng.call("dy_bn_act_bwd_reduce_acc", dy.ptr, dy.ld, raw.data_ptr(), 16, coef.data_ptr(), ab.data_ptr(), npix, 16, 1)
+        eng.call("dy_bn_act_bwd_reduce_acc", dy.ptr, dy.ld, raw.data_ptr(), 16, coef.data_ptr(), ab.data_ptr(), npix, 16, 1, 0, 0, 0)
         sp.gweight.zero_()
         if direct:
             ns = eng.L.dy_stem_grid(N, H, W)
