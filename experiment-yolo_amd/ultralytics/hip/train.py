@@ -533,7 +533,7 @@ class StepPlan:
             n, h, w, cout, ld_cin, ld_taps, ld_cphys = args[6:13]
             if L.dy_wgrad_kernel_name(ld_taps * ld_cphys, cout, 1, 1, buf, 128) == 0:
                 return buf.value.decode(), n * h * w * (ld_taps * ld_cphys + (cout + 7) // 8 * 8) * 2
-        tmpl = {"dy_bn_act_apply": ("bn_act_apply_kernel<{}, false>", 9), "dy_bn_act_apply_acc": ("bn_act_apply_kernel<{}, true>", 14),
+        tmpl = {"dy_bn_act_apply": ("bn_act_apply_kernel<{}, false, false>", 9), "dy_bn_act_apply_acc": ("bn_act_apply_kernel<{}, true, " + ("false" if os.environ.get("DY_SILU_FAST") == "0" else "true") + ">", 14),
                 "dy_bn_act_bwd_reduce": ("bn_act_bwd_reduce_kernel<{}, false>", 9),
                 "dy_bn_act_bwd_apply": ("bn_act_bwd_apply_kernel<{}, false>", 10),
                 "dy_bn_act_bwd_apply_acc": ("bn_act_bwd_apply_kernel<{}, true>", 12)}

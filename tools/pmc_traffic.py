@@ -6,7 +6,7 @@
                                        FETCH_SIZE / WRITE_SIZE passes ((2*FETCH_SIZE + WRITE_SIZE)*1024: MI355X_MICROARCH.md)
   profiles/<tag>_mfma_lds_pmc.csv      per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD) and
                                        SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, averaged over its dispatches
-usage: pmc_traffic.py <tag> [steps-in-the-pmc-runs = 3]     (e.g. r02a)"""
+usage: pmc_traffic.py <tag> [steps-in-the-pmc-runs: taken from the dispatch count of the once-per-step pack kernel]     (e.g. r03a)"""
 import csv
 import json
 import os
@@ -45,6 +45,12 @@ def counters(sub, prefix):
 
 
 fetch, write = counters("prof_fetch", "f"), counters("prof_write", "w")
+# bench.py runs more steps than --steps + --warmup (loss-scale settling, the second loss mode): the weight pack is launched exactly
+# once per step, so its dispatch count IS the number of steps a pass executed
+for once in ("pack_weights_batched_kernel",):
+    n_once = [v.get(c, [0.0, 0])[1] for v, c in ((fetch.get(once, {}), "FETCH_SIZE"), (write.get(once, {}), "WRITE_SIZE")) if v]
+    if n_once:
+        pmc_steps = max(n_once)
 by_kernel, per_step, n_disp = {}, {}, {}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, {}).get("FETCH_SIZE", [0.0, 1]), write.get(k, {}).get("WRITE_SIZE", [0.0, 1])
