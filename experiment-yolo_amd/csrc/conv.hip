@@ -31,6 +31,13 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int npix;       // FLAT (1x1) only: N*Ho*Wo
   int xcd_map;    // 1: workgroups of one XCD (blockIdx.x % 8) own a contiguous band of tiles, so halo rows meet in one L2
+  // RED (input-gradient launches only): y is the COMPLETE gradient w.r.t. the activated output of a Conv (conv + BatchNorm + SiLU) --
+  // this launch is its only writer -- so the first pass of that layer's BatchNorm backward (sums of g = dy * act'(z) and g * xhat,
+  // bn_act_bwd_reduce_kernel) runs here, in the epilogue, on the values being stored, and is added into racc
+  const f16* rraw;     // (N, Ho, Wo, ldrraw) raw conv output of that layer's forward
+  const float* rcoef;  // [4][rC]: scale, shift, mean, invstd
+  double* racc;        // [DY_BN_COPIES][2][rC]
+  int ldrraw, rC;
 };
 
 
@@ -285,6 +292,34 @@ static __device__ __forceinline__ int swz(int pixel, int part) {
   return pixel * ps_bytes(CC, STRIDE) + (part << 4);
 }
 
+
+// The cout group's packed weights into LDS (rows of 64 B, 16-byte slots XOR-swizzled by row group).  All of a thread's loads are
+// issued before the first store: the 64-wide 3x3 set (73.7 KB) is nine 16-byte loads per thread, and as a plain load -> store loop
+// they were nine DEPENDENT round trips to L2 -- in-kernel stamps put 27 % of a 40x40 launch (8.9 k of 32 k cycles) and ~10 us of every
+// launch before the first MFMA.
+template <int NTHR>
+static __device__ __forceinline__ void weights_to_lds(char* sw, const f16* w, int wrows) {
+  const uint4* src = reinterpret_cast<const uint4*>(w);
+  const int total = wrows * 4;
+  constexpr int WB = 10;
+  for (int c0 = threadIdx.x; c0 < total; c0 += NTHR * WB) {
+    uint4 t[WB];
+#pragma unroll
+    for (int k = 0; k < WB; ++k) {
+      const int c = c0 + k * NTHR;
+      t[k] = c < total ? src[c] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < WB; ++k) {
+      const int c = c0 + k * NTHR;
+      if (c < total) {
+        const int row = c >> 2, qq = c & 3;
+        *reinterpret_cast<uint4*>(sw + row * 64 + ((qq ^ ((0 - (row >> 2)) & 3)) << 4)) = t[k];
+      }
+    }
+  }
+}
+
 #ifdef DY_CONV_TIMING
 __device__ unsigned long long dy_timing[8];
 extern "C" int dy_conv_timing_fetch(unsigned long long* out, int reset) {
@@ -320,13 +355,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_wlds_kernel(ConvArgs a, int
   char* const st = dsm + wrows * 64;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(a.w + (size_t)blockIdx.y * wrows * 32);
-    for (int c = tid; c < wrows * 4; c += NTHR) {
-      const int row = c >> 2, qq = c & 3;
-      *reinterpret_cast<uint4*>(sw + row * 64 + ((qq ^ ((0 - (row >> 2)) & 3)) << 4)) = src[c];
-    }
-  }
+  weights_to_lds<NTHR>(sw, a.w + (size_t)blockIdx.y * wrows * 32, wrows);
   constexpr int PS = ps_bytes(CC, STRIDE);
   // LDS byte offset of this lane's pixel in each N-tile
   int boff[NT];
@@ -600,7 +629,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_wlds_kernel(ConvArgs a, int
 // slot and the vector/memory work runs beside it.
 //   slot s:  group g computes chunk j = (s-g)/2 when s-g is even, and runs MEM(j) with j = (s-g-1)/2 when it is odd.
 //   MEM(j):  epilogue of j's tile if j was its last chunk; LDS write of chunk j+1; global prefetch of chunk j+2.
-template <int CC, int MT, int KS, int STRIDE, int TROWS>
+template <int CC, int MT, int KS, int STRIDE, int TROWS, bool REDK = false>
 __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntiles) {
 #ifdef DY_CONV_TIMING
   unsigned long long tacc[8] = {}, tlast = clock64();
@@ -633,17 +662,45 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
   char* const st = dsm + wrows * 64 + g * TILE_BYTES;
   char* const xs = dsm + wrows * 64 + 2 * TILE_BYTES + wave * (16 * XROW);
   float* const bsh = reinterpret_cast<float*>(dsm + wrows * 64 + 2 * TILE_BYTES + 8 * (16 * XROW));  // this cout group's bias
+  float* const rcf = bsh + 16 * MT;  // RED: [scale | shift] of this cout group's channels
   if (tid < 16 * MT) {
     const int c = blockIdx.y * (16 * MT) + tid;
     bsh[tid] = ((a.epi & DY_EPI_BIAS) && c < a.cout) ? a.bias[c] : 0.f;
-  }
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(a.w + (size_t)blockIdx.y * wrows * 32);
-    for (int c = tid; c < wrows * 4; c += 512) {
-      const int row = c >> 2, qq = c & 3;
-      *reinterpret_cast<uint4*>(sw + row * 64 + ((qq ^ ((0 - (row >> 2)) & 3)) << 4)) = src[c];
+    if (REDK) {
+      rcf[tid] = c < a.rC ? a.rcoef[c] : 0.f;
+      rcf[16 * MT + tid] = c < a.rC ? a.rcoef[a.rC + c] : 0.f;
     }
   }
+  f32x2 rsg[4], rsgx[4];  // RED: this lane's running sums over its 8-channel piece (dead registers in every other variant)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rsg[j] = rsgx[j] = (f32x2){0.f, 0.f};
+  // RED: the raw conv output of the layer whose gradient this launch writes, for the pixels / channel pieces of this lane's stores in
+  // the NEXT tile this group will finish.  Requested one tile ahead (right after the previous epilogue), so that the HBM latency
+  // lies under a compute slot: requested inside the epilogue it was exposed once per tile and tripled the kernel (measured).
+  constexpr int R_PPR = (4 * NC * 2) / 16, R_PIXPASS = 64 / R_PPR, R_NPASS = R_PIXPASS >= 16 ? 1 : 16 / R_PIXPASS;
+  union RU4 { uint4 u; half2_ h[4]; };
+  RU4 rw[REDK ? NT : 1][REDK ? R_NPASS : 1];
+  auto red_prefetch = [&](const auto& tc) {
+    const int r_dpix = lane / R_PPR, r_piece = lane % R_PPR;
+    const int n = tc.n, oy0 = tc.by * TH, ox0 = tc.bx * TW, pix0 = tc.bx * HW_;
+    const int row0 = FLAT ? 0 : oy0 + wgs * TROWS;
+    const long tbase = FLAT ? (long)(pix0 + wgs * (NT * 16)) * a.ldrraw : ((long)(n * a.Ho + row0) * a.Wo + ox0) * a.ldrraw;
+    const char* const rbase = reinterpret_cast<const char*>(a.rraw) + tbase * 2;
+    const unsigned rloff = (unsigned)((r_dpix * a.ldrraw + blockIdx.y * (16 * MT) + r_piece * 8) * 2);
+    const int collim = FLAT ? a.npix - (pix0 + wgs * (NT * 16)) : a.Wo - ox0;
+    const bool chok = (int)(blockIdx.y * (16 * MT) + r_piece * 8) < a.rC;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ps = 0; ps < R_NPASS; ++ps) {
+        const int c0 = (FLAT ? t * 16 : (t & 1) * 16) + ps * R_PIXPASS;
+        const bool rowok = FLAT ? true : row0 + (t >> 1) < a.Ho;
+        const bool valid = rowok && chok && r_dpix < 16 && c0 + r_dpix < collim;
+        const long soff = FLAT ? (long)c0 * a.ldrraw : ((long)(t >> 1) * a.Wo + c0) * a.ldrraw;
+        rw[REDK ? t : 0][REDK ? ps : 0].u = *reinterpret_cast<const uint4*>(valid ? rbase + soff * 2 + rloff : reinterpret_cast<const char*>(a.rraw));
+      }
+  };
+  weights_to_lds<512>(sw, a.w + (size_t)blockIdx.y * wrows * 32, wrows);
   // LDS byte offset of this lane's pixel in N-tile 0; N-tile t lies a compile-time distance further (bdelta)
   const int boff0 = FLAT ? (wg * (NT * 16) + p) * PS : ((wg * TROWS * STRIDE) * HW_ + p * STRIDE) * PS;
   auto bdelta = [](int t) { return FLAT ? t * 16 * PS : (((t >> 1) * STRIDE) * HW_ + (t & 1) * 16 * STRIDE) * PS; };
@@ -761,6 +818,8 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
     if (++ph == a.nch) { ph = 0; tile_next(pcur); }
   };
   advance_pf();  // chunk 0 in flight while the weights land
+  int etiles_left = ntg;  // RED: tiles of this group whose epilogue is still to come
+  if (REDK && etiles_left > 0) red_prefetch(ecur);
 
   const int e4 = a.epi & (DY_EPI_ACCUM | DY_EPI_STATS | DY_EPI_BIAS | DY_EPI_SILU);
   const bool fast_epi = !(a.epi & DY_EPI_F32OUT) && a.cout % 8 == 0 && !(a.ldy & 7) &&
@@ -843,9 +902,9 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
           //    store is 64 separate 16-byte writes per instruction (measured: 21 % of the kernel).  Each N-tile is
           //    therefore turned through a per-wave LDS scratch so that PPR consecutive lanes write one pixel's whole
           //    channel block: full-line stores, 8x fewer write requests.
-          auto fast = [&](auto acc_tag, auto stats_tag, auto bias_tag, auto silu_tag) {
+          auto fast = [&](auto acc_tag, auto stats_tag, auto bias_tag, auto silu_tag, auto red_tag) {
             constexpr bool ACCUM = decltype(acc_tag)::value, STATS = decltype(stats_tag)::value;
-            constexpr bool BIAS = decltype(bias_tag)::value, SILU = decltype(silu_tag)::value;
+            constexpr bool BIAS = decltype(bias_tag)::value, SILU = decltype(silu_tag)::value, RED = decltype(red_tag)::value;
             constexpr int PPR = RB / 16;                       // 16-byte pieces per pixel row
             constexpr int PIXPASS = 64 / PPR;                  // pixels one store instruction covers
             constexpr int NPASS = PIXPASS >= 16 ? 1 : 16 / PIXPASS;
@@ -949,6 +1008,22 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
                     v.h[k] = __builtin_convertvector(__builtin_convertvector(v.h[k], f32x2) + __builtin_convertvector(o[ACCUM ? t : 0][ps].h[k], f32x2), half2_);
                 }
                 if (valid && !(a.epi & DY_EPI_DEBUG_NOSTORE)) *yp = v.u;
+                if (RED) {  // g = dy * act'(x * scale + shift) on the fp16 values just stored; sums of g and g * x per channel
+                  // (lanes without a destination hold whatever the transpose scratch had: selected away, never multiplied away)
+                  const bool use = valid && (int)(blockIdx.y * (16 * MT) + piece * 8) < a.rC;
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) {
+                    const f32x2 x = __builtin_convertvector(rw[RED ? t : 0][RED ? ps : 0].h[k], f32x2);
+                    const f32x2 sc2 = *reinterpret_cast<const f32x2*>(rcf + piece * 8 + 2 * k);
+                    const f32x2 sh2 = *reinterpret_cast<const f32x2*>(rcf + 16 * MT + piece * 8 + 2 * k);
+                    f32x2 gg = __builtin_convertvector(v.h[k], f32x2) * act_grad2<DY_ACT_SILU>(__builtin_elementwise_fma(x, sc2, sh2));
+                    f32x2 gx = gg * x;
+                    gg = use ? gg : (f32x2){0.f, 0.f};
+                    gx = use ? gx : (f32x2){0.f, 0.f};
+                    rsg[k] += gg;
+                    rsgx[k] += gx;
+                  }
+                }
               }
             }
           };
@@ -981,11 +1056,12 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             constexpr std::true_type Y{};
             constexpr std::false_type N_{};
             const int e = a.epi & (DY_EPI_ACCUM | DY_EPI_STATS | DY_EPI_BIAS | DY_EPI_SILU);
-            if (e == DY_EPI_ACCUM) fast(Y, N_, N_, N_);
-            else if (e == DY_EPI_STATS) fast(N_, Y, N_, N_);
-            else if (e == (DY_EPI_STATS | DY_EPI_BIAS)) fast(N_, Y, Y, N_);
-            else if (e == (DY_EPI_BIAS | DY_EPI_SILU)) fast(N_, N_, Y, Y);
-            else fast(N_, N_, N_, N_);
+            if (e == DY_EPI_ACCUM) fast(Y, N_, N_, N_, N_);
+            else if (e == DY_EPI_STATS) fast(N_, Y, N_, N_, N_);
+            else if (e == (DY_EPI_STATS | DY_EPI_BIAS)) fast(N_, Y, Y, N_, N_);
+            else if (e == (DY_EPI_BIAS | DY_EPI_SILU)) fast(N_, N_, Y, Y, N_);
+            else if (REDK) fast(N_, N_, N_, N_, std::integral_constant<bool, REDK>{});
+            else fast(N_, N_, N_, N_, N_);
           }
         } else {
 #pragma unroll
@@ -1049,6 +1125,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             }
           }
         }
+        if (REDK && --etiles_left > 0) red_prefetch(ecur);  // ecur is already the next tile this group finishes
       }
     }
     TSTAMP(2)
@@ -1067,6 +1144,44 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
   }
 #endif
 
+  if (REDK) {
+    // lanes with the same channel piece (lane % PPR) -> one value; waves -> LDS; then per channel sum(g * xhat) = (sum(g x) - mean sum(g))
+    // * invstd and one fp64 atomic add per (sum, channel) into copy blockIdx.x % DY_BN_COPIES of the layer's accumulator
+    constexpr int PPR = (4 * NC * 2) / 16;
+    float* red = reinterpret_cast<float*>(dsm + wrows * 64);  // [8 waves][2][16*MT]
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float u = rsg[k][e], w = rsgx[k][e];
+#pragma unroll
+        for (int msk = PPR; msk < 64; msk <<= 1) {
+          u += __shfl_xor(u, msk, 64);
+          w += __shfl_xor(w, msk, 64);
+        }
+        if (lane < PPR) {
+          red[(wave * 2 + 0) * (16 * MT) + lane * 8 + 2 * k + e] = u;
+          red[(wave * 2 + 1) * (16 * MT) + lane * 8 + 2 * k + e] = w;
+        }
+      }
+    __syncthreads();
+    if (tid < 16 * MT) {
+      const int c = blockIdx.y * (16 * MT) + tid;
+      if (c < a.rC) {
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          sg += red[(w * 2 + 0) * (16 * MT) + tid];
+          sgx += red[(w * 2 + 1) * (16 * MT) + tid];
+        }
+        sgx = (sgx - a.rcoef[2 * a.rC + c] * sg) * a.rcoef[3 * a.rC + c];
+        double* dst = a.racc + (size_t)(blockIdx.x % DY_BN_COPIES) * 2 * a.rC;
+        unsafeAtomicAdd(dst + c, (double)sg);
+        unsafeAtomicAdd(dst + a.rC + c, (double)sgx);
+      }
+    }
+  }
   if (a.epi & DY_EPI_STATS) {
     float* red = reinterpret_cast<float*>(dsm + wrows * 64);
     if (true) {
@@ -1355,13 +1470,7 @@ __global__ __launch_bounds__(512) void conv_mfma_dg2_kernel(ConvArgs a, int ntil
   const int wgs = __builtin_amdgcn_readfirstlane(wg);
   char* const st = dsm + wrows * 64 + g * TILE_BYTES;
   char* const xs = dsm + wrows * 64 + 2 * TILE_BYTES + wave * (16 * XROW);
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(a.w + (size_t)blockIdx.y * wrows * 32);
-    for (int c = tid; c < wrows * 4; c += 512) {
-      const int row = c >> 2, qq = c & 3;
-      *reinterpret_cast<uint4*>(sw + row * 64 + ((qq ^ ((0 - (row >> 2)) & 3)) << 4)) = src[c];
-    }
-  }
+  weights_to_lds<512>(sw, a.w + (size_t)blockIdx.y * wrows * 32, wrows);
   const char* const stb = st + (wg * HW_ + p) * PS + q * 16;
   const int aoff = p * 64 + ((q ^ ((0 - (p >> 2)) & 3)) << 4);
 
@@ -1560,7 +1669,7 @@ static size_t pp_lds_bytes(int cc, int mt, int ks, int stride, int nch, int trow
   if (tile < red) tile = red;
   const size_t wts = (size_t)nch * ((ks * ks * cc + 31) / 32) * 16 * mt * 64;
   const size_t xpose = 8 * 16 * (size_t)(32 * mt + 16);  // per-wave store-transpose scratch
-  return 2 * tile + wts + xpose + 16 * mt * 4;          // + this cout group's bias
+  return 2 * tile + wts + xpose + 3 * 16 * mt * 4;      // + this cout group's bias + the RED coefficient table (scale | shift)
 }
 // rows per wave of the ping-pong kernel for a geometry (0 = does not fit: v3/v1 take it)
 static int pp_trows(int cc, int mt, int ks, int stride, int nch) {
@@ -1579,10 +1688,14 @@ static int pp_grid(int cc, int mt, int ks, int stride, int nch, int trows, int n
   return want < cap ? want : cap;
 }
 
-template <int CC, int MT, int KS, int STRIDE, int TR>
+template <int CC, int MT, int KS, int STRIDE, int TR, bool REDK = false>
 static int launch_pp(const ConvArgs& a, int grid_y, hipStream_t s) {
+  if (!REDK && a.racc) {  // the epilogue that also runs a BatchNorm backward reduce: its own instantiation (stride-1 dgrads only), so
+    if constexpr (STRIDE == 1) return launch_pp<CC, MT, KS, 1, TR, true>(a, grid_y, s);  // that its registers are not every launch's problem
+    return DY_ERR_ARG;
+  }
   static bool attr_set = false;
-  auto kern = conv_mfma_pp_kernel<CC, MT, KS, STRIDE, TR>;
+  auto kern = conv_mfma_pp_kernel<CC, MT, KS, STRIDE, TR, REDK>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DY_WLDS_BUDGET) != hipSuccess)
       return DY_ERR_LAUNCH;
@@ -1656,9 +1769,37 @@ static int launch_dg2(const ConvArgs& a, int grid_y, hipStream_t s) {
   return DY_OK;
 }
 
+struct RedHost { const void* raw; int ldraw; const float* coef; double* acc; int C; };
+static int conv_forward_impl(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                             float* partials, int n, int h, int w, int cin, int cout, int ks, int stride, int dil,
+                             int out_h, int out_w, int epi, int* num_partials, hipStream_t stream, const RedHost* red);
 extern "C" int dy_conv_forward(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                                float* partials, int n, int h, int w, int cin, int cout, int ks, int stride, int dil,
                                int out_h, int out_w, int epi, int* num_partials, hipStream_t stream) {
+  return conv_forward_impl(x, ldx, w_packed, bias, y, ldy, partials, n, h, w, cin, cout, ks, stride, dil, out_h, out_w, epi, num_partials,
+                           stream, nullptr);
+}
+// 1 when dy_conv_input_grad_red can take this (stride-1) input-gradient geometry: the ping-pong kernel with its transposing epilogue
+extern "C" int dy_conv_red_supported(int cin, int cout, int ks) {
+  int cp, op, cc, nch, mt, ng, kst, pe;
+  if (dy_conv_geometry(cin, cout, ks, 1, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return 0;
+  return (cin == cp && cout % 8 == 0 && pp_trows(cc, mt, ks, 1, nch) != 0) ? 1 : 0;
+}
+// The input gradient of a stride-1 convolution (dy_conv_forward over the transposed pack, no epilogue flags) that is the ONLY writer of
+// the gradient it produces -- the gradient w.r.t. the activated output of a Conv (conv + BatchNorm + SiLU) -- and therefore also runs
+// the first pass of that Conv's BatchNorm backward on the values it stores: sums of g = dy * silu'(raw * scale + shift) and g * xhat,
+// added into acc [DY_BN_COPIES][2][C] (what dy_bn_act_bwd_reduce_acc would compute from the stored tensor in a pass of its own).
+extern "C" int dy_conv_input_grad_red(const void* dy, int lddy, const void* w_packed_t, void* dx, int lddx, int n, int h, int w, int cin,
+                                      int cout, int ks, const void* raw, int ldraw, const float* coef, double* acc, int C,
+                                      hipStream_t stream) {
+  if (!raw || !coef || !acc || C != cout || (ldraw & 7) || ((uintptr_t)raw & 15) || !dy_conv_red_supported(cin, cout, ks) || (lddx & 7))
+    return DY_ERR_ARG;
+  const RedHost red{raw, ldraw, coef, acc, C};
+  return conv_forward_impl(dy, lddy, w_packed_t, nullptr, dx, lddx, nullptr, n, h, w, cin, cout, ks, 1, 1, 0, 0, 0, nullptr, stream, &red);
+}
+static int conv_forward_impl(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                             float* partials, int n, int h, int w, int cin, int cout, int ks, int stride, int dil,
+                             int out_h, int out_w, int epi, int* num_partials, hipStream_t stream, const RedHost* red) {
   int cp, op, cc, nch, mt, ng, kst, pe;
   if (dy_conv_geometry(cin, cout, ks, stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return DY_ERR_ARG;
   if (cin != cp || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return DY_ERR_ALIGN;
@@ -1680,6 +1821,9 @@ extern "C" int dy_conv_forward(const void* x, int ldx, const void* w_packed, con
     a.Wo = out_w;
   }
   a.cout = cout; a.nch = nch; a.epi = epi; a.dil = dil;
+  if (red) {
+    a.rraw = (const f16*)red->raw; a.ldrraw = red->ldraw; a.rcoef = red->coef; a.racc = red->acc; a.rC = red->C;
+  }
   static const bool xcd_map = getenv("DY_CONV_NO_XCDMAP") == nullptr;
   a.xcd_map = xcd_map && ks == 3;  // 1x1 tiles have no halo to share
   int gx;
@@ -1713,7 +1857,7 @@ extern "C" int dy_conv_kernel_name(int cin, int cout, int ks, int stride, char* 
   if (!out || cap < 8 || dy_conv_geometry(cin, cout, ks, stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return DY_ERR_ARG;
   const int pp = pp_trows(cc, mt, ks, stride, nch);
   if (pp) {
-    snprintf(out, cap, "conv_mfma_pp_kernel<%d, %d, %d, %d, %d>", cc, mt, ks, stride, pp);
+    snprintf(out, cap, "conv_mfma_pp_kernel<%d, %d, %d, %d, %d, false>", cc, mt, ks, stride, pp);  // "true": dy_conv_input_grad_red
     return DY_OK;
   }
   const int cfg = (g_force_v1 || (cc == 64 && stride == 2)) ? 0 : v3_trows(cc, mt, ks, stride, nch);

@@ -64,6 +64,8 @@ SIGNATURES = {
     "dy_pack_desc_fill": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32]),
     "dy_pack_weights_batched": (i32, [vp, i32, i32, vp]),
     "dy_conv_forward": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, ip, vp]),
+    "dy_conv_red_supported": (i32, [i32, i32, i32]),
+    "dy_conv_input_grad_red": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp]),
     "dy_conv_kernel_name": (i32, [i32, i32, i32, i32, C.c_char_p, i32]),
     "dy_wgrad_kernel_name": (i32, [i32, i32, i32, i32, C.c_char_p, i32]),
     "dy_wgrad_reduce_desc_bytes": (i32, []),

@@ -50,6 +50,14 @@ BN_RES = BN_ACC and os.environ.get("DY_BN_RES", "1") != "0"
 # Bias gradients (Detect's final convs, LDConv.p_conv) summed inside the weight-gradient kernel and finished by the batched slab
 # reduction, instead of a reduce + finalize launch pair per layer.  DY_BIAS_WGRAD=0: the launch pair.
 BIAS_WGRAD = BN_ACC and os.environ.get("DY_BIAS_WGRAD", "1") != "0"
+# The first pass of a Conv's BatchNorm backward (sums of g and g*xhat) run by the input-gradient kernel that is the ONLY writer of that
+# Conv's output gradient, in its epilogue (csrc/conv.hip, REDK), instead of by a dy_bn_act_bwd_reduce_acc launch that re-reads the
+# gradient.  MEASURED SLOWER (round 3, one box, alternating): 12.87 ms per step without, 13.06 ms with it for outputs up to 32 channels,
+# 15.34 ms up to 64 channels (those instantiations spill): exp + rcp per element in the memory slot of the ping-pong kernel make that
+# slot, not the MFMA slot, set the pace (a fused 32->32 3x3 dgrad at 160x160: 90-107 us against ~50 us + ~50 us for the two launches).
+# Off by default; DY_BN_DGRED=1 enables it, DY_BN_DGRED_MAXC bounds the output width it is used for.
+BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
+BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
 
 
 def dev_empty(shape, dtype, device):
@@ -163,6 +171,9 @@ class Act:
 
     def grad_target(self):
         """-> accumulate flag for a writer of this slice's gradient; marks the range as written."""
+        gw = self.st.eng._gw
+        k = (id(self.st), self.c0, self.C)
+        gw[k] = gw.get(k, 0) + 1
         c0, c1 = self.c0, self.c0 + self.C
         self._gbuf()
         overl = [(a, b) for a, b in self.st.gwritten if a < c1 and b > c0]
@@ -236,10 +247,14 @@ class Engine:
             raise RuntimeError("the DEAL-YOLO HIP engine needs a GPU device (no CPU fallback exists by design)")
         self.L = lib()
         self.keep = []  # keep-alive list for buffers referenced by recorded launches
-        self.tape = None  # list of backward closures while training-tracing
+        self._tape = None  # list of backward closures while training-tracing (property ``tape``)
         self.rec = None  # active Recorder
         self._scratch = {}
         self._ident = {}
+        self._gw = {}         # gradient writers per exact Act slice (grad_target calls) ...
+        self._uses = {}       # ... forward consumers per storage {id(st): {(c0, C): count}} ...
+        self._prod = {}       # ... and the Conv (spec, raw Act) that produced a slice: dataflow facts of the trace in progress that
+        self._reduced = set() # decide where a BatchNorm backward reduce can ride on the dgrad that writes its gradient (BN_DGRED)
         self.training = False
         self._tmp_int = C.c_int(0)
 
@@ -300,6 +315,36 @@ class Engine:
             rc = fn(*args, self.side_stream.cuda_stream if side else s)
             if rc != 0:
                 check(rc, name)
+
+    @property
+    def tape(self):
+        return self._tape
+
+    @tape.setter
+    def tape(self, v):
+        self._tape = v
+        if v is not None and len(v) == 0:  # a new trace begins: the dataflow facts of the previous one (keyed by object ids) are void
+            self.reset_dataflow()
+
+    def reset_dataflow(self):
+        self._gw.clear(); self._uses.clear(); self._prod.clear(); self._reduced.clear()
+
+    def _use(self, *xs):
+        """Forward bookkeeping: ``x`` will receive a gradient contribution from the op being traced."""
+        if self.tape is None:
+            return
+        for x in xs:
+            if isinstance(x, Act) and x.needs_grad:
+                d = self._uses.setdefault(id(x.st), {})
+                d[(x.c0, x.C)] = d.get((x.c0, x.C), 0) + 1
+
+    def _sole_consumer_of_conv(self, x):
+        """(spec, raw) of the Conv whose output IS ``x`` when the op now writing x's gradient is the only one that ever will: every
+        forward use of x's storage was this one use of exactly this slice."""
+        uses = self._uses.get(id(x.st))
+        if uses is None or len(uses) != 1 or uses.get((x.c0, x.C)) != 1:
+            return None
+        return self._prod.get((id(x.st), x.c0, x.C))
 
     def hold(self, *ts):
         """Keep per-call buffers alive for recorded launches.  Eager (un-recorded) calls must NOT retain them: the caching
@@ -497,6 +542,9 @@ class Engine:
         Ho, Wo = self.out_hw(spec, x)
         raw = self.new_act(x.N, Ho, Wo, spec.cout)
         y = out if out is not None else self.new_act(x.N, Ho, Wo, spec.cout)
+        self._use(x, res)
+        if self.tape is not None:
+            self._prod[(id(y.st), y.c0, y.C)] = (spec, raw)
         assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, spec.cout), (spec.name, (y.N, y.H, y.W, y.C), (x.N, Ho, Wo, spec.cout))
         npix = x.N * Ho * Wo
         bn = spec.bn
@@ -565,16 +613,21 @@ class Engine:
         assert y.grad_ready(), f"gradient of {spec.name} output incomplete"
         npix = y.npix
         acc = BN_ACC and spec.acc_b is not None
+        fused_red = id(spec) in self._reduced  # the dgrad that wrote y's gradient already summed g and g*xhat into acc_b
+        if fused_red and self._gw.get((id(y.st), y.c0, y.C)) != 1:
+            raise RuntimeError(f"{spec.name}: BatchNorm backward reduce was fused into a dgrad that is not the only writer of the gradient")
         rg = (0, 0, 0)
         if res is not None and res.needs_grad:
             racc = res.grad_target()
-            if acc and BN_RES and res.C == spec.cout:  # the shortcut's gradient (= dy) rides on the reduce pass below
+            if acc and BN_RES and res.C == spec.cout and not fused_red:  # the shortcut's gradient (= dy) rides on the reduce pass below
                 rg = (res.gptr, res.ld, racc)
             elif racc:
                 self.call("dy_add", res.gptr, res.ld, y.gptr, y.ld, 0, 0, res.gptr, res.ld, npix, res.C)
             else:
                 self.call("dy_copy_slice", y.gptr, y.ld, res.gptr, res.ld, npix, res.C)
-        if acc:
+        if acc and fused_red:
+            pass
+        elif acc:
             self.call("dy_bn_act_bwd_reduce_acc", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), self._acc_ready(spec.acc_b),
                       npix, spec.cout, spec.act, *rg)
         else:
@@ -648,8 +701,21 @@ class Engine:
                       spec.cin, spec.cout, spec.ks, spec.stride, accumulate_w, side=side)
         if x.needs_grad:
             acc = x.grad_target()
-            self.call("dy_conv_forward", dy_ptr, lddy, spec.wpack_t.data_ptr(), 0, x.gptr, x.ld, 0, x.N, Ho, Wo,
-                      spec.cout_phys, spec.cin, spec.ks, 1, spec.stride, x.H, x.W, DY_EPI_ACCUM if acc else 0, None)
+            prod = self._sole_consumer_of_conv(x) if (BN_DGRED and not acc and spec.stride == 1 and spec.ld is None) else None
+            if prod is not None:
+                ps, praw = prod
+                if not (ps.act == DY_ACT_SILU and ps.acc_b is not None and ps.cout == x.C == spec.cin and x.C <= BN_DGRED_MAXC
+                        and (praw.N, praw.H, praw.W) == (x.N, x.H, x.W)
+                        and self.L.dy_conv_red_supported(spec.cout_phys, spec.cin, spec.ks)):
+                    prod = None
+            if prod is not None:
+                # this dgrad is the only writer of the gradient of ps's output: ps's BatchNorm backward reduce rides on its epilogue
+                self.call("dy_conv_input_grad_red", dy_ptr, lddy, spec.wpack_t.data_ptr(), x.gptr, x.ld, x.N, Ho, Wo, spec.cout_phys, spec.cin,
+                          spec.ks, praw.ptr, praw.ld, ps.coef.data_ptr(), self._acc_ready(ps.acc_b), ps.cout)
+                self._reduced.add(id(ps))
+            else:
+                self.call("dy_conv_forward", dy_ptr, lddy, spec.wpack_t.data_ptr(), 0, x.gptr, x.ld, 0, x.N, Ho, Wo,
+                          spec.cout_phys, spec.cin, spec.ks, 1, spec.stride, x.H, x.W, DY_EPI_ACCUM if acc else 0, None)
 
     deferred_wgrad = None
 
@@ -690,6 +756,7 @@ class Engine:
     def conv_bias(self, spec: ConvSpec, x: Act, y_ptr, ldy, f32out=True, dy_ptr_fn=None, out_hw=None):
         """Plain conv + bias (Detect's final nn.Conv2d 1x1, reference nn/modules/head.py:38-42).  ``dy_ptr_fn`` returns
         (ptr, ld) of the fp16 gradient w.r.t. the output at backward time."""
+        self._use(x)
         self._conv_raw(spec, x, y_ptr, ldy, DY_EPI_BIAS | (DY_EPI_F32OUT if f32out else 0), 0, spec.bias)
         if self.tape is not None:
             self.tape.append(lambda: self._conv_bias_bwd(spec, x, dy_ptr_fn))
@@ -715,6 +782,7 @@ class Engine:
 
     def upsample2x(self, x: Act, out: Act | None = None):
         y = out if out is not None else self.new_act(x.N, 2 * x.H, 2 * x.W, x.C)
+        self._use(x)
         self.call("dy_upsample2x", x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, 0, 0)
         if self.tape is not None:
             def bwd():
@@ -726,6 +794,7 @@ class Engine:
     def maxpool5(self, x: Act, out: Act):
         arg = self.transient((x.npix * x.C,), torch.uint8)
         self.hold(arg)
+        self._use(x)
         self.call("dy_maxpool5", x.ptr, x.ld, out.ptr, out.ld, arg.data_ptr(), x.N, x.H, x.W, x.C)
         if self.tape is not None:
             def bwd():
@@ -740,6 +809,7 @@ class Engine:
         b = xs[1]
         c = xs[2] if len(xs) > 2 else None
         assert len(xs) <= 3
+        self._use(*xs)
         self.call("dy_add", a.ptr, a.ld, b.ptr, b.ld, 0 if c is None else c.ptr, 0 if c is None else c.ld, y.ptr, y.ld, a.npix, a.C)
         if self.tape is not None:
             def bwd():
@@ -769,6 +839,7 @@ class Engine:
             return Act(st, xs[0].c0, pos - xs[0].c0)
         a = xs[0]
         y = self.new_act(a.N, a.H, a.W, sum(t.C for t in xs))
+        self._use(*xs)
         off = 0
         parts = []
         for t in xs:
@@ -795,6 +866,7 @@ class Engine:
         l, m, s = xs
         assert l.H == 2 * m.H and l.W == 2 * m.W and m.H == 2 * s.H and m.W == 2 * s.W, "Zoom_cat needs exact 2x pyramids"
         y = out if out is not None else self.new_act(m.N, m.H, m.W, l.C + m.C + s.C)
+        self._use(l, m, s)
         yl, ym, ys = y.sub(0, l.C), y.sub(l.C, m.C), y.sub(l.C + m.C, s.C)
         self.call("dy_zoom_pool", l.ptr, l.ld, yl.ptr, yl.ld, l.N, m.H, m.W, l.C)
         self.call("dy_copy_slice", m.ptr, m.ld, ym.ptr, ym.ld, m.npix, m.C)
@@ -881,6 +953,7 @@ class Engine:
             doff = torch.zeros((x.N, h, w, 8 * ((2 * Np + 7) // 8)), dtype=torch.float16, device=self.device)
             self.hold(doff)
         self.conv_bias(sp_p, x, off.data_ptr(), 2 * Np, True, lambda: (doff.data_ptr(), doff.shape[-1]))
+        self._use(x)  # the sampler's backward writes x's gradient too
         xo = self.new_act(x.N, h, w, Np * x.C)
         self.call("dy_ldconv_sample", x.ptr, x.ld, off.data_ptr(), 2 * Np, pn_i32.data_ptr(), xo.ptr, xo.ld, x.N, x.H, x.W, h, w,
                   x.C, Np, stride)

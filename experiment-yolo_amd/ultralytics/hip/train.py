@@ -111,6 +111,7 @@ class StepPlan:
         if self.arena is not None:
             self.arena.reset()
         try:
+            eng.reset_dataflow()
             eng.zero_acc_pool()
             rt.pack_all(transposed=True)
             x = self.import_input()
@@ -511,6 +512,10 @@ class StepPlan:
             cin, cout, ks, stride = args[9:13]
             if L.dy_wgrad_kernel_name(cin, cout, ks, stride, buf, 128) == 0:
                 return buf.value.decode(), self.wgrad_algorithmic_bytes(args)
+        if name == "dy_conv_input_grad_red":  # (dy, lddy, w, dx, lddx, n, h, w, cin, cout, ks, ...): a stride-1 input gradient
+            n, h, w, cin, cout, ks = args[5:11]
+            if L.dy_conv_kernel_name(cin, cout, ks, 1, buf, 128) == 0:
+                return buf.value.decode().replace("false>", "true>"), n * h * w * (cin + cout) * 2
         if name == "dy_stem_forward":  # (img, w, raw, ldraw, acc, n, h, w, mul): 3 input channels read once, 16 output channels written once
             n, h, w = args[5:8]
             return "stem_fwd_kernel", n * h * w * 3 * 2 + n * ((h - 1) // 2 + 1) * ((w - 1) // 2 + 1) * 16 * 2

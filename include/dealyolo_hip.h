@@ -72,6 +72,14 @@ int dy_conv_forward(const void* x, int ldx, const void* w_packed, const float* b
                     int n, int h, int w, int cin, int cout, int ks, int stride, int dil, int out_h, int out_w, int epi,
                     int* num_partials, hipStream_t stream);
 int dy_conv_num_partials(int n, int h, int w, int cin, int cout, int ks, int stride, int dil);
+/* Input gradient of a stride-1 conv (the dgrad half of aten::convolution_backward: dy (n,h,w,cin) x transposed pack -> dx (n,h,w,cout))
+ * that is the ONLY writer of dx = the gradient w.r.t. the activated output of a Conv (nn/modules/conv.py:49-55): the first pass of that
+ * Conv's BatchNorm backward (sums of g = dx * silu'(raw*scale+shift) and g*xhat over the pixels, dy_bn_act_bwd_reduce_acc) runs in
+ * the epilogue on the values being stored and is added into acc [DY_BN_COPIES][2][C].  C == cout; dy_conv_red_supported(cin, cout, ks)
+ * tells whether the geometry has this form (else DY_ERR_ARG). */
+int dy_conv_red_supported(int cin, int cout, int ks);
+int dy_conv_input_grad_red(const void* dy, int lddy, const void* w_packed_t, void* dx, int lddx, int n, int h, int w, int cin, int cout,
+                           int ks, const void* raw, int ldraw, const float* coef, double* acc, int C, hipStream_t stream);
 /* host-side: the kernel instantiation dy_conv_forward launches for this geometry, spelled as rocprofv3 prints it */
 int dy_conv_kernel_name(int cin, int cout, int ks, int stride, char* out, int cap);
 

@@ -433,3 +433,35 @@ def test_direct_stem_equals_import_plus_generic_conv(N, H, W):
     assert relerr(a["raw"], b["raw"]) < 1e-3 and float((a["raw"] != b["raw"]).float().mean()) < 2e-2   # summation order only
     assert relerr(a["sums"], b["sums"]) < 1e-5
     assert relerr(a["gw"], b["gw"]) < 2e-3 and relerr(a["dg"], b["dg"]) < 2e-3 and relerr(a["db"], b["db"]) < 2e-3
+
+
+@pytest.mark.parametrize("cp,cq,ks,H,W", [(32, 32, 1, 37, 45), (16, 16, 3, 40, 40), (32, 32, 3, 33, 35), (64, 64, 3, 24, 40), (64, 64, 1, 31, 17),
+                                          (32, 8, 1, 20, 20), (128, 64, 1, 10, 10)])
+def test_bn_backward_reduce_in_the_dgrad_epilogue(cp, cq, ks, H, W):
+    """dy_conv_input_grad_red: the stride-1 input gradient that is the only writer of a Conv's output gradient also runs the first pass
+    of that Conv's BatchNorm backward in its epilogue.  Against the two launches it replaces (dy_conv_forward over the transposed pack,
+    then dy_bn_act_bwd_reduce_acc on the stored gradient): the same gradient tensor bit for bit, the same sums up to fp32 summation order."""
+    from ultralytics.hip import DY_BN_COPIES, check
+    torch.manual_seed(cp + cq + ks)
+    eng = _eng()
+    N = 3
+    if not eng.L.dy_conv_red_supported((cq + 7) // 8 * 8, cp, ks):
+        pytest.skip("geometry outside the ping-pong kernel")
+    w = h16(torch.randn(cq, cp, ks, ks) / (cp * ks * ks) ** 0.5)   # the consumer conv: cp -> cq
+    sp = _spec(eng, w, None, ks, 1)
+    dy = _act(eng, h16(torch.randn(N, cq, H, W)))                  # gradient w.r.t. the consumer's raw output
+    raw = h16(torch.randn(N, H, W, cp) * 1.5 + 0.2).half().cuda().contiguous()   # the producer's raw conv output
+    coef = torch.cat([torch.rand(cp) + 0.5, torch.randn(cp) * 0.3, torch.randn(cp) * 0.2, torch.rand(cp) + 0.5]).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    dx_a = torch.full((N, H, W, cp), float("nan"), dtype=torch.float16, device="cuda")
+    acc_a = torch.zeros(DY_BN_COPIES * 2 * cp, dtype=torch.float64, device="cuda")
+    check(eng.L.dy_conv_input_grad_red(dy.ptr, dy.ld, sp.wpack_t.data_ptr(), dx_a.data_ptr(), cp, N, H, W, sp.cout_phys, cp, ks, raw.data_ptr(), cp,
+                                       coef.data_ptr(), acc_a.data_ptr(), cp, s), "dy_conv_input_grad_red")
+    dx_b = torch.full_like(dx_a, float("nan"))
+    acc_b = torch.zeros_like(acc_a)
+    eng.call("dy_conv_forward", dy.ptr, dy.ld, sp.wpack_t.data_ptr(), 0, dx_b.data_ptr(), cp, 0, N, H, W, sp.cout_phys, cp, ks, 1, 1, 0, 0, 0, None)
+    eng.call("dy_bn_act_bwd_reduce_acc", dx_b.data_ptr(), cp, raw.data_ptr(), cp, coef.data_ptr(), acc_b.data_ptr(), N * H * W, cp, 1, 0, 0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(dx_a, dx_b)
+    sa, sb = acc_a.view(DY_BN_COPIES, 2, cp).sum(0), acc_b.view(DY_BN_COPIES, 2, cp).sum(0)
+    assert relerr(sa, sb) < 2e-5, relerr(sa, sb)
