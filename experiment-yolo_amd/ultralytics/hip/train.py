@@ -277,7 +277,10 @@ class StepPlan:
             else:
                 dg = 0.0 if not bool(torch.isfinite(got_g).all()) else float("inf")
             db = float((self.rt.flat_b - want_b).abs().max() / want_b.abs().max().clamp_min(1e-12))
-            if not (ds <= 1e-5 and dg <= 2e-2 and db <= 1e-5):
+            # a replay repeats the traced step BIT FOR BIT (fp32 partial sums added in fp64: no order dependence); only LDConv's
+            # far-sample side pass (fp32 atomics) leaves rounding-order noise in the gradients
+            ld = any(type(mod).__name__ == "LDConv" for mod in self.model.modules())
+            if not ((ds <= 1e-5 and dg <= 2e-2 and db <= 1e-5) if ld else (ds == 0.0 and dg == 0.0 and db == 0.0)):
                 self.graph_fb = self.rec_fb = None
                 raise RuntimeError(f"the captured step graph does not reproduce the traced step {what} (loss items off by {ds:.2e}, "
                                    f"gradients by {dg:.2e}, BN statistics by {db:.2e} relative): was another host thread issuing device "

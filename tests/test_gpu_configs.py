@@ -57,9 +57,10 @@ def test_fullsize_640_step_vs_reference(golden, mi, name, copies):
         ref_items, ref_loss = G.t(f"{name}/{mode}/items"), float(G[f"{name}/{mode}/loss"]) * copies  # loss = sum(items) * B
         e_items, e_loss = relerr(items, ref_items), abs(loss - ref_loss) / ref_loss
         print(f"{name} bs{B} {mode}: items {items.tolist()} ref {ref_items.tolist()} relerr {e_items:.2e} loss relerr {e_loss:.2e}")
-        # fp16 activation storage against the fp32 reference (measured 1e-4 .. 2e-3 on N, up to 6e-3 on LD whose floor() of the
-        # sampling coordinates can move a sample to the neighbouring pixel)
-        assert e_items < (1.5e-2 if ld else 4e-3) and e_loss < (1.5e-2 if ld else 4e-3)
+        # fp16 activation storage against the fp32 reference.  Measured (round 3): N 6.5e-4 at batch 2, 8.3e-6 at batch 64; LD 5.7e-4 /
+        # 6.1e-5.  Bounds: the north-star's 1e-3 for N, twice the measured error for LD (its floor() of the sampling coordinates can
+        # move a sample to the neighbouring pixel)
+        assert e_items < (1.2e-3 if ld else 1e-3) and e_loss < (1.2e-3 if ld else 1e-3)
         if mode == "ciou":
             assert float(plan.state[2]) == 0.0 and torch.isfinite(plan.rt.flat_g).all()
         if mode == "ciou" and not ld:  # LD gradients: test_fullsize_640_ld_gradients_in_the_init_regime (see there)
@@ -101,14 +102,14 @@ def test_fullsize_640_ld_gradients_in_the_init_regime(golden, copies):
     loss, items = plan.loss_items()
     e = relerr(items, G.t(f"{name}/ciou/items"))
     print(f"LD init regime bs{B}: items {items.tolist()} ref {G.t(f'{name}/ciou/items').tolist()} relerr {e:.2e}")
-    assert e < 4e-3 and float(plan.state[2]) == 0.0
+    assert e < 2e-4 and float(plan.state[2]) == 0.0  # measured 9.6e-5 (batch 2), 3.0e-5 (batch 64)
     names = [str(k) for k in G[f"{name}/grad_names"]]
     params = dict(m.named_parameters())
     l2 = torch.stack([params[k].grad.float().norm() for k in names]).cpu() / (float(plan.state[0]) * copies)
     ref = G.t(f"{name}/grad_l2")
     rel = ((l2 - ref).abs() / (ref.abs() + 1e-3 * ref.abs().max())).numpy()
     print(f"  grad-l2 rel err: median {np.median(rel):.2e} max {rel.max():.2e} ({names[int(rel.argmax())]})")
-    assert np.median(rel) < 1e-2 and rel.max() < 0.15
+    assert np.median(rel) < 3e-3 and rel.max() < 6e-2  # measured 1.0e-3 / 2.9e-2
 
 
 # ---- configs[4]: yolov8n-p2 -------------------------------------------------------------------------------------------------
@@ -120,14 +121,36 @@ def test_p2_models_vs_golden(golden, mi, name):
     m, g = _model(name, 7 + mi)
     m.cuda().train()
     plan = StepPlan(m, 2, 64, nmax=8, init_scale=1.0)
+    m._capture = []
     plan.forward_backward({k: G.t(f"{name}/{k}") for k in ("img", "batch_idx", "cls", "bboxes")})
     torch.cuda.synchronize()
+    acts, m._capture = m._capture, None
     print(f"{name}: non-finite gradient words {int((~torch.isfinite(plan.rt.flat_g)).sum())}, loss items {plan.crit.scalars[5:9].tolist()}")
-    for l, f in enumerate(plan.ho.as_reference_list()):
-        e = l2err(f.float(), G.t(f"{name}/feat{l}"))
-        print(f"{name} feat{l} l2err {e:.2e}")
-        # measured 0.9e-2 .. 4.4e-2: fp16 activations, randomly filled weights, and at this fixture size the coarse levels' batch
-        # statistics come from 2 x 4 x 4 and 2 x 2 x 2 samples; the eval-mode comparison below is the tight one
+    feats = [f.float() for f in plan.ho.as_reference_list()]
+    # (1) the kernels: Detect in the fp16-storage oracle (oracle.nn.STORAGE_FP16 rounds where the engine stores) fed with the ENGINE's
+    # own input maps -- what is left is the head kernels' arithmetic, whatever the batch statistics of a 2 x 2 x 2 map amplify upstream
+    import oracle.nn as onn
+    from oracle import graph as og
+    from ultralytics.hip.runtime import Runtime
+    sd = og.fill_state(og.state_layout(g), 7 + mi)
+    sd = {k: (v.half().float() if v.dim() >= 4 else v) for k, v in sd.items()}
+    det = g.layers[-1]
+    src = [Runtime.to_tensor(acts[j]).float().cpu() for j in det.f]
+    onn.STORAGE_FP16 = True
+    try:
+        with torch.no_grad():
+            ref_feats = onn.apply_layer(det, sd, src, True, g.strides)
+    finally:
+        onn.STORAGE_FP16 = False
+    for l, (f, r) in enumerate(zip(feats, ref_feats)):
+        e = l2err(f, r)
+        print(f"{name} feat{l} vs fp16-storage oracle on the engine's inputs {e:.2e}")
+        assert e < 2e-3, f"level {l}"
+    # (2) the whole chain against the fp32 reference: informative at this fixture size (measured 0.9e-2 .. 4.4e-2: the coarse levels'
+    # batch statistics come from 2 x 4 x 4 and 2 x 2 x 2 samples); the eval-mode comparison below is the tight end-to-end one
+    for l, f in enumerate(feats):
+        e = l2err(f, G.t(f"{name}/feat{l}"))
+        print(f"{name} feat{l} l2err vs fp32 reference (whole chain) {e:.2e}")
         assert e < (4e-2 if l == 0 else 0.15)
     assert torch.isfinite(plan.rt.flat_g).all() and float(plan.state[2]) == 0.0
     m2, _ = _model(name, 7 + mi)

@@ -3,7 +3,8 @@
 
 A training step captured into a hipGraph is replayed after a burst of ordinary launches issued by the SAME thread between two
 replays: N eval-mode forwards of the model (~170 launches each), the eager traces of N other launch lists (~540 each), N tiny
-launches of one library kernel, N torch element-wise launches.  With the runtime's graph packet capture on
+launches of one library kernel, N torch element-wise launches, N torch multi-tensor launches (fat argument blocks: does the size of
+the kernel arguments decide, or whose kernels they are?), N launches of the same tiny kernel from a second copy of the library.  With the runtime's graph packet capture on
 (DEBUG_CLR_GRAPH_PACKET_CAPTURE=1, the default of ROCm 7.2) the replay after ~1,000 library launches returns non-finite gradients
 while the same recorded launch list issued eagerly is fine; with the flag at 0 every case is finite.  Also shown: StepPlan's
 capture check (two eager passes over the list, then the verification replay) catches the defect at capture time.
@@ -15,7 +16,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = [("fwd", 3), ("fwd", 6), ("fwd", 20), ("trace", 1), ("trace", 2), ("trace", 3), ("crit", 4), ("burst", 5000), ("torchburst", 20000)]
+CASES = [("fwd", 3), ("fwd", 6), ("fwd", 20), ("trace", 1), ("trace", 2), ("trace", 3), ("crit", 4), ("burst", 5000), ("torchburst", 20000),
+         ("torchfat", 5000), ("torchfat", 20000), ("burstcopy", 5000), ("burstcopy", 20000)]  # round 3: torch launches with a FAT argument block (multi-tensor apply: ~4 KB of kernarg each)
 
 CHILD = r'''
 import os, sys
@@ -55,6 +57,18 @@ elif mode == "burst":
 elif mode == "torchburst":
     x = torch.zeros(1024, device="cuda")
     for k in range(N): x.add_(1.0)
+elif mode == "burstcopy":  # the SAME small kernel, launched from a second copy of the shared library (its own code object / hipModule)
+    import ctypes as C, shutil, tempfile
+    from ultralytics.hip import LIB_PATH
+    cp = os.path.join(tempfile.mkdtemp(), "libdealyolo_hip_copy.so"); shutil.copy(LIB_PATH, cp)
+    L2 = C.CDLL(cp)
+    L2.dy_bn_eval_coef.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_void_p]
+    t = [torch.ones(16, device="cuda") for _ in range(4)] + [torch.zeros(64, device="cuda")]
+    st = torch.cuda.current_stream().cuda_stream
+    for k in range(N): L2.dy_bn_eval_coef(*[x.data_ptr() for x in t], 16, 1e-3, st)
+elif mode == "torchfat":
+    xs = [torch.zeros(256, device="cuda") for _ in range(100)]
+    for k in range(N): torch._foreach_add_(xs, 1.0)   # one multi_tensor_apply launch: a table of 100 addresses + sizes by value
 elif mode == "fwd":
     m.eval()
     with torch.no_grad():
