@@ -718,6 +718,7 @@ class Engine:
                           spec.cout_phys, spec.cin, spec.ks, 1, spec.stride, x.H, x.W, DY_EPI_ACCUM if acc else 0, None)
 
     deferred_wgrad = None
+    tape_mark = None  # index into the tape where the neck + head begin (set by BaseModel.forward_act while tracing)
 
     def flush_wgrad(self):
         """Reduce the slabs of every deferred layer into its fp32 weight gradient: one launch, one descriptor per layer."""

@@ -84,6 +84,15 @@ class StepPlan:
         self.graph_fb = None
         self.gsum, self._micro = None, 0
         self.ema_updates = 0
+        # Data-parallel gradient buckets (DY_DP_BUCKETS=2, world_size > 1): the backward list is cut where the neck + head end; their
+        # gradients (bucket 1) are all-reduced on a side stream WHILE the backbone's backward runs, the backbone's (bucket 2) after it
+        # -- the reference's DDP reducer fires its buckets inside loss.backward() the same way (engine/trainer.py:695, :810).
+        self.buckets = 2 if (world_size > 1 and os.environ.get("DY_DP_BUCKETS", "1") == "2") else 1
+        self.fb_cut = None          # index into rec_fb.ops between the two halves of the backward pass
+        self._bucket_idx = None     # (positions of bucket 1 in flat_gb, positions of bucket 2 + the buffer tail)
+        self._bucket_stage = None
+        self._bucket_pending = False
+        self.graph_fb2 = None
         self.dynamic_scale = bool(dynamic_scale)  # False (amp=False): the loss scale is a constant, nothing ever halves it
         self.opt_calls = 0                        # optimizer_step() calls so far; the device counts taken + skipped (state[5], state[6])
         self.rt.refresh_frozen()
@@ -123,8 +132,15 @@ class StepPlan:
             self.fb_split = len(eng.rec.ops)  # [0, fb_split) = forward + loss, the rest = backward (forward_only / backward_accumulate)
             eng.deferred_wgrad = []
             eng.side_wgrad = self.side_wgrad
-            for f in reversed(eng.tape):
+            mark = eng.tape_mark if (self.buckets == 2 and eng.tape_mark) else 0
+            for f in reversed(eng.tape[mark:]):
                 f()
+            if mark:  # neck + head done: their weight gradients leave the slabs now, the first bucket is complete
+                eng.flush_wgrad()
+                eng.deferred_wgrad = []
+                self.fb_cut = len(eng.rec.ops)
+                for f in reversed(eng.tape[:mark]):
+                    f()
             eng.flush_wgrad()
         finally:
             eng.deferred_wgrad = None
@@ -152,11 +168,60 @@ class StepPlan:
                 with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
                     self.eng.replay(self.rec_fb)
                 self._verify_capture(*pre)
+                if self.fb_cut is not None:  # the same list as two graphs, so that a collective can start between them
+                    g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                        self.eng.replay(self.rec_fb, 0, self.fb_cut)
+                    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                        self.eng.replay(self.rec_fb, self.fb_cut, None)
+                    self.graph_fb, self.graph_fb2 = g1, g2
+            if self.fb_cut is not None:
+                self._start_bucket1()  # the traced step ran whole: its first bucket starts now (nothing left to overlap with)
+        elif self.fb_cut is not None:
+            if self.graph_fb is not None:
+                self.graph_fb.replay()
+            else:
+                self.eng.replay(self.rec_fb, 0, self.fb_cut)
+            self._start_bucket1()
+            if self.graph_fb2 is not None:
+                self.graph_fb2.replay()
+            else:
+                self.eng.replay(self.rec_fb, self.fb_cut, None)
         elif self.graph_fb is not None:
             self.graph_fb.replay()
         else:
             self.eng.replay(self.rec_fb)
         return self.crit.scalars
+
+    # ---- gradient buckets ------------------------------------------------------------------------------------------------------
+    def _bucket_positions(self):
+        if self._bucket_idx is None:
+            rt, dev = self.rt, self.rt.flat_p.device
+            nb = len(self.model.yaml.get("backbone", []))
+            in1 = torch.zeros(rt.flat_gb.numel(), dtype=torch.bool)
+            for name, p in self.model.named_parameters():
+                parts = name.split(".")
+                if parts[0] == "model" and parts[1].isdigit() and int(parts[1]) >= nb:
+                    o = rt.param_off[name]
+                    in1[o:o + (p.numel() + 7) // 8 * 8] = True
+            self._bucket_idx = (in1.nonzero().flatten().to(dev), (~in1).nonzero().flatten().to(dev))
+            self._bucket_stage = [torch.zeros(i.numel(), dtype=torch.float32, device=dev) for i in self._bucket_idx]
+            self._bucket_stream = torch.cuda.Stream(dev)
+        return self._bucket_idx
+
+    def _start_bucket1(self):
+        """Neck + head gradients are final: gather them and start their all-reduce on the side stream."""
+        if self._micro:  # gradient accumulation exchanges the accumulated buffer once, at the optimizer step
+            return
+        idx1, _ = self._bucket_positions()
+        st = self._bucket_stage[0]
+        torch.index_select(self.rt.flat_gb, 0, idx1, out=st)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self._bucket_stream):
+            self._bucket_stream.wait_event(ready)
+            all_reduce_flat(st, self.world_size)
+        self._bucket_pending = True
 
     # ---- the two halves on their own: ``loss = model(batch); loss.backward()`` (nn/tasks.py, BaseModel.loss) -----------------------
     def forward_only(self, batch):
@@ -307,7 +372,21 @@ class StepPlan:
                 t[n:].copy_(rt.flat_b)
             else:
                 t[n:].zero_()
-            all_reduce_flat(t, self.world_size)
+            if self._bucket_pending and not self._micro:
+                # bucket 1 is (being) reduced on the side stream; bucket 2 = the backbone's gradients + the buffer tail goes now
+                idx1, idx2 = self._bucket_positions()
+                st2 = self._bucket_stage[1]
+                torch.index_select(t, 0, idx2, out=st2)
+                all_reduce_flat(st2, self.world_size)
+                torch.cuda.current_stream().wait_stream(self._bucket_stream)
+                t.index_copy_(0, idx1, self._bucket_stage[0])
+                t.index_copy_(0, idx2, st2)
+                self._bucket_pending = False
+            else:
+                if self._bucket_pending:  # an accumulating step: the early bucket is not used
+                    torch.cuda.current_stream().wait_stream(self._bucket_stream)
+                    self._bucket_pending = False
+                all_reduce_flat(t, self.world_size)
             rt.flat_b.copy_(t[n:])
 
     def accumulate(self):

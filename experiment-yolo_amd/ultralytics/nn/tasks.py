@@ -173,7 +173,10 @@ class BaseModel(HipModule):
         from ..hip.engine import ImageAct
         if isinstance(x, ImageAct) and not (type(self.model[0]) is Conv and self.model[0].f == -1 and 0 not in plan):
             x = x.materialize()  # only a plain Conv stem reads the image batch directly (csrc/stem.hip)
+        n_backbone = len(self.yaml.get("backbone", [])) if isinstance(getattr(self, "yaml", None), dict) else 0
         for m in self.model:
+            if m.i == n_backbone and eng.tape is not None:
+                eng.tape_mark = len(eng.tape)  # backward closures from here on belong to the neck + head (StepPlan's gradient buckets)
             if m.f != -1:
                 x = ys[m.f] if isinstance(m.f, int) else [x if j == -1 else ys[j] for j in m.f]
             dst = None

@@ -30,6 +30,8 @@ def main(out_dir):
         plan.all_reduce()
         plan.optimizer_step()
     torch.cuda.synchronize()
+    if os.environ.get("DY_DP_BUCKETS") == "2":
+        assert plan.buckets == 2 and plan.fb_cut is not None and plan.graph_fb2 is not None, "the bucketed path was asked for and not taken"
     taken, skipped, _ = plan.check_progress()
     assert (taken, skipped) == (len(STEPS), 0)
     torch.save({"p": plan.rt.flat_p.cpu(), "b": plan.rt.flat_b.cpu(), "ema": plan.ema.cpu()}, os.path.join(out_dir, f"rank{rank}.pt"))

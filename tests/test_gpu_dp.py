@@ -40,17 +40,20 @@ def _emulate(world, b):
     return rt.flat_p.cpu(), rt.flat_b.cpu(), plan.ema.cpu()
 
 
-@pytest.mark.parametrize("steps", ["1,1,1", "1,2,1"])
-def test_two_rank_step_equals_the_single_process_emulation(tmp_path, steps, monkeypatch):
+@pytest.mark.parametrize("steps,buckets", [("1,1,1", 1), ("1,2,1", 1), ("1,1,1", 2), ("1,2,1", 2)])
+def test_two_rank_step_equals_the_single_process_emulation(tmp_path, steps, buckets, monkeypatch):
     """steps = micro-batches per optimizer step.  Without accumulation the two ranks' sum g0 + g1 has ONE order: the replicas must
     equal the emulation bit for bit.  With an accumulating step the rank-wise sum (a + b) + (c + d) and the emulation's chain
     ((a + b) + c) + d differ by fp32 rounding (measured 4e-9 on the weights right after such a step); the step that follows runs on
     fp16 activations, which turn that into isolated last-bit flips: 5e-10 ... 1.5e-6 depending on the trajectory (round 3: the same
-    schedule gave 5e-10 with the imported stem input and 1.5e-6 with the direct stem, 4e-9 for '2,1' either way)."""
+    schedule gave 5e-10 with the imported stem input and 1.5e-6 with the direct stem, 4e-9 for '2,1' either way).
+    buckets = 2 (DY_DP_BUCKETS): the backward list is cut where the neck + head end and their gradients are all-reduced on a side stream
+    while the backbone's backward runs (hip/train.py, _start_bucket1) -- the same sums, so the same bits."""
     import dp_common
     world, b = 2, 2
     port = 29500 + os.getpid() % 2000
     monkeypatch.setenv("DY_TEST_DP_STEPS", steps)
+    monkeypatch.setenv("DY_DP_BUCKETS", str(buckets))
     monkeypatch.setattr(dp_common, "STEPS", [int(v) for v in steps.split(",")])
     monkeypatch.setattr(sys.modules[__name__], "STEPS", dp_common.STEPS)
     env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
