@@ -220,12 +220,14 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a, BnAccFwd
   if (pix < a.npix) one(pix, *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0));
 }
 
-// Which passes walk their pixels from the far end (bit 0 forward apply, bit 1 backward apply, bit 2 backward reduce).  The backward
-// apply re-reads dY and x right after the reduce pass streamed them front to back; starting at the end, where the most recently
-// fetched lines still sit in L2 / Infinity Cache, measured 14.17 -> 14.11 ms per step (three alternating runs on one box); the other
-// two bits measured nothing.  Element-wise, so the results do not depend on the order.
+// Which passes walk their pixels from the far end (bit 0 forward apply, bit 1 the stand-alone backward apply, bit 2 backward reduce).
+// Round 3 default 4: the backward reduce reads dy right after the dgrad kernels wrote it front to back -- starting at the end, where the
+// most recently written lines still sit in L2 / Infinity Cache -- and finishes at the front, which is where the weight-gradient kernel
+// that follows starts reading dy and raw: 12.778 -> 12.723 ms per step (alternating runs on one box; bits 0 and 1 measured nothing:
+// 12.77 / 12.81 with bit 0, and the stand-alone backward apply of bit 1 is no longer launched).  Element-wise / order-free sums of
+// fp32 partials in fp64, so the results do not depend on the order.
 static inline int ew_reverse() {
-  static const int rev = getenv("DY_EW_REVERSE") ? atoi(getenv("DY_EW_REVERSE")) : 2;
+  static const int rev = getenv("DY_EW_REVERSE") ? atoi(getenv("DY_EW_REVERSE")) : 4;
   return rev;
 }
 
