@@ -7,10 +7,11 @@ A "step" is one full training iteration of DEAL-YOLO-N (yolov8n-ASF-P2P2) at 640
 configs[1]): image import, forward, detection loss (TAL + CIoU + DFL + BCE), hand-written backward, gradient all-reduce
 (RCCL, N>1), SGD-nesterov + EMA -- all through libdealyolo_hip.so.  Inputs are synthetic and already resident in HBM.
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     the kernel with the largest total time per step among ALL launches (whatever it is): algorithmic bytes per launch
-               (only convolutions have any; BatchNorm / activation passes count as fused away = 0) / its average
-               launch duration, measured live with HIP events on the launch stream, against 8 TB/s HBM; `traffic` = its PMC HBM
-               bytes per launch from profiles/; `step` = the whole step priced the same way (images/s x 367 MB / 8 TB/s);
+  roofline     the kernel with the largest total time per step among ALL launches (whatever it is): the bytes its launch cannot
+               avoid (operands read once + results written once at fp16; for a convolution that IS SURVEY.md 8(d)'s algorithmic
+               bytes) / its average launch duration, measured live with HIP events on the launch stream, against 8 TB/s HBM;
+               `traffic` = its PMC HBM bytes per launch from profiles/; `step` = the whole step priced by 8(d) alone, where
+               BatchNorm / activation passes count as fused away = 0 bytes (images/s x 367 MB / 8 TB/s);
                `top_conv` = the most expensive convolution instantiation, for comparison with earlier rounds;
   cpu_baseline the CPU oracle (a port of the reference's PyTorch CPU path) timed on the host cores in BASELINE.md section 2's protocol
                (bs=2, median of 8 steps after 2 warm-up); `bs16` = the same at bs=16 (about 25 s of CPU work: the bounded sample).
@@ -176,29 +177,40 @@ def main():
     for _ in range(a.warmup):
         one_step()
     # The dynamic loss scale starts at 65536 (GradScaler's policy) and halves on every overflow: until the search ends some
-    # optimizer steps are skipped ones.  Keep stepping (untimed) until the skip counter has stood still for three steps, so that
+    # optimizer steps are skipped ones.  Keep stepping (untimed) until the skip counter has stood still for eight steps, so that
     # every TIMED step is a full one whatever --warmup was.
     settle, still, last = 0, 0, float(plan.state[6])
-    while still < 3 and settle < 40:
+    while still < 8 and settle < 100:
         one_step()
         settle += 1
         now = float(plan.state[6])
         still, last = (still + 1, last) if now == last else (0, now)
     if world > 1:  # every rank leaves the settling loop after the same number of steps (all-reduced gradients overflow together)
         dist.barrier()
-    skipped_before = float(plan.state[6])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def timed_region():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            one_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    # A timed region in which the scale search skipped an optimizer step anyway (the fixed synthetic batch is being over-fitted at
+    # the reference's lr0, gradient spikes do happen) is thrown away and timed again, so that the line below never holds a skipped step.
+    retimed = 0
+    while True:
+        skipped_before = float(plan.state[6])
+        dt = timed_region()
+        if float(plan.state[6]) == skipped_before or retimed == 3:  # state is all-reduced with the gradients: the same on every rank
+            break
+        retimed += 1
     if world > 1:
         tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -247,6 +259,9 @@ def main():
             tc = pr["top_conv"]
             roof = {"bound": "hbm", "achieved": pr["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pr["gbs"] / HBM_PEAK_GBS,
                     "traffic": traffic(pr["kernel"]), "kernel": pr["kernel"], "avg_us": pr["us"], "bytes_per_launch": pr["bytes"],
+                    "bytes_definition": "each operand of the launch read once + each result written once at fp16 (for a convolution this IS "
+                                        "SURVEY.md 8(d)'s algorithmic bytes; 8(d) prices a BatchNorm/activation pass at 0 -- the step figure below does)",
+                    "algorithmic_bytes_per_launch_8d": pr["algorithmic_bytes"],
                     "launches_per_step": pr["launches_per_step"], "ms_per_step": pr["ms_per_step"],
                     "step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS if step_gbs else None, "unit": "GB/s",
                              "algorithmic_bytes_per_image": alg, "device_ms_sum_of_launches": pr["step_device_ms"],
@@ -266,7 +281,7 @@ def main():
                "config": {"workload": f"{'DEAL-YOLO-N' if a.model == 'yolov8n-ASF-P2P2' else a.model} ({a.model}.yaml) train step {a.imgsz}x{a.imgsz}, per-GPU batch {a.batch}, "
                                       f"fwd+TAL/{a.loss.upper()}/DFL/BCE loss+bwd+SGD+EMA, BASELINE.json configs[{3 if 'LD' in a.model else 1}]",
                           "loss_mode": a.loss, f"{other.replace('+', '_')}_images_per_s": other_rate,
-                          "settle_steps": settle, "skipped_in_timed_steps": skipped_timed,
+                          "settle_steps": settle, "skipped_in_timed_steps": skipped_timed, "timed_regions_discarded": retimed,
                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
                           "loss_items_last": [float(x) for x in s[5:8]], "loss_scale": float(plan.state[0]),
                           "skipped_steps": float(plan.state[6]),

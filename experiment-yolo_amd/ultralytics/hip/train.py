@@ -579,9 +579,41 @@ class StepPlan:
         return n * h * w * ((cin + 7) // 8 * 8) * 2 + n * Ho * Wo * ((cout + 7) // 8 * 8) * 2
 
     def kernel_of(self, name, args):
-        """(kernel name as rocprofv3 prints it, algorithmic bytes) of one recorded C-ABI call.  Under SURVEY.md 8(d)'s definition
-        only the convolutions (forward, input gradient, weight gradient) have algorithmic bytes: BatchNorm / activation passes
-        and every other element-wise launch count as fused away, i.e. 0."""
+        """(kernel name as rocprofv3 prints it, algorithmic bytes, the launch's own least traffic) of one recorded C-ABI call.
+        Under SURVEY.md 8(d)'s definition only the convolutions (forward, input gradient, weight gradient) have algorithmic
+        bytes: BatchNorm / activation passes and every other element-wise launch count as fused away, i.e. 0 -- that is what the
+        STEP's roofline is priced with.  A kernel's OWN roofline needs the bytes that launch cannot avoid (each operand read once,
+        each result written once at the storage dtype): equal to the algorithmic bytes for a convolution, the streams of the pass
+        for a BatchNorm / activation kernel (which 8(d) prices at 0 because a perfect fusion would not launch it at all)."""
+        key, alg = self._kernel_alg(name, args)
+        own = alg
+        e = 2  # fp16 storage
+        if name == "dy_bn_act_apply":
+            own = int(args[7]) * int(args[8]) * e * (3 if args[2] else 2)
+        elif name == "dy_bn_act_apply_acc":
+            own = int(args[12]) * int(args[13]) * e * (3 if args[2] else 2)
+        elif name == "dy_bn_act_bwd_reduce":
+            own = int(args[7]) * int(args[8]) * e * 2
+        elif name == "dy_bn_act_bwd_reduce_acc":  # dy and raw read; the shortcut gradient stored (or read, added and stored)
+            own = int(args[6]) * int(args[7]) * e * (2 + ((2 if args[11] else 1) if args[9] else 0))
+        elif name == "dy_bn_act_bwd_apply":
+            own = int(args[8]) * int(args[9]) * e * 3
+        elif name == "dy_bn_act_bwd_apply_acc":
+            own = int(args[10]) * int(args[11]) * e * 3
+        elif name in ("dy_conv_wgrad_bn", "dy_conv_wgrad_ld_bn"):  # + raw read and d(raw) written, both the size of the output gradient
+            n, h, w = args[14:17]
+            if name == "dy_conv_wgrad_bn":
+                cin, cout, ks, stride = args[17:21]
+            else:
+                cout, ks, stride = args[17], 1, 1
+            pad = ks // 2
+            own = alg + 2 * n * ((h + 2 * pad - ks) // stride + 1) * ((w + 2 * pad - ks) // stride + 1) * ((cout + 7) // 8 * 8) * e
+        elif name == "dy_stem_wgrad_bn":
+            n, h, w = args[11:14]
+            own = alg + n * ((h - 1) // 2 + 1) * ((w - 1) // 2 + 1) * 16 * e
+        return key, alg, own
+
+    def _kernel_alg(self, name, args):
         import ctypes as C
         L, buf = self.eng.L, C.create_string_buffer(128)
         if name == "dy_conv_forward":
@@ -642,14 +674,15 @@ class StepPlan:
         self.last_profile = prof
         groups = {}
         for name, args, ms in prof:
-            key, by = self.kernel_of(name, args)
-            groups.setdefault(key, []).append((ms, by))
+            key, by, own = self.kernel_of(name, args)
+            groups.setdefault(key, []).append((ms, by, own))
 
         def summary(key):
             items = groups[key]
             ms = sum(t[0] for t in items) / len(items)
-            by = sum(t[1] for t in items) / len(items)
+            by = sum(t[2] for t in items) / len(items)  # the kernel's own least traffic (== algorithmic bytes for a convolution)
             return {"kernel": key, "us": ms * 1e3, "bytes": by, "gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                    "algorithmic_bytes": sum(t[1] for t in items) / len(items),
                     "launches_per_step": len(items), "ms_per_step": sum(t[0] for t in items)}
 
         if not groups:
@@ -659,9 +692,10 @@ class StepPlan:
         convs = [k for k in rank if k.startswith("conv_")]
         top["top_conv"] = summary(convs[0]) if convs else None
         top["ranking"] = [{"kernel": k, "ms_per_step": round(sum(t[0] for t in groups[k]), 4), "launches": len(groups[k]),
-                           "algorithmic_MB_per_step": round(sum(t[1] for t in groups[k]) / 1e6, 1)} for k in rank[:12]]
+                           "algorithmic_MB_per_step": round(sum(t[1] for t in groups[k]) / 1e6, 1),
+                           "own_MB_per_step": round(sum(t[2] for t in groups[k]) / 1e6, 1)} for k in rank[:12]]
         top["step_device_ms"] = sum(t[2] for t in prof)
-        top["step_algorithmic_bytes"] = sum(by for v in groups.values() for _ms, by in v)
+        top["step_algorithmic_bytes"] = sum(t[1] for v in groups.values() for t in v)
         return top
 
     def breakdown(self):
