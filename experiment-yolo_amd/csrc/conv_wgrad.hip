@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgReduc
                      d.ld_taps, d.ld_cphys, d.ld_cin);
 }
 extern "C" int dy_wgrad_reduce_desc_bytes(void) { return (int)sizeof(WgReduceDesc); }
-static void wgrad_geometry(int cin, int cout, int ks, int stride, int* cin_p, int* cout_p, int* nci, int* mtc);
+static void wgrad_geometry(int cin, int cout, int ks, int stride, int* cin_p, int* cout_p, int* nci, int* mtc, long npix_out = 0);
 // Fills one host-side descriptor for a layer whose dy_conv_wgrad / dy_conv_wgrad_ld call was made with dw == NULL; returns its
 // block count (to be prefix-summed into first_block by the caller) or a negative error.
 extern "C" int dy_wgrad_reduce_desc_fill(void* desc, const float* slabs, int nslabs, float* dw, int cin, int cout, int ks, int stride,
@@ -489,20 +489,46 @@ static int dispatch_wgrad(int nci, int mtc, const WgArgs& a, int gx, int gy, hip
   return DY_ERR_ARG;
 }
 
-static void wgrad_geometry(int cin, int cout, int ks, int stride, int* cin_p, int* cout_p, int* nci, int* mtc) {
+// (ci tiles, co tiles) of 16 channels one workgroup owns.  Every resident workgroup column ends by writing a full fp32 weight slab
+// that the reduce launch reads back, so the slab bytes of a layer are (workgroup columns) x (weight bytes) whatever the map size:
+// 37.7 MB for a 64->64 3x3, against 26 MB of activations on a 40x40 map at batch 64.  npix_out > 0 (the layer's output pixels) lets
+// small maps trade that for re-reads of the activations, which stay in L2 / Infinity Cache at that size: a workgroup then owns a
+// smaller (ci, co) block over more pixels, fewer columns exist, and every operand is read once per chunk of the OTHER side.
+// Halves the co side first (a second ci chunk repeats the BatchNorm backward arithmetic of dy_conv_wgrad_bn, a second co chunk only
+// re-reads x).  DY_WGRAD_SPLIT=0 restores one block per layer; DY_WGRAD_SPLIT_F scales the threshold: measured per step (one box,
+// alternating runs) off 12.810 / 12.740 ms, F=0.5 13.330 / 13.217 (re-reads dominate), F=1 12.787 / 12.745, F=2 12.708 / 12.676
+// (the default: 64->64 3x3 @40x40 takes (32, 32) blocks, 128 columns), F=4 12.778 / 12.701.
+static long wgrad_columns(int ks, int nci, int mtc, int cp, int op) {
+  const int gy = (cp / (16 * nci)) * (op / (16 * mtc));
+  const int per_cu = (ks == 3 && nci * mtc >= 16) ? 1 : 2;
+  int gx = (256 * per_cu) / gy;
+  return gx < 32 ? 32 : gx;
+}
+static void wgrad_geometry(int cin, int cout, int ks, int stride, int* cin_p, int* cout_p, int* nci, int* mtc, long npix_out) {
   *cin_p = (cin + 15) / 16 * 16;
   *cout_p = (cout + 15) / 16 * 16;
   const int cit = *cin_p / 16, cot = *cout_p / 16;
   const int cap = (ks == 3 && stride == 2) ? 2 : 4;
   *nci = (cit % 4 == 0 && cap >= 4) ? 4 : ((ks == 1 && cit % 3 == 0) ? 3 : (cit % 2 == 0 ? 2 : 1));
   *mtc = cot % 4 == 0 ? 4 : ((ks == 1 && cot % 3 == 0) ? 3 : (cot % 2 == 0 ? 2 : 1));
+  static const bool split = !(getenv("DY_WGRAD_SPLIT") && atoi(getenv("DY_WGRAD_SPLIT")) == 0);
+  static const double f = getenv("DY_WGRAD_SPLIT_F") ? atof(getenv("DY_WGRAD_SPLIT_F")) : 2.0;
+  if (!split || npix_out <= 0) return;
+  const double wbytes = (double)ks * ks * *cin_p * *cout_p * 4.0;
+  const double act = (double)npix_out * (*cin_p * stride * stride + *cout_p) * 2.0;
+  while (2.0 * wgrad_columns(ks, *nci, *mtc, *cin_p, *cout_p) * wbytes > f * act) {  // slab written + read back
+    if (*mtc % 2 == 0 && *mtc >= *nci) *mtc /= 2;
+    else if (*nci % 2 == 0) *nci /= 2;
+    else if (*mtc % 2 == 0) *mtc /= 2;
+    else break;
+  }
 }
 
 extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int stride, int* nslabs,
                                   long* slab_elems) {
   int cp, op, nci, mtc;
-  wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc);
   const int pad = ks / 2, Ho = (h + 2 * pad - ks) / stride + 1, Wo = (w + 2 * pad - ks) / stride + 1;
+  wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc, (long)n * Ho * Wo);
   const int th = wg_th(ks, stride, nci, mtc);
   int ntiles;
   if (ks == 1) ntiles = (int)(((long)n * Ho * Wo + th * 32 - 1) / (th * 32));
@@ -538,6 +564,16 @@ extern "C" int dy_wgrad_kernel_name(int cin, int cout, int ks, int stride, char*
   int cp, op, nci, mtc;
   wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc);
   snprintf(out, cap, "conv_wgrad_kernel<%d, %d, %d, %d, 0>", ks, stride, nci, mtc);  // ", 1>": the dy_conv_wgrad_bn form
+  return DY_OK;
+}
+
+// the same for a given map (small maps take smaller channel blocks per workgroup: wgrad_geometry)
+extern "C" int dy_wgrad_kernel_name_at(int n, int h, int w, int cin, int cout, int ks, int stride, char* out, int cap) {
+  if (!out || cap < 8) return DY_ERR_ARG;
+  int cp, op, nci, mtc;
+  wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc,
+                 (long)n * ((h + 2 * (ks / 2) - ks) / stride + 1) * ((w + 2 * (ks / 2) - ks) / stride + 1));
+  snprintf(out, cap, "conv_wgrad_kernel<%d, %d, %d, %d, 0>", ks, stride, nci, mtc);
   return DY_OK;
 }
 
@@ -591,7 +627,8 @@ static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, flo
   // staging uses 32-bit buffer offsets: one image (3x3) or the whole tensor (1x1) must stay below 2 GiB
   if ((ks == 1 ? (double)n : 1.0) * h * w * (ldx > lddy ? ldx : lddy) * 2.0 >= 2147483648.0) return DY_ERR_ARG;
   int cp, op, nci, mtc;
-  wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc);
+  wgrad_geometry(cin, cout, ks, stride, &cp, &op, &nci, &mtc,
+                 (long)n * ((h + 2 * (ks / 2) - ks) / stride + 1) * ((w + 2 * (ks / 2) - ks) / stride + 1));
   WgArgs a{};
   a.x = (const f16*)x; a.dy = (const f16*)dy; a.slabs = slabs; a.ldx = ldx; a.lddy = lddy;
   a.N = n; a.H = h; a.W = w;

@@ -623,8 +623,8 @@ class StepPlan:
             if L.dy_conv_kernel_name(cin, cout, ks, stride, buf, 128) == 0:
                 return buf.value.decode(), self.conv_algorithmic_bytes(args)
         if name == "dy_conv_wgrad":
-            cin, cout, ks, stride = args[9:13]
-            if L.dy_wgrad_kernel_name(cin, cout, ks, stride, buf, 128) == 0:
+            n, h, w, cin, cout, ks, stride = args[6:13]
+            if L.dy_wgrad_kernel_name_at(n, h, w, cin, cout, ks, stride, buf, 128) == 0:
                 return buf.value.decode(), self.wgrad_algorithmic_bytes(args)
         if name == "dy_conv_input_grad_red":  # (dy, lddy, w, dx, lddx, n, h, w, cin, cout, ks, ...): a stride-1 input gradient
             n, h, w, cin, cout, ks = args[5:11]
@@ -643,14 +643,14 @@ class StepPlan:
             else:
                 cout, _ld_cin, ld_taps, ld_cphys = args[17:21]
                 cin, ks, stride = ld_taps * ld_cphys, 1, 1
-            if L.dy_wgrad_kernel_name(cin, cout, ks, stride, buf, 128) == 0:
+            if L.dy_wgrad_kernel_name_at(n, h, w, cin, cout, ks, stride, buf, 128) == 0:
                 pad = ks // 2
                 Ho, Wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
                 return (buf.value.decode().replace(", 0>", ", 1>"),
                         n * h * w * ((cin + 7) // 8 * 8) * 2 + n * Ho * Wo * ((cout + 7) // 8 * 8) * 2)
         if name == "dy_conv_wgrad_ld":
             n, h, w, cout, ld_cin, ld_taps, ld_cphys = args[6:13]
-            if L.dy_wgrad_kernel_name(ld_taps * ld_cphys, cout, 1, 1, buf, 128) == 0:
+            if L.dy_wgrad_kernel_name_at(n, h, w, ld_taps * ld_cphys, cout, 1, 1, buf, 128) == 0:
                 return buf.value.decode(), n * h * w * (ld_taps * ld_cphys + (cout + 7) // 8 * 8) * 2
         tmpl = {"dy_bn_act_apply": ("bn_act_apply_kernel<{}, false, false>", 9), "dy_bn_act_apply_acc": ("bn_act_apply_kernel<{}, true, " + ("false" if os.environ.get("DY_SILU_FAST") == "0" else "true") + ">", 14),
                 "dy_bn_act_bwd_reduce": ("bn_act_bwd_reduce_kernel<{}, false>", 9),

@@ -87,6 +87,8 @@ int dy_conv_kernel_name(int cin, int cout, int ks, int stride, char* out, int ca
 int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int stride, int* nslabs, long* slab_elems);
 /* host-side: the kernel instantiation dy_conv_wgrad launches for this geometry, spelled as rocprofv3 prints it */
 int dy_wgrad_kernel_name(int cin, int cout, int ks, int stride, char* out, int cap);
+/* the same for a given map: on small maps a workgroup owns a smaller (ci, co) channel block, so that fewer fp32 weight slabs exist */
+int dy_wgrad_kernel_name_at(int n, int h, int w, int cin, int cout, int ks, int stride, char* out, int cap);
 int dy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
                   int cin, int cout, int ks, int stride, int accumulate, hipStream_t stream);
 /* Weight gradient of a Conv (conv + BatchNorm + SiLU, nn/modules/conv.py:49-55) from the gradient w.r.t. its ACTIVATED output

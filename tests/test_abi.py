@@ -60,9 +60,14 @@ def test_conv_kernel_name_helper():
     from ultralytics.hip import lib
     L = lib()
     buf = C.create_string_buffer(128)
-    assert L.dy_conv_kernel_name(64, 64, 3, 1, buf, 128) == 0 and buf.value == b"conv_mfma_pp_kernel<32, 4, 3, 1, 2>"
+    assert L.dy_conv_kernel_name(64, 64, 3, 1, buf, 128) == 0 and buf.value == b"conv_mfma_pp_kernel<32, 4, 3, 1, 2, false>"
     assert L.dy_conv_kernel_name(64, 64, 1, 1, buf, 128) == 0 and buf.value.startswith(b"conv_mfma_pp_kernel<64, 4, 1, 1,")
     assert L.dy_conv_kernel_name(64, 64, 5, 1, buf, 128) != 0
+    # the weight gradient of the same layer: one (64, 64) channel block per workgroup on a large map, (32, 32) blocks on a 40x40 one,
+    # where the fp32 weight slabs of 256 workgroup columns would outweigh the activations
+    assert L.dy_wgrad_kernel_name(64, 64, 3, 1, buf, 128) == 0 and buf.value == b"conv_wgrad_kernel<3, 1, 4, 4, 0>"
+    assert L.dy_wgrad_kernel_name_at(64, 160, 160, 64, 64, 3, 1, buf, 128) == 0 and buf.value == b"conv_wgrad_kernel<3, 1, 4, 4, 0>"
+    assert L.dy_wgrad_kernel_name_at(64, 40, 40, 64, 64, 3, 1, buf, 128) == 0 and buf.value == b"conv_wgrad_kernel<3, 1, 2, 2, 0>", buf.value
     assert L.dy_wgrad_reduce_desc_bytes() >= 64
 
 
