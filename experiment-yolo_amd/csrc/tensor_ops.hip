@@ -451,6 +451,199 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(PoolArgs a) {
     *reinterpret_cast<half8*>(a.y + pix * a.ldy + c0) = o;
   }
 }
+// ---- SPPF's chain of three 5x5 pools (reference nn/modules/block.py:166-171: y1 = m(x), y2 = m(y1), y3 = m(y2), all four concatenated)
+// in ONE launch when a whole map fits in LDS: a workgroup owns one image x CG channels, keeps the map in LDS and pools it three times
+// in place.  Each pool is separable -- a row pass (max over dx, first maximum kept) and a column pass over the row results (first row
+// kept) -- which is the row-major "first maximum" of the 25-tap scan above, NaN rule included (a NaN always replaces, so the last
+// NaN in row-major order wins in both forms); 10 LDS reads per output instead of 25 L1 reads.  x is read once and y1..y3 + the three
+// arg-max maps are written once: 1 + 3 + 1.5 tensor units instead of 3 x (1 + 1 + 0.5), and one launch instead of three.
+// 16 waves per workgroup: the passes are VALU work (compare / select chains) on LDS operands, and one workgroup owns the whole CU's LDS --
+// with 4 waves (one per SIMD) every LDS wait stalled its SIMD and the fused form was SLOWER than the three launches (13.08 vs 13.00 ms / step)
+#define SPPF_THREADS 1024
+struct SppfArgs {
+  f16* cat;            // [N*H*W][ld]: slice 0 = x (C channels), slices 1..3 = y1..y3 (forward); the gradients of the same (backward)
+  uint8_t* arg[3];     // [N*H*W][C] window position 0..24 of pool l
+  int ld, C, N, H, W, acc[3];
+};
+template <int CG>
+__global__ __launch_bounds__(SPPF_THREADS) void sppf_pool3_fwd_kernel(SppfArgs a) {
+  constexpr int G = CG / 8;
+  extern __shared__ __attribute__((aligned(16))) char sppf_lds[];
+  const int HW = a.H * a.W, items = HW * G;
+  half8* cur = reinterpret_cast<half8*>(sppf_lds);          // the map being pooled; overwritten by its pooled form
+  half8* rowm = cur + items;                                 // row-pass maxima
+  uint2* rowa = reinterpret_cast<uint2*>(rowm + items);      // row-pass arg (dx) per channel
+  const int groups = a.C / CG, n = blockIdx.x / groups, c0 = (blockIdx.x - n * groups) * CG;
+  f16* const base = a.cat + (size_t)n * HW * a.ld + c0;
+  for (int i = threadIdx.x; i < items; i += SPPF_THREADS) {
+    const int px = i / G, part = i - px * G;
+    cur[i] = *reinterpret_cast<const half8*>(base + (size_t)px * a.ld + part * 8);
+  }
+  __syncthreads();
+  for (int l = 0; l < 3; ++l) {
+    for (int i = threadIdx.x; i < items; i += SPPF_THREADS) {
+      const int px = i / G, part = i - px * G, y = px / a.W, x = px - y * a.W;
+      float best[8];
+      uint8_t bd[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bd[j] = 0; }
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+        const int xx = x + dx - 2;
+        if (xx < 0 || xx >= a.W) continue;
+        const half8 v = cur[(y * a.W + xx) * G + part];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = (float)v[j];
+          if (f > best[j] || f != f) { best[j] = f; bd[j] = (uint8_t)dx; }
+        }
+      }
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (f16)best[j];
+      rowm[i] = o;
+      rowa[i] = *reinterpret_cast<const uint2*>(bd);
+    }
+    __syncthreads();
+    f16* const yb = base + (size_t)(l + 1) * a.C;
+    uint8_t* const ab = a.arg[l] ? a.arg[l] + (size_t)n * HW * a.C + c0 : nullptr;
+    for (int i = threadIdx.x; i < items; i += SPPF_THREADS) {
+      const int px = i / G, part = i - px * G, y = px / a.W, x = px - y * a.W;
+      float best[8];
+      uint8_t bi[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+#pragma unroll
+      for (int dy = 0; dy < 5; ++dy) {
+        const int yy = y + dy - 2;
+        if (yy < 0 || yy >= a.H) continue;
+        const int k = (yy * a.W + x) * G + part;
+        const half8 v = rowm[k];
+        const uint2 ra = rowa[k];
+        const uint8_t* rd = reinterpret_cast<const uint8_t*>(&ra);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = (float)v[j];
+          if (f > best[j] || f != f) { best[j] = f; bi[j] = (uint8_t)(dy * 5 + rd[j]); }
+        }
+      }
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (f16)best[j];
+      cur[i] = o;  // only this thread reads or writes cur[i] in this pass: the column pass reads the row results
+      *reinterpret_cast<half8*>(yb + (size_t)px * a.ld + part * 8) = o;
+      if (ab) *reinterpret_cast<uint2*>(ab + (size_t)px * a.C + part * 8) = *reinterpret_cast<const uint2*>(bi);
+    }
+    __syncthreads();
+  }
+}
+// The backward chain of the same three pools in one launch: g2 = dcat2 + poolbwd(dcat3), g1 = dcat1 + poolbwd(g2), dcat0 += poolbwd(g1),
+// gather form and summation order of maxpool5_bwd_kernel, each level rounded to fp16 as its stand-alone launch would store it.  The
+// intermediate gradients never leave LDS (nothing else reads the gradients of y1..y3 once cv2's input gradient has been chained through).
+template <int CG>
+__global__ __launch_bounds__(SPPF_THREADS) void sppf_pool3_bwd_kernel(SppfArgs a) {
+  constexpr int G = CG / 8;
+  extern __shared__ __attribute__((aligned(16))) char sppf_lds[];
+  const int HW = a.H * a.W, items = HW * G;
+  half8* g0 = reinterpret_cast<half8*>(sppf_lds);
+  half8* g1 = g0 + items;
+  uint2* ar = reinterpret_cast<uint2*>(g1 + items);
+  const int groups = a.C / CG, n = blockIdx.x / groups, c0 = (blockIdx.x - n * groups) * CG;
+  f16* const base = a.cat + (size_t)n * HW * a.ld + c0;
+  for (int i = threadIdx.x; i < items; i += SPPF_THREADS) {
+    const int px = i / G, part = i - px * G;
+    g0[i] = *reinterpret_cast<const half8*>(base + (size_t)3 * a.C + (size_t)px * a.ld + part * 8);
+  }
+  for (int l = 2; l >= 0; --l) {
+    const uint8_t* const ab = a.arg[l] + (size_t)n * HW * a.C + c0;
+    for (int i = threadIdx.x; i < items; i += SPPF_THREADS) {
+      const int px = i / G, part = i - px * G;
+      ar[i] = *reinterpret_cast<const uint2*>(ab + (size_t)px * a.C + part * 8);
+    }
+    __syncthreads();
+    f16* const tb = base + (size_t)l * a.C;
+    for (int i = threadIdx.x; i < items; i += SPPF_THREADS) {
+      const int px = i / G, part = i - px * G, y = px / a.W, x = px - y * a.W;
+      float s[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] = 0.f;
+      if (a.acc[l]) {
+        const half8 o = *reinterpret_cast<const half8*>(tb + (size_t)px * a.ld + part * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = (float)o[j];
+      }
+#pragma unroll
+      for (int dy = 0; dy < 5; ++dy) {
+        const int wy = y - (dy - 2);
+        if (wy < 0 || wy >= a.H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          const int wx = x - (dx - 2);
+          if (wx < 0 || wx >= a.W) continue;
+          const int k = (wy * a.W + wx) * G + part;
+          const uint2 raw = ar[k];
+          const half8 g = g0[k];
+          const uint8_t* ai = reinterpret_cast<const uint8_t*>(&raw);
+          const int code = dy * 5 + dx;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (ai[j] == code) s[j] += (float)g[j];
+        }
+      }
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (f16)s[j];
+      if (l > 0) g1[i] = o;
+      else *reinterpret_cast<half8*>(tb + (size_t)px * a.ld + part * 8) = o;
+    }
+    __syncthreads();
+    half8* t = g0; g0 = g1; g1 = t;
+  }
+}
+// channels per workgroup the fused SPPF pools would use for this map (16 or 8), 0 = the map does not fit in LDS: use dy_maxpool5
+extern "C" int dy_sppf_pool3_supported(int h, int w, int C) {
+  if (h < 1 || w < 1 || C < 8 || (C & 7)) return 0;
+  const long px = (long)h * w;
+  if (!(C & 15) && px * (2 * 32 + 16) <= 156 * 1024) return 16;
+  if (px * (2 * 16 + 8) <= 156 * 1024) return 8;
+  return 0;
+}
+extern "C" int dy_sppf_pool3(void* cat, int ld, int C, void* arg0, void* arg1, void* arg2, int n, int h, int w, hipStream_t stream) {
+  const int cg = dy_sppf_pool3_supported(h, w, C);
+  if (!cg || !cat || ld < 4 * C) return DY_ERR_ARG;
+  if ((ld & 7) || ((uintptr_t)cat & 15)) return DY_ERR_ALIGN;
+  SppfArgs a{(f16*)cat, {(uint8_t*)arg0, (uint8_t*)arg1, (uint8_t*)arg2}, ld, C, n, h, w, {0, 0, 0}};
+  const size_t lds = (size_t)h * w * (cg / 8) * (2 * 16 + 8);
+  static bool attr[2] = {false, false};
+  if (cg == 16) {
+    if (!attr[0]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return DY_ERR_LAUNCH; attr[0] = true; }
+    hipLaunchKernelGGL(sppf_pool3_fwd_kernel<16>, dim3(n * (C / 16)), dim3(SPPF_THREADS), lds, stream, a);
+  } else {
+    if (!attr[1]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return DY_ERR_LAUNCH; attr[1] = true; }
+    hipLaunchKernelGGL(sppf_pool3_fwd_kernel<8>, dim3(n * (C / 8)), dim3(SPPF_THREADS), lds, stream, a);
+  }
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+extern "C" int dy_sppf_pool3_backward(void* gcat, int ld, int C, const void* arg0, const void* arg1, const void* arg2, int n, int h,
+                                      int w, int acc0, int acc1, int acc2, hipStream_t stream) {
+  const int cg = dy_sppf_pool3_supported(h, w, C);
+  if (!cg || !gcat || !arg0 || !arg1 || !arg2 || ld < 4 * C) return DY_ERR_ARG;
+  if ((ld & 7) || ((uintptr_t)gcat & 15)) return DY_ERR_ALIGN;
+  SppfArgs a{(f16*)gcat, {(uint8_t*)arg0, (uint8_t*)arg1, (uint8_t*)arg2}, ld, C, n, h, w, {acc0, acc1, acc2}};
+  const size_t lds = (size_t)h * w * (cg / 8) * (2 * 16 + 8);
+  static bool attr[2] = {false, false};
+  if (cg == 16) {
+    if (!attr[0]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return DY_ERR_LAUNCH; attr[0] = true; }
+    hipLaunchKernelGGL(sppf_pool3_bwd_kernel<16>, dim3(n * (C / 16)), dim3(SPPF_THREADS), lds, stream, a);
+  } else {
+    if (!attr[1]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return DY_ERR_LAUNCH; attr[1] = true; }
+    hipLaunchKernelGGL(sppf_pool3_bwd_kernel<8>, dim3(n * (C / 8)), dim3(SPPF_THREADS), lds, stream, a);
+  }
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
 extern "C" int dy_maxpool5(const void* x, int ldx, void* y, int ldy, void* argmax, int n, int h, int w, int C,
                            hipStream_t stream) {
   if ((C & 7) || (ldx & 7) || (ldy & 7)) return DY_ERR_ALIGN;

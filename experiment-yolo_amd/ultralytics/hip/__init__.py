@@ -110,6 +110,9 @@ SIGNATURES = {
     "dy_upsample2x": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_maxpool5": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "dy_maxpool5_backward": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_sppf_pool3_supported": (i32, [i32, i32, i32]),
+    "dy_sppf_pool3": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
+    "dy_sppf_pool3_backward": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dy_scalseq_tail": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "dy_scalseq_tail_backward": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32,
                                        i32, i32, ip, vp]),

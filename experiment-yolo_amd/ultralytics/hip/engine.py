@@ -56,6 +56,9 @@ BIAS_WGRAD = BN_ACC and os.environ.get("DY_BIAS_WGRAD", "1") != "0"
 # 15.34 ms up to 64 channels (those instantiations spill): exp + rcp per element in the memory slot of the ping-pong kernel make that
 # slot, not the MFMA slot, set the pace (a fused 32->32 3x3 dgrad at 160x160: 90-107 us against ~50 us + ~50 us for the two launches).
 # Off by default; DY_BN_DGRED=1 enables it, DY_BN_DGRED_MAXC bounds the output width it is used for.
+# SPPF's three chained 5x5 pools (and their backward chain) as one launch each with the map resident in LDS, when it fits
+# (Engine.sppf_pools; =0: three dy_maxpool5 / dy_maxpool5_backward launches).
+SPPF_FUSED = os.environ.get("DY_SPPF_FUSED", "1") != "0"
 BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
 BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
 
@@ -803,6 +806,33 @@ class Engine:
                 self.call("dy_maxpool5_backward", out.gptr, out.ld, arg.data_ptr(), x.gptr, x.ld, x.N, x.H, x.W, x.C, acc)
             self.tape.append(bwd)
         return out
+
+    def sppf_pools(self, cat, c_):
+        """SPPF's y1 = m(x), y2 = m(y1), y3 = m(y2) into slices 1..3 of ``cat`` (slice 0 = x): one launch with the map resident in LDS
+        when it fits (DY_SPPF_FUSED=0: never), three dy_maxpool5 launches otherwise.  Reference nn/modules/block.py:166-171."""
+        x = cat.act(0, c_)
+        if not (SPPF_FUSED and cat.buf.dtype == torch.float16 and self.L.dy_sppf_pool3_supported(x.H, x.W, c_)):
+            for j in range(3):
+                self.maxpool5(cat.act(j * c_, c_), cat.act((j + 1) * c_, c_))
+            return
+        sl = [cat.act(j * c_, c_) for j in range(4)]
+        taping = self.tape is not None
+        args = [self.transient((x.npix * c_,), torch.uint8) for _ in range(3)] if taping else [None] * 3
+        if taping:
+            self.hold(*args)
+        for a in sl[:3]:
+            self._use(a)
+        ap = [t.data_ptr() if t is not None else 0 for t in args]
+        self.call("dy_sppf_pool3", cat.act().ptr, cat.C, c_, ap[0], ap[1], ap[2], x.N, x.H, x.W)
+        if taping:
+            def bwd():
+                acc = [0, 0, 0]
+                for j in (2, 1, 0):  # the order the three stand-alone backward launches would claim their targets in
+                    acc[j] = sl[j].grad_target()
+                # (the closure holds the arg-max tensors themselves: un-recorded calls keep nothing alive otherwise)
+                self.call("dy_sppf_pool3_backward", cat.act().gptr, cat.C, c_, args[0].data_ptr(), args[1].data_ptr(), args[2].data_ptr(),
+                          x.N, x.H, x.W, acc[0], acc[1], acc[2])
+            self.tape.append(bwd)
 
     def add(self, xs, out: Act | None = None):
         a = xs[0]

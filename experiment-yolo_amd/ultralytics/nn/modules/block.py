@@ -77,6 +77,5 @@ class SPPF(HipModule):
         c_ = self.cv1.conv.out_channels
         cat = eng.new_storage(x.N, x.H, x.W, 4 * c_)
         self.cv1.forward_act(x, cat.act(0, c_))
-        for j in range(3):
-            eng.maxpool5(cat.act(j * c_, c_), cat.act((j + 1) * c_, c_))
+        eng.sppf_pools(cat, c_)
         return self.cv2.forward_act(cat.act(), out)

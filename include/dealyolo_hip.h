@@ -213,6 +213,15 @@ int dy_upsample2x(const void* x, int ldx, void* y, int ldy, int n, int h, int w,
 int dy_maxpool5(const void* x, int ldx, void* y, int ldy, void* argmax, int n, int h, int w, int C, hipStream_t stream);
 int dy_maxpool5_backward(const void* dy, int lddy, const void* argmax, void* dx, int lddx, int n, int h, int w, int C,
                          int accumulate, hipStream_t stream);
+/* SPPF's three chained pools (nn/modules/block.py:166-171) in one launch when a whole map fits in LDS.  cat: [n*h*w][ld] fp16, slice 0
+ * (C channels) = cv1's output, slices 1..3 receive y1..y3; argK: [n*h*w][C] uint8 arg-max of pool K (as dy_maxpool5 writes it; may be
+ * NULL in forward when no backward follows).  dy_sppf_pool3_supported: channels per workgroup (16 / 8) or 0 = use dy_maxpool5.
+ * Backward: gcat holds the gradients of the four slices (from cv2's input gradient); on return slice 0 holds (accK: is added to)
+ * the gradient of cv1's output; the gradients of y1 / y2 are consumed inside the kernel and not written back. */
+int dy_sppf_pool3_supported(int h, int w, int C);
+int dy_sppf_pool3(void* cat, int ld, int C, void* arg0, void* arg1, void* arg2, int n, int h, int w, hipStream_t stream);
+int dy_sppf_pool3_backward(void* gcat, int ld, int C, const void* arg0, const void* arg1, const void* arg2, int n, int h, int w,
+                           int acc0, int acc1, int acc2, hipStream_t stream);
 int dy_scalseq_tail(const void* r0, int ld0, const void* r1, int ld1, const void* r2, int ld2, const void* res,
                     int ldres, void* y, int ldy, const float* coef, int n, int h, int w, int C, hipStream_t stream);
 /* mode 0: BN3d backward partial sums for `level`; mode 1: dr_level */

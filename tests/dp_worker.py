@@ -15,12 +15,19 @@ from dp_common import STEPS, build_model, global_batch, hyper
 
 def main(out_dir):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("DY_TEST_DP_BACKEND", "gloo")
+    if backend == "nccl":  # RCCL: device tensors go into the collective as they are (hip/dist.py's non-gloo branch)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a one-rank group whose plan believes in `plan_world` ranks: every collective of the N > 1 path is issued (and is the identity)
+    plan_world = int(os.environ.get("DY_TEST_DP_PLAN_WORLD", world))
     from ultralytics.hip.dist import shard_batch
     from ultralytics.hip.train import StepPlan
     m = build_model().cuda().train()
     b = 2
-    plan = StepPlan(m, b, 64, nmax=8, optimizer="SGD", world_size=world, use_graph=True, init_scale=1.0, dynamic_scale=False)
+    plan = StepPlan(m, b, 64, nmax=8, optimizer="SGD", world_size=plan_world, use_graph=True, init_scale=1.0, dynamic_scale=False)
     for it, accumulate in enumerate(STEPS):
         for micro in range(accumulate):
             plan.set_hyper(*hyper(it))

@@ -72,3 +72,26 @@ def test_two_rank_step_equals_the_single_process_emulation(tmp_path, steps, buck
     if "2" not in steps:
         assert dp == 0.0 and db == 0.0 and de == 0.0
     assert dp < 1e-5 and db < 5e-5 and de < 1e-5
+
+
+@pytest.mark.parametrize("buckets", [1, 2])
+def test_rccl_runs_the_collective_path_on_the_gpu(tmp_path, buckets):
+    """The box has one GPU and RCCL refuses two ranks on one device, so the N > 1 replicas above talk over gloo through a host copy.
+    This runs the SAME step over RCCL itself: a one-rank "nccl" group whose StepPlan is told world_size = 2, so that every
+    collective of the data-parallel path is issued on device tensors -- the flat [gradients | buffers] all-reduce, and with
+    DY_DP_BUCKETS=2 the first bucket on the side stream beside the backbone's backward -- and must leave exactly the weights the
+    gloo form of the same one-rank run leaves (a one-rank all-reduce is the identity in both)."""
+    port = 29500 + (os.getpid() + 7 * buckets) % 2000
+    res = {}
+    for backend in ("nccl", "gloo"):
+        out = tmp_path / backend
+        out.mkdir()
+        env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", DY_TEST_DP_BACKEND=backend, DY_TEST_DP_PLAN_WORLD="2", DY_TEST_DP_STEPS="1,2,1",
+                   DY_DP_BUCKETS=str(buckets))
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(out)], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout
+        res[backend] = torch.load(os.path.join(out, "rank0.pt"))
+    for k in ("p", "b", "ema"):
+        assert torch.equal(res["nccl"][k], res["gloo"][k]), k

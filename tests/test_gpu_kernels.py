@@ -259,6 +259,57 @@ def test_pool_upsample_add():
     assert relerr(xa.st.gbuf.float().permute(0, 3, 1, 2), xr.grad) < 4e-3
 
 
+@pytest.mark.parametrize("C,H,W,ties", [(64, 40, 40, False), (16, 11, 13, True), (8, 56, 56, False), (24, 20, 20, True)])
+def test_sppf_fused_pools_equal_three_maxpool_launches(C, H, W, ties):
+    """Engine.sppf_pools (one launch, the map in LDS, separable passes) against the three dy_maxpool5 launches it replaces: pooled
+    slices, arg-max maps and the chained backward bit for bit -- with ties (values on a coarse grid, so that "first maximum in
+    row-major window order" decides) and with a NaN in the map (reference nn/modules/block.py:166-171 through ATen's max_pool2d)."""
+    import ultralytics.hip.engine as E
+    torch.manual_seed(9)
+    x = h16(torch.randn(3, C, H, W))
+    if ties:
+        x = (x * 2).round() / 2
+        x[1, 3, H // 2, W // 2] = float("nan")
+    g = h16(torch.randn(3, 4 * C, H, W))
+
+    def run(fused):
+        old, E.SPPF_FUSED = E.SPPF_FUSED, fused
+        try:
+            eng = _eng()
+            eng.tape = []
+            cat = eng.new_storage(3, H, W, 4 * C)
+            cat.buf.zero_()
+            cat.buf[..., :C] = x.cuda().permute(0, 2, 3, 1)
+            assert bool(eng.L.dy_sppf_pool3_supported(H, W, C))
+            n0 = len(eng.tape)
+            eng.sppf_pools(cat, C)
+            assert len(eng.tape) - n0 == (1 if fused else 3)
+            a = cat.act()
+            a._gbuf()[...] = g.cuda().permute(0, 2, 3, 1)
+            cat.gwritten.append((0, 4 * C))
+            for f in reversed(eng.tape):
+                f()
+            torch.cuda.synchronize()
+            return cat.buf.clone(), cat.gbuf[..., :C].clone()
+        finally:
+            E.SPPF_FUSED = old
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    assert torch.equal(torch.nan_to_num(y1.float(), nan=7e4), torch.nan_to_num(y0.float(), nan=7e4))
+    dg = (torch.nan_to_num(g1.float(), nan=7e4) - torch.nan_to_num(g0.float(), nan=7e4)).abs()
+    assert float(dg.max()) == 0.0, (float(dg.max()), int((dg > 0).sum()), (dg > 0).nonzero()[:4].tolist(), int(torch.isnan(g0).sum()), int(torch.isnan(g1).sum()))
+    if not ties:  # and both are ATen's chain
+        xr = x.clone().requires_grad_(True)
+        ys = [xr]
+        for _ in range(3):
+            ys.append(F.max_pool2d(ys[-1], 5, 1, 2))
+        cat = torch.cat(ys, 1)
+        cat.backward(g)
+        assert torch.equal(y1.float().permute(0, 3, 1, 2).cpu(), cat.detach())
+        assert relerr(g1.float().permute(0, 3, 1, 2).cpu(), xr.grad) < 2e-3
+
+
 def test_wgrad_deferred_batched_reduce_matches_immediate():
     """dy_conv_wgrad with dw == NULL + dy_wgrad_reduce_batched (what StepPlan's backward trace uses: every layer's slabs
     reduced by one launch) gives the same fp32 gradients as the immediate per-layer reduction."""
