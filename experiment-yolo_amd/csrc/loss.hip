@@ -206,14 +206,24 @@ static __device__ __forceinline__ float softmax16_expect(float logit, int bin, f
 // 16 lanes per anchor (lane = side*4 + quarter, 4 consecutive bins each): one 16-byte load per lane, a wave covers four
 // anchors per instruction and the 16-bin softmax needs two shuffles instead of four.
 __global__ __launch_bounds__(256) void decode_kernel(LossCtx c) {
-  const long total = (long)c.B * c.A;
+  // blockIdx.y = image.  No integer division in the loop: the logits of anchor a of level l lie at pixel b*H*W + (a - a0) of that
+  // level's tensor, and the row is floor((r + 0.5) / W) in fp32 (r + 0.5 is at least 0.5 / W away from a multiple of W; the
+  // product with the rounded reciprocal is off by < 1e-4 of a row for any map a 32-bit anchor index can address).  The first form
+  // spent a 64-bit and a 32-bit division per 16-byte load and was VALU-bound at 3.1 TB/s.
   const int sub = threadIdx.x & 15, side = sub >> 2, quarter = sub & 3;
-  for (long ba = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; ba < total; ba += ((long)gridDim.x * 256) >> 4) {
-    const int b = (int)(ba / c.A), a = (int)(ba - (long)b * c.A);
-    int l, iy, ix;
-    anchor_of(c, a, l, iy, ix);
+  const int b = blockIdx.y;
+  float invw[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) invw[k] = k < c.nl ? 1.0f / (float)c.lv[k].W : 0.f;
+  for (int a = (int)((blockIdx.x * 256 + threadIdx.x) >> 4); a < c.A; a += (int)((gridDim.x * 256) >> 4)) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (k < c.nl && a >= c.lv[k].a0) l = k;
     const Level& L = c.lv[l];
-    const float4 v = *reinterpret_cast<const float4*>(L.box + (((size_t)b * L.H + iy) * L.W + ix) * 64 + sub * 4);
+    const int r = a - L.a0;
+    const int iy = (int)(((float)r + 0.5f) * invw[l]), ix = r - iy * L.W;
+    const float4 v = *reinterpret_cast<const float4*>(L.box + ((size_t)b * (L.H * L.W) + r) * 64 + sub * 4);
     float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
     m = fmaxf(m, __shfl_xor(m, 1, 64));
     m = fmaxf(m, __shfl_xor(m, 2, 64));
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void decode_kernel(LossCtx c) {
     num += __shfl_xor(num, 2, 64);
     const float e = num / den;
     const float anc = (side & 1) ? (iy + 0.5f) : (ix + 0.5f);
-    if (quarter == 0) c.pred_box[ba * 4 + side] = side < 2 ? anc - e : anc + e;
+    if (quarter == 0) c.pred_box[((size_t)b * c.A + a) * 4 + side] = side < 2 ? anc - e : anc + e;
   }
 }
 
@@ -772,8 +782,8 @@ extern "C" int dy_detection_loss(const DyLossArgs* d, hipStream_t stream) {
   if (hipMemsetAsync(c.cnt, 0, BA * 4, stream) != hipSuccess) return DY_ERR_LAUNCH;
   const int gridA = (int)((BA * 64 + 255) / 256 < 2048 ? (BA * 64 + 255) / 256 : 2048);
   {
-    const long nb = ((long)BA * 16 + 255) / 256;
-    hipLaunchKernelGGL(decode_kernel, dim3((int)(nb < 4096 ? nb : 4096)), dim3(256), 0, stream, c);
+    const long nb = ((long)c.A * 16 + 255) / 256;  // per image: 16 lanes per anchor; blockIdx.y = image
+    hipLaunchKernelGGL(decode_kernel, dim3((int)(nb < 256 ? nb : 256), c.B), dim3(256), 0, stream, c);
   }
   hipLaunchKernelGGL(tal_topk_kernel, dim3((int)BN), dim3(256), 0, stream, c);
   hipLaunchKernelGGL(tal_scatter_kernel, dim3(cdiv((int)BN * TOPK, 256)), dim3(256), 0, stream, c);
