@@ -516,3 +516,43 @@ def test_bn_backward_reduce_in_the_dgrad_epilogue(cp, cq, ks, H, W):
     assert torch.equal(dx_a, dx_b)
     sa, sb = acc_a.view(DY_BN_COPIES, 2, cp).sum(0), acc_b.view(DY_BN_COPIES, 2, cp).sum(0)
     assert relerr(sa, sb) < 2e-5, relerr(sa, sb)
+
+
+@pytest.mark.parametrize("ratio", [1.0, 30.0, 300.0])
+def test_bn_backward_reduce_with_a_large_mean_to_std_ratio(ratio):
+    """The backward reduce sums g and g*x on the RAW conv outputs and forms sum(g * xhat) = (sum(g x) - mean sum(g)) * invstd
+    afterwards (per thread, fp32; blocks are added in fp64): a cancellation when |mean| >> std.  Measured against an fp64
+    evaluation of the same sums on the same fp16 inputs -- the bound grows with the ratio as eps_fp32 * ratio * sqrt(terms)
+    and stays far below what the fp16 storage of the activations itself costs."""
+    torch.manual_seed(11)
+    eng = _eng()
+    N, C, H, W = 4, 32, 40, 40
+    std = 0.5
+    x = h16(torch.randn(N, C, H, W) * std + ratio * std)
+    dy = h16(torch.randn(N, C, H, W))
+    xa, da = _act(eng, x), _act(eng, dy)
+    npix = N * H * W
+    xf = x.double().permute(0, 2, 3, 1).reshape(npix, C)
+    mean = xf.mean(0)
+    var = xf.var(0, unbiased=False)
+    inv = 1.0 / torch.sqrt(var + 1e-3)
+    gamma = torch.rand(C, dtype=torch.float64) + 0.5
+    beta = torch.randn(C, dtype=torch.float64) * 0.1
+    coef = torch.stack([gamma * inv, beta - mean * gamma * inv, mean, inv]).float().cuda().contiguous()
+    from ultralytics.hip import DY_BN_COPIES, check
+    acc = torch.zeros(DY_BN_COPIES, 2, C, dtype=torch.float64, device="cuda")
+    check(eng.L.dy_bn_act_bwd_reduce_acc(da.ptr, da.ld, xa.ptr, xa.ld, coef.data_ptr(), acc.data_ptr(), npix, C, 1, 0, 0, 0, eng.stream), "reduce")
+    torch.cuda.synchronize()
+    got = acc.sum(0).cpu()
+    # fp64 reference with the coefficients the kernel saw (fp32 scale / shift / mean / invstd)
+    cf = coef.double().cpu()
+    z = xf * cf[0] + cf[1]
+    s = torch.sigmoid(z)
+    g = dy.double().permute(0, 2, 3, 1).reshape(npix, C) * (s * (1 + z * (1 - s)))
+    ref = torch.stack([g.sum(0), (g * (xf - cf[2]) * cf[3]).sum(0)])
+    scale = torch.stack([g.abs().sum(0), (g * (xf - cf[2]) * cf[3]).abs().sum(0)])
+    err = float(((got - ref).abs() / scale).max())
+    print(f"mean/std {ratio:g}: worst |error| / sum|terms| = {err:.2e}")
+    # measured 1.1e-8 / 1.1e-7 / 1.1e-6 (linear in the ratio, as the fp32 cancellation predicts); fp16 storage of x alone costs
+    # 5e-4 relative per element
+    assert err < {1.0: 1e-7, 30.0: 1e-6, 300.0: 1e-5}[ratio]
