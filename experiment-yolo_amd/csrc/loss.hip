@@ -802,7 +802,7 @@ extern "C" int dy_detection_loss(const DyLossArgs* d, hipStream_t stream) {
   }
   c.partials = partB;
   for (int l = 0; l < c.nl; ++l)  // background anchors get zero box-gradient: one memset instead of 2 M scattered stores
-    if (c.lv[l].dbox && hipMemsetAsync(c.lv[l].dbox, 0, (size_t)c.B * c.lv[l].H * c.lv[l].W * 64 * 2, stream) != hipSuccess)
+    if (c.lv[l].dbox && !d->dbox_rows_only && hipMemsetAsync(c.lv[l].dbox, 0, (size_t)c.B * c.lv[l].H * c.lv[l].W * 64 * 2, stream) != hipSuccess)
       return DY_ERR_LAUNCH;
   hipLaunchKernelGGL(box_loss_kernel, dim3(gridA), dim3(256), 0, stream, c);
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, stream, c, partB, gridA, partC, n_cls);

@@ -59,6 +59,10 @@ BIAS_WGRAD = BN_ACC and os.environ.get("DY_BIAS_WGRAD", "1") != "0"
 # SPPF's three chained 5x5 pools (and their backward chain) as one launch each with the map resident in LDS, when it fits
 # (Engine.sppf_pools; =0: three dy_maxpool5 / dy_maxpool5_backward launches).
 SPPF_FUSED = os.environ.get("DY_SPPF_FUSED", "1") != "0"
+# Detect's final box convolution back-propagated from the ROWS of its output gradient (the loss writes box / DFL gradients for
+# foreground anchors only): csrc/head_rows.hip reads the loss's assignment instead of a zero-filled dense gradient.  Only inside a
+# StepPlan trace (the plan binds the assignment buffer and tells the loss not to zero the rest); DY_HEAD_ROWS=0: the dense kernels.
+HEAD_ROWS = BIAS_WGRAD and os.environ.get("DY_HEAD_ROWS", "1") != "0"
 BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
 BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
 
@@ -757,17 +761,38 @@ class Engine:
             self.call("dy_add", y.ptr, y.ld, res.ptr, res.ld, 0, 0, y.ptr, y.ld, y.npix, y.C)
         return y
 
-    def conv_bias(self, spec: ConvSpec, x: Act, y_ptr, ldy, f32out=True, dy_ptr_fn=None, out_hw=None):
+    def conv_bias(self, spec: ConvSpec, x: Act, y_ptr, ldy, f32out=True, dy_ptr_fn=None, out_hw=None, rows_level=None):
         """Plain conv + bias (Detect's final nn.Conv2d 1x1, reference nn/modules/head.py:38-42).  ``dy_ptr_fn`` returns
-        (ptr, ld) of the fp16 gradient w.r.t. the output at backward time."""
+        (ptr, ld) of the fp16 gradient w.r.t. the output at backward time.  ``rows_level``: this is the box branch of detection
+        level ``rows_level`` -- its output gradient is non-zero at foreground anchors only (see HEAD_ROWS)."""
         self._use(x)
         self._conv_raw(spec, x, y_ptr, ldy, DY_EPI_BIAS | (DY_EPI_F32OUT if f32out else 0), 0, spec.bias)
         if self.tape is not None:
-            self.tape.append(lambda: self._conv_bias_bwd(spec, x, dy_ptr_fn))
+            if (rows_level is not None and self.rows_used is not None and spec.ks == 1 and spec.ld is None and spec.acc_bias is not None
+                    and self.L.dy_conv1x1_rows_supported(spec.cin, spec.cout)):
+                self.rows_used.add(rows_level)
+            else:
+                rows_level = None
+            self.tape.append(lambda: self._conv_bias_bwd(spec, x, dy_ptr_fn, rows_level=rows_level))
 
-    def _conv_bias_bwd(self, spec, x, dy_ptr_fn, accumulate=0, defer=True):
+    rows_used = None   # set() while a StepPlan traces its forward: the detection levels whose box conv can take the rows form
+    loss_rows = None   # (assignment pointer, anchors per image, first anchor of each level) once the plan has bound the loss
+
+    def _conv_bias_bwd(self, spec, x, dy_ptr_fn, accumulate=0, defer=True, rows_level=None):
         dyp, ld = dy_ptr_fn()
         Ho, Wo = self.out_hw(spec, x)
+        if (rows_level is not None and self.loss_rows is not None and defer and not accumulate and self.deferred_wgrad is not None
+                and not self.side_wgrad):
+            asg, A, a0 = self.loss_rows
+            ns = self.L.dy_conv1x1_rows_slabs()
+            slabs = self.transient((ns * spec.cout * spec.cin,), torch.float32)
+            self.hold(slabs)
+            self.deferred_wgrad.append((spec, slabs, ns, spec.acc_bias))
+            acc = x.grad_target() if x.needs_grad else 0
+            self.call("dy_conv1x1_rows_backward", x.ptr, x.ld, dyp, ld, asg, A, a0[rows_level], spec.weight.data_ptr(),
+                      x.gptr if x.needs_grad else 0, x.ld, acc, slabs.data_ptr(), self._acc_ready(spec.acc_bias), x.N, Ho, Wo,
+                      spec.cin, spec.cout)
+            return
         if (BIAS_WGRAD and defer and not accumulate and self.deferred_wgrad is not None and spec.acc_bias is not None and spec.ld is None
                 and not self.side_wgrad):
             # the bias gradient rides on the weight-gradient kernel (sum of dY while it is staged) and the batched slab reduction

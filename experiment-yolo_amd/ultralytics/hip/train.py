@@ -124,10 +124,17 @@ class StepPlan:
             eng.zero_acc_pool()
             rt.pack_all(transposed=True)
             x = self.import_input()
+            from .engine import HEAD_ROWS
+            eng.rows_used, eng.loss_rows = (set() if HEAD_ROWS else None), None
             ho = model.forward_act(x)
             crit.bind(ho, self.nmax, gscale=self.state[0:1])
             crit.__dict__["_last"] = crit
             crit.sync_modes()
+            # every level's box conv can be back-propagated from the foreground rows of its gradient: the loss need not zero the rest
+            rows = eng.rows_used is not None and len(eng.rows_used) == len(ho.box)
+            crit._args.dbox_rows_only = 1 if rows else 0
+            if rows:
+                eng.loss_rows = crit.assignment_rows()
             eng.call("dy_detection_loss", C.byref(crit._args))
             self.fb_split = len(eng.rec.ops)  # [0, fb_split) = forward + loss, the rest = backward (forward_only / backward_accumulate)
             eng.deferred_wgrad = []
@@ -144,6 +151,7 @@ class StepPlan:
             eng.flush_wgrad()
         finally:
             eng.deferred_wgrad = None
+            eng.rows_used = eng.loss_rows = None
             eng.side_wgrad = False
             eng.acc_zeroed = False
             eng.arena = None

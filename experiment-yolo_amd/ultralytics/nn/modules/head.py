@@ -102,7 +102,7 @@ class Detect(HipModule):
             a = self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(x))
             c = self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(x))
             eng.conv_bias(rt.specs[(id(self), "cv2", l)], a, boxes[l].data_ptr(), nb, True,
-                          lambda l=l: (ho.dbox[l].data_ptr(), nb))
+                          lambda l=l: (ho.dbox[l].data_ptr(), nb), rows_level=l)
             eng.conv_bias(rt.specs[(id(self), "cv3", l)], c, clss[l].data_ptr(), ncp, True,
                           lambda l=l: (ho.dcls[l].data_ptr(), ncp))
         return ho

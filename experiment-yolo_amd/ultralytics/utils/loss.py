@@ -192,6 +192,19 @@ class v8DetectionLoss:
             cls.append(c)
         return HeadOut(box, cls, self.nc, [float(s) for s in self.stride])
 
+    def assignment_rows(self):
+        """(device pointer of the per-anchor assigned-gt index (B, A) int32 the loss kernels leave in the workspace, A, first anchor
+        of each level) of the bound geometry: what dy_conv1x1_rows_backward reads instead of a dense box-logit gradient."""
+        from ..hip import lib
+        a = self._args
+        o = [C.c_size_t() for _ in range(3)]
+        lib().dy_loss_workspace_layout(a.B, self.A, a.nmax, *[C.byref(x) for x in o])
+        a0, first = 0, []
+        for l in range(a.nl):
+            first.append(a0)
+            a0 += a.H[l] * a.W[l]
+        return self._ws.data_ptr() + o[1].value, self.A, first
+
     def debug_assignment(self):
         """(target_gt_idx (B,A) with -1 for background, target score (B,A), pred boxes (B,A,4)) of the last call."""
         from ..hip import lib

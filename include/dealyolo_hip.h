@@ -266,12 +266,26 @@ typedef struct DyLossArgs {
   float* scalars;                /* 16 persistent floats: [1] target_scores_sum [3] #fg [4] WIoU iou_mean (init 1)
                                     [5..7] loss_items box,cls,dfl [8] loss.sum()*B [9] error flag */
   void* workspace;               /* dy_loss_workspace_bytes(B, A, nmax) bytes */
+  int dbox_rows_only;            /* non-zero: dbox is written at foreground anchors only and NOT zeroed elsewhere -- for a consumer that
+                                    reads it through the assignment (dy_conv1x1_rows_backward); 0: every row is defined */
 } DyLossArgs;
 size_t dy_loss_workspace_bytes(int B, int A, int nmax);
 /* byte offsets of pred_box (B,A,4 f32, grid units), assigned gt index (B,A i32, -1 = background) and target score
  * (B,A f32) inside the workspace after a call -- used by the parity tests */
 int dy_loss_workspace_layout(int B, int A, int nmax, size_t* off_pred_box, size_t* off_asg_gt, size_t* off_tscore);
 int dy_detection_loss(const DyLossArgs* args, hipStream_t stream);
+/* Backward of Detect's final box convolution (nn/modules/head.py:38-40, Conv2d(c2, 4*reg_max, 1) with bias) from a gradient that has
+ * ROWS: utils/loss.py:436-445 gives box / DFL terms to foreground anchors only, every other row of d(box logits) is zero.
+ * assigned: the loss's per-anchor gt index (B, A) int32, -1 = background (workspace + off_asg_gt of dy_loss_workspace_layout);
+ * this level's pixel (b, r) is anchor a0 + r.  Weight gradient: dy_conv1x1_rows_slabs() fp32 slabs [64][64] for
+ * dy_wgrad_reduce_batched (descriptor: cin 64, cout 64, ks 1); bias gradient: fp64 sums into bias_acc [DY_BN_COPIES][64] (finished by
+ * dy_wgrad_reduce_desc_bias); input gradient dx (may be NULL): W^T dy on foreground pixels, zeros (or untouched when dx_accumulate)
+ * elsewhere.  Rows of dy whose anchor is background are never read.  Supported: cin == cout == 64. */
+int dy_conv1x1_rows_supported(int cin, int cout);
+int dy_conv1x1_rows_slabs(void);
+int dy_conv1x1_rows_backward(const void* x, int ldx, const void* dy, int lddy, const int* assigned, int A, int a0,
+                             const float* weight, void* dx, int lddx, int dx_accumulate, float* slabs, double* bias_acc, int n,
+                             int h, int w, int cin, int cout, hipStream_t stream);
 /* TaskAlignedAssigner.forward utils/tal.py:39-88 as a call of its own (topk 10, alpha 0.5, beta 6.0: what v8DetectionLoss builds,
  * utils/loss.py:311): scores[l] (B,H,W,ncp) class PROBABILITIES (pd_scores re-laid per level), pd_boxes_grid (B,A,4) xyxy in grid
  * units (pd_bboxes / stride), gt_labels (B,n) int32, gt_bboxes (B,n,4) xyxy pixels, mask_gt (B,n) int32.  Out: asg_gt (B,A) int32,

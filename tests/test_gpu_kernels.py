@@ -556,3 +556,46 @@ def test_bn_backward_reduce_with_a_large_mean_to_std_ratio(ratio):
     # measured 1.1e-8 / 1.1e-7 / 1.1e-6 (linear in the ratio, as the fp32 cancellation predicts); fp16 storage of x alone costs
     # 5e-4 relative per element
     assert err < {1.0: 1e-7, 30.0: 1e-6, 300.0: 1e-5}[ratio]
+
+
+@pytest.mark.parametrize("acc", [0, 1])
+def test_conv1x1_rows_backward_reads_foreground_rows_only(acc):
+    """dy_conv1x1_rows_backward (Detect's final box conv from the rows of its gradient, reference nn/modules/head.py:38-40 +
+    utils/loss.py:436-445): weight / bias / input gradients against the dense fp32 products, with NaN in every background row of the
+    gradient -- a background row that is read shows up in all three."""
+    import ctypes as C
+    from ultralytics.hip import DY_BN_COPIES, check, lib
+    L = lib()
+    torch.manual_seed(4)
+    B, H, W, A0, Aextra = 3, 9, 13, 50, 7
+    hw, A = H * W, 50 + 9 * 13 + 7
+    npix = B * hw
+    x = h16(torch.randn(npix, 64)).cuda().half()
+    w = (torch.randn(64, 64) / 8).cuda()
+    fg = torch.rand(B, hw) < 0.08
+    fg[0, 0] = fg[2, hw - 1] = True
+    asg = torch.full((B, A), -1, dtype=torch.int32)
+    asg[:, :A0] = 3  # other levels' anchors: foreground there must not leak into this level
+    asg[:, A0:A0 + hw][fg] = 1
+    dy = torch.full((npix, 64), float("nan"), dtype=torch.float16)
+    rows = fg.reshape(-1)
+    dy[rows] = h16(torch.randn(int(rows.sum()), 64)).half()
+    dyc = dy.cuda()
+    dx0 = h16(torch.randn(npix, 64)).cuda().half()
+    dx = dx0.clone()
+    ns = L.dy_conv1x1_rows_slabs()
+    slabs = torch.full((ns, 64, 64), float("nan"), device="cuda")
+    bacc = torch.zeros(DY_BN_COPIES, 64, dtype=torch.float64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    check(L.dy_conv1x1_rows_backward(x.data_ptr(), 64, dyc.data_ptr(), 64, asg.cuda().data_ptr(), A, A0, w.data_ptr(), dx.data_ptr(), 64, acc,
+                                     slabs.data_ptr(), bacc.data_ptr(), B, H, W, 64, 64, s), "rows")
+    torch.cuda.synchronize()
+    d = torch.nan_to_num(dy.float(), nan=0.0).cuda()
+    dw_ref = d.t().double() @ x.double()
+    assert relerr(slabs.double().sum(0), dw_ref) < 1e-6
+    assert relerr(bacc.sum(0), d.double().sum(0)) < 1e-6
+    dx_ref = d @ w.half().float() + (dx0.float() if acc else 0.0)
+    assert torch.isfinite(dx.float()).all()
+    assert relerr(dx.float(), dx_ref) < 2e-3
+    bg = ~rows.cuda()
+    assert torch.equal(dx[bg], dx0[bg] if acc else torch.zeros_like(dx0[bg]))
