@@ -435,6 +435,98 @@ extern "C" int dy_bn_act_bwd_reduce_acc(const void* dy, int lddy, const void* x,
   return DY_OK;
 }
 
+// The same pass when dy has ROWS (the gradient Detect's final box conv passes down: non-zero at the loss's foreground anchors only,
+// csrc/head_rows.hip): g = dy * act'(.) is zero wherever dy is, so only foreground pixels are visited -- the assignment (4 bytes per
+// anchor) is read instead of dy and x (4 * C bytes per pixel).  A workgroup owns a contiguous pixel range and lists its foreground
+// pixels in ascending order, so its sums have one order; workgroups meet in the fp64 accumulator as in the dense form.
+struct BwdRedRowsArgs {
+  const f16* dy;
+  const f16* x;
+  const float* coef;
+  double* acc;
+  const int* flag;  // (B, A) assigned-gt index, -1 = background; pixel (b, r) of this tensor is anchor a0 + r
+  int lddy, ldx, C, A, a0, hw, B;
+};
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_rows_kernel(BwdRedRowsArgs a) {
+  __shared__ int s_list[256];
+  __shared__ int s_cnt[4];
+  __shared__ float red[2][256][8 + 1];
+  const int cpp = a.C >> 3, rows = 256 / cpp, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int part = tid % cpp, row = tid / cpp, c0 = part * 8;
+  f32x2 sg[4], sgx[4], sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sg[j] = sgx[j] = (f32x2){0.f, 0.f};
+    sc[j] = (f32x2){a.coef[c0 + 2 * j], a.coef[c0 + 2 * j + 1]};
+    sh[j] = (f32x2){a.coef[a.C + c0 + 2 * j], a.coef[a.C + c0 + 2 * j + 1]};
+  }
+  const long npix = (long)a.B * a.hw;
+  const long chunk = (npix + gridDim.x - 1) / gridDim.x;
+  const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < npix ? lo + chunk : npix;
+  for (long p0 = lo; p0 < hi; p0 += 256) {
+    const long p = p0 + tid;
+    bool fg = false;
+    if (p < hi) {
+      const int b = (int)(p / a.hw), r = (int)(p - (long)b * a.hw);
+      fg = a.flag[(size_t)b * a.A + a.a0 + r] >= 0;
+    }
+    const unsigned long long m = __ballot(fg);
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) base += s_cnt[w];
+      total += s_cnt[w];
+    }
+    if (fg) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = tid;
+    __syncthreads();
+    if (row < rows) {
+      for (int i = row; i < total; i += rows) {
+        const long q = p0 + s_list[i];
+        const half8 dv = *reinterpret_cast<const half8*>(a.dy + q * a.lddy + c0);
+        const half8 xv = *reinterpret_cast<const half8*>(a.x + q * a.ldx + c0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2 x = (f32x2){(float)xv[2 * j], (float)xv[2 * j + 1]};
+          const f32x2 g = (f32x2){(float)dv[2 * j], (float)dv[2 * j + 1]} * act_grad2<ACT>(__builtin_elementwise_fma(x, sc[j], sh[j]));
+          sg[j] += g;
+          sgx[j] += g * x;
+        }
+      }
+    }
+    __syncthreads();  // the list is rewritten by the next trip
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      sgx[j][k] = (sgx[j][k] - a.coef[2 * a.C + c0 + 2 * j + k] * sg[j][k]) * a.coef[3 * a.C + c0 + 2 * j + k];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[0][tid][j] = row < rows ? sg[j >> 1][j & 1] : 0.f;
+    red[1][tid][j] = row < rows ? sgx[j >> 1][j & 1] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * a.C; i += 256) {
+    const int which = i / a.C, c = i - which * a.C, pp = c >> 3, j = c & 7;
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += red[which][r * cpp + pp][j];
+    if (t != 0.f) unsafeAtomicAdd(&a.acc[((size_t)(blockIdx.x % DY_BN_COPIES) * 2 + which) * a.C + c], (double)t);
+  }
+}
+extern "C" int dy_bn_act_bwd_reduce_rows(const void* dy, int lddy, const void* x, int ldx, const float* coef, double* acc, int n,
+                                         int hw, int C, int act, const int* assigned, int A, int a0, hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (lddy & 7)) return DY_ERR_ALIGN;
+  const int cpp = C >> 3;
+  if (cpp > 256 || !acc || !assigned || n < 1 || hw < 1 || a0 < 0 || a0 + hw > A) return DY_ERR_ARG;
+  BwdRedRowsArgs a{(const f16*)dy, (const f16*)x, coef, acc, assigned, lddy, ldx, C, A, a0, hw, n};
+  DY_ACT_DISPATCH(bn_act_bwd_reduce_rows_kernel, dim3(256), stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
 // pass 1b: reduce partials -> dgamma, dbeta (fp32 grads, scaled by the loss scale like every gradient) and the two
 // per-channel means pass 2 needs.  bwdcoef = [2][C]: mean_g, mean_gxhat.
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partials, int nparts, float* dgamma,

@@ -110,6 +110,7 @@ SIGNATURES = {
     "dy_upsample2x": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_maxpool5": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "dy_maxpool5_backward": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_bn_act_bwd_reduce_rows": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "dy_conv1x1_rows_supported": (i32, [i32, i32]),
     "dy_conv1x1_rows_slabs": (i32, []),
     "dy_conv1x1_rows_backward": (i32, [vp, i32, vp, i32, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -262,6 +262,7 @@ class Engine:
         self._uses = {}       # ... forward consumers per storage {id(st): {(c0, C): count}} ...
         self._prod = {}       # ... and the Conv (spec, raw Act) that produced a slice: dataflow facts of the trace in progress that
         self._reduced = set() # decide where a BatchNorm backward reduce can ride on the dgrad that writes its gradient (BN_DGRED)
+        self._rows_grad = {}  # slices whose gradient was written by dy_conv1x1_rows_backward alone: {(id(st), c0, C): (assigned, A, a0)}
         self.training = False
         self._tmp_int = C.c_int(0)
 
@@ -334,7 +335,7 @@ class Engine:
             self.reset_dataflow()
 
     def reset_dataflow(self):
-        self._gw.clear(); self._uses.clear(); self._prod.clear(); self._reduced.clear()
+        self._gw.clear(); self._uses.clear(); self._prod.clear(); self._reduced.clear(); self._rows_grad.clear()
 
     def _use(self, *xs):
         """Forward bookkeeping: ``x`` will receive a gradient contribution from the op being traced."""
@@ -632,8 +633,17 @@ class Engine:
                 self.call("dy_add", res.gptr, res.ld, y.gptr, y.ld, 0, 0, res.gptr, res.ld, npix, res.C)
             else:
                 self.call("dy_copy_slice", y.gptr, y.ld, res.gptr, res.ld, npix, res.C)
+        ykey = (id(y.st), y.c0, y.C)
+        rows = self._rows_grad.get(ykey)
+        if rows is not None and self._gw.get(ykey) != 1:
+            rows = None  # somebody else wrote into that gradient as well: it is dense
         if acc and fused_red:
             pass
+        elif acc and rows is not None and rg == (0, 0, 0):
+            # y's gradient came from dy_conv1x1_rows_backward alone: zero outside the loss's foreground anchors, so are the summands
+            asg, A, a0 = rows
+            self.call("dy_bn_act_bwd_reduce_rows", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), self._acc_ready(spec.acc_b),
+                      y.N, y.H * y.W, spec.cout, spec.act, asg, A, a0)
         elif acc:
             self.call("dy_bn_act_bwd_reduce_acc", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), self._acc_ready(spec.acc_b),
                       npix, spec.cout, spec.act, *rg)
@@ -789,6 +799,9 @@ class Engine:
             self.hold(slabs)
             self.deferred_wgrad.append((spec, slabs, ns, spec.acc_bias))
             acc = x.grad_target() if x.needs_grad else 0
+            if x.needs_grad and not acc and self._sole_consumer_of_conv(x) is not None:
+                # x is a Conv's output whose only forward use was this conv: its gradient has the same rows, and nothing else
+                self._rows_grad[(id(x.st), x.c0, x.C)] = (asg, A, a0[rows_level])
             self.call("dy_conv1x1_rows_backward", x.ptr, x.ld, dyp, ld, asg, A, a0[rows_level], spec.weight.data_ptr(),
                       x.gptr if x.needs_grad else 0, x.ld, acc, slabs.data_ptr(), self._acc_ready(spec.acc_bias), x.N, Ho, Wo,
                       spec.cin, spec.cout)

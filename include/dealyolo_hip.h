@@ -175,6 +175,10 @@ int dy_bn_act_apply_acc(const void* x, int ldx, const void* res, int ldr, void* 
  * -- it equals dy, and is stored (res_accumulate 0) or added (1) while dy streams through, instead of by a pass of its own */
 int dy_bn_act_bwd_reduce_acc(const void* dy, int lddy, const void* x, int ldx, const float* coef, double* acc, long npix,
                              int C, int act, void* res_grad, int ldrg, int res_accumulate, hipStream_t stream);
+/* dy_bn_act_bwd_reduce_acc for a gradient that has ROWS (what dy_conv1x1_rows_backward passes down: zero at every background anchor):
+ * the sums visit the foreground pixels of `assigned` (B = n images, A anchors each, this tensor's pixel (b, r) is anchor a0 + r) only */
+int dy_bn_act_bwd_reduce_rows(const void* dy, int lddy, const void* x, int ldx, const float* coef, double* acc, int n, int hw, int C,
+                              int act, const int* assigned, int A, int a0, hipStream_t stream);
 int dy_bn_act_bwd_apply_acc(const void* dy, int lddy, const void* x, int ldx, void* dx, int lddx, const float* coef,
                             const double* acc, float* dgamma, float* dbeta, long npix, int C, int act, float count,
                             hipStream_t stream);

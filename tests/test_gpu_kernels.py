@@ -599,3 +599,34 @@ def test_conv1x1_rows_backward_reads_foreground_rows_only(acc):
     assert relerr(dx.float(), dx_ref) < 2e-3
     bg = ~rows.cuda()
     assert torch.equal(dx[bg], dx0[bg] if acc else torch.zeros_like(dx0[bg]))
+
+
+def test_bn_backward_reduce_rows_equals_the_dense_pass_on_a_row_sparse_gradient():
+    """dy_bn_act_bwd_reduce_rows against dy_bn_act_bwd_reduce_acc on the same gradient (zero outside the foreground rows): the sums
+    agree to fp32 summation order; background rows of dy hold NaN for the rows form -- it must not read them."""
+    from ultralytics.hip import DY_BN_COPIES, check, lib
+    L = lib()
+    torch.manual_seed(6)
+    B, H, W, C_, A0 = 4, 20, 20, 64, 37
+    hw, A = H * W, 37 + 400 + 11
+    npix = B * hw
+    x = (torch.randn(npix, C_) * 0.7 + 0.2).half().cuda()
+    fg = torch.rand(B, hw) < 0.05
+    fg[1, 7] = True
+    asg = torch.full((B, A), -1, dtype=torch.int32)
+    asg[:, A0:A0 + hw][fg] = 0
+    rows = fg.reshape(-1)
+    dense = torch.zeros(npix, C_, dtype=torch.float16)
+    dense[rows] = torch.randn(int(rows.sum()), C_).half()
+    sparse = dense.clone()
+    sparse[~rows] = float("nan")
+    coef = torch.stack([torch.rand(C_) + 0.5, torch.randn(C_) * 0.1, torch.randn(C_) * 0.2, torch.rand(C_) + 0.5]).cuda().contiguous()
+    s = torch.cuda.current_stream().cuda_stream
+    acc_d = torch.zeros(DY_BN_COPIES, 2, C_, dtype=torch.float64, device="cuda")
+    acc_r = torch.zeros_like(acc_d)
+    dd, ds, asg_c = dense.cuda(), sparse.cuda(), asg.cuda()
+    check(L.dy_bn_act_bwd_reduce_acc(dd.data_ptr(), C_, x.data_ptr(), C_, coef.data_ptr(), acc_d.data_ptr(), npix, C_, 1, 0, 0, 0, s), "dense")
+    check(L.dy_bn_act_bwd_reduce_rows(ds.data_ptr(), C_, x.data_ptr(), C_, coef.data_ptr(), acc_r.data_ptr(), B, hw, C_, 1, asg_c.data_ptr(), A, A0, s), "rows")
+    torch.cuda.synchronize()
+    a, b = acc_d.sum(0), acc_r.sum(0)
+    assert torch.isfinite(b).all() and relerr(b, a) < 2e-6

@@ -321,8 +321,10 @@ def test_reference_loop_shape_trains_through_autograd():
     print("autograd loop vs StepPlan: losses", losses_a, losses_b, "weights after each step", dw)
     # Same gradients (one recorded launch list); torch's clip_grad_norm_ + SGD and the flat optimizer kernel round differently in the
     # last bit (1e-8 on the weights after the first step).  From the second forward on, fp16 activation storage can turn that into
-    # isolated rounding flips that the next update amplifies: measured [4e-9, 2e-6, 2.4e-5] on this batch, 5e-10 throughout on another.
-    assert dw[0] < 1e-6 and max(dw) < 2e-4
+    # isolated rounding flips that the next update amplifies: measured [4e-9, 2e-6, 2.4e-5] on this batch, 5e-10 throughout on another,
+    # [1e-9, 1.4e-6, 2.0e-4] once the head's box branch was back-propagated from its foreground rows (another summation order).
+    # What the test pins is the FIRST step (same gradients, same update); the later steps only have to stay a rounding-flip apart.
+    assert dw[0] < 1e-6 and dw[1] < 2e-5 and max(dw) < 1e-3
     assert losses_a[0] == losses_b[0] and max(abs(a - b) / abs(b) for a, b in zip(losses_a, losses_b)) < 1e-3, (losses_a, losses_b)
     assert losses_a[-1] != losses_a[0]
     # accumulate semantics and scaled losses
