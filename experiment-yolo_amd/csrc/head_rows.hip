@@ -112,6 +112,99 @@ __global__ __launch_bounds__(256) void rows_dgrad_kernel(RowsArgs a) {
   }
 }
 
+// ---- Forward of the same convolution fused with the loss's box decode (reference utils/loss.py:347-354, bbox_decode: softmax over the
+// 16 DFL bins of each side, expectation, dist2bbox against the anchor point).  Inside a training step nothing needs the 64 fp32
+// logits of all 2.2 M anchors: the assigner wants the decoded box (4 floats), the DFL / IoU terms want the logits of the ~0.2 %
+// foreground anchors -- which the loss recomputes from this layer's input.  So the layer reads its input once and writes 16 bytes per
+// anchor instead of 256 (and the 557 MB are not read back by a decode launch).
+// One wave = 64 pixels: B fragments straight from global memory (a pixel's 64 channels are 128 contiguous bytes), A fragments from
+// an LDS copy of the weights whose rows are permuted so that a lane ends up with the 16 bins of ONE side of its pixel: MFMA row
+// 16 m + 4 q + j holds channel 16 q + 4 m + j.  The arithmetic after the accumulators is decode_kernel's, association included.
+struct BoxDecArgs {
+  const f16* x;
+  const float* w;     // fp32 master [64][64]
+  const float* bias;  // [64]
+  float* pred_box;    // (B, A, 4) grid units
+  int ldx, A, a0, hw, W, B;
+};
+__global__ __launch_bounds__(256) void head_box_decode_kernel(BoxDecArgs a) {
+  constexpr int PITCH = 160;  // bytes per weight row: 10 sixteen-byte slots (== 2 mod 4: conflict-free for ds_read_b128's lane groups)
+  __shared__ __attribute__((aligned(16))) char s_w[64 * PITCH];
+  __shared__ float s_b[64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int c = i >> 6, k = i & 63;                          // channel c = 16 q' + 4 m' + j'  ->  row 16 m' + 4 q' + j'
+    const int row = ((c >> 2) & 3) * 16 + (c >> 4) * 4 + (c & 3);
+    *reinterpret_cast<f16*>(s_w + row * PITCH + k * 2) = (f16)a.w[i];
+  }
+  if (tid < 64) s_b[tid] = a.bias[tid];
+  __syncthreads();
+  const long npix = (long)a.B * a.hw;
+  const float invw = 1.0f / (float)a.W;
+  for (long base = ((long)blockIdx.x * 4 + wave) * 64; base < npix; base += (long)gridDim.x * 256) {
+    half8 bf[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const long pix = base + t * 16 + p;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (pix < npix) bf[t][ks] = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + ks * 32 + q * 8);
+        else bf[t][ks] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const half8 a0f = *reinterpret_cast<const half8*>(s_w + (m * 16 + p) * PITCH + q * 16);
+      const half8 a1f = *reinterpret_cast<const half8*>(s_w + (m * 16 + p) * PITCH + 64 + q * 16);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0f, bf[t][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1f, bf[t][1], acc[m][t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const long pix = base + t * 16 + p;
+      if (pix >= npix) continue;
+      float v[16];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[m * 4 + j] = acc[m][t][j] + s_b[q * 16 + m * 4 + j];
+      float mx = v[0];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) mx = fmaxf(mx, v[k]);
+      float den4[4], num4[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // decode_kernel's quarters: four consecutive bins, then (q0 + q1) + (q2 + q3)
+        const float e0 = expf(v[g * 4] - mx), e1 = expf(v[g * 4 + 1] - mx), e2 = expf(v[g * 4 + 2] - mx), e3 = expf(v[g * 4 + 3] - mx);
+        const float k0 = (float)(g * 4);
+        den4[g] = (e0 + e1) + (e2 + e3);
+        num4[g] = e0 * k0 + e1 * (k0 + 1.f) + e2 * (k0 + 2.f) + e3 * (k0 + 3.f);
+      }
+      const float den = (den4[0] + den4[1]) + (den4[2] + den4[3]), num = (num4[0] + num4[1]) + (num4[2] + num4[3]);
+      const float e = num / den;
+      const int b = (int)(pix / a.hw), r = (int)(pix - (long)b * a.hw);
+      const int iy = (int)(((float)r + 0.5f) * invw), ix = r - iy * a.W;
+      const float anc = (q & 1) ? (iy + 0.5f) : (ix + 0.5f);
+      a.pred_box[((size_t)b * a.A + a.a0 + r) * 4 + q] = q < 2 ? anc - e : anc + e;
+    }
+  }
+}
+extern "C" int dy_head_box_decode(const void* x, int ldx, const float* weight, const float* bias, float* pred_box, int A, int a0, int n,
+                                  int h, int w, int cin, int cout, hipStream_t stream) {
+  if (cin != 64 || cout != 64 || !x || !weight || !bias || !pred_box || n < 1 || h < 1 || w < 1 || a0 < 0 || a0 + h * w > A) return DY_ERR_ARG;
+  if ((ldx & 7) || ((uintptr_t)x & 15)) return DY_ERR_ALIGN;
+  BoxDecArgs a{(const f16*)x, weight, bias, pred_box, ldx, A, a0, h * w, w, n};
+  const long npix = (long)n * h * w;
+  long blocks = (npix + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(head_box_decode_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
 extern "C" int dy_conv1x1_rows_supported(int cin, int cout) { return cin == 64 && cout == 64; }
 extern "C" int dy_conv1x1_rows_slabs(void) { return 256; }
 extern "C" int dy_conv1x1_rows_backward(const void* x, int ldx, const void* dy, int lddy, const int* assigned, int A, int a0,

@@ -22,6 +22,12 @@ struct Level {
   f16* dcls;         // (B,H,W,ncp)
   int H, W, a0;
   float stride;
+  // box == NULL inside a training step (dy_head_box_decode wrote pred_box from the layer input): the DFL logits of a foreground
+  // anchor are recomputed from the final box convolution's input, fp32 master weight (rounded to fp16 as the packed form) and bias
+  const f16* xin = nullptr;
+  int ldin = 0;
+  const float* w = nullptr;
+  const float* bias = nullptr;
 };
 struct LossCtx {
   Level lv[4];
@@ -564,7 +570,20 @@ __global__ __launch_bounds__(256) void box_loss_kernel(LossCtx c) {
     anchor_of(c, a, l, iy, ix);
     const Level& L = c.lv[l];
     const size_t off = (((size_t)b * L.H + iy) * L.W + ix) * 64 + lane;
-    const float logit = L.box[off];
+    float logit;
+    if (L.box) {
+      logit = L.box[off];
+    } else {  // lane = output channel (side * 16 + bin): one row of the 64x64 weight against this pixel's 64 input channels
+      const f16* xr = L.xin + (((size_t)b * L.H + iy) * L.W + ix) * L.ldin;
+      const float* wr = L.w + lane * 64;
+      float sacc = 0.f;
+      for (int k8 = 0; k8 < 64; k8 += 8) {
+        const half8 xv = *reinterpret_cast<const half8*>(xr + k8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc += (float)(f16)wr[k8 + k] * (float)xv[k];
+      }
+      logit = sacc + L.bias[lane];
+    }
     float pr;
     const float e = softmax16_expect(logit, bin, pr);
     const float w = c.tscore[ba];  // weight = target_scores.sum(-1)
@@ -757,6 +776,11 @@ extern "C" int dy_detection_loss(const DyLossArgs* d, hipStream_t stream) {
   int a0 = 0;
   for (int l = 0; l < d->nl; ++l) {
     c.lv[l] = Level{d->box[l], d->cls[l], (f16*)d->dbox[l], (f16*)d->dcls[l], d->H[l], d->W[l], a0, d->stride[l]};
+    if (d->box_from_input) {
+      if (!d->box_in[l] || !d->box_w[l] || !d->box_b[l] || (d->box_in_ld[l] & 7)) return DY_ERR_ARG;
+      c.lv[l].box = nullptr;
+      c.lv[l].xin = (const f16*)d->box_in[l]; c.lv[l].ldin = d->box_in_ld[l]; c.lv[l].w = d->box_w[l]; c.lv[l].bias = d->box_b[l];
+    }
     a0 += d->H[l] * d->W[l];
   }
   c.A = a0;
@@ -781,7 +805,7 @@ extern "C" int dy_detection_loss(const DyLossArgs* d, hipStream_t stream) {
                      d->n_targets, d->n_targets_dev, d->img_w, d->img_h);
   if (hipMemsetAsync(c.cnt, 0, BA * 4, stream) != hipSuccess) return DY_ERR_LAUNCH;
   const int gridA = (int)((BA * 64 + 255) / 256 < 2048 ? (BA * 64 + 255) / 256 : 2048);
-  {
+  if (!d->box_from_input) {  // else dy_head_box_decode has written pred_box already (same workspace, same layout)
     const long nb = ((long)c.A * 16 + 255) / 256;  // per image: 16 lanes per anchor; blockIdx.y = image
     hipLaunchKernelGGL(decode_kernel, dim3((int)(nb < 256 ? nb : 256), c.B), dim3(256), 0, stream, c);
   }

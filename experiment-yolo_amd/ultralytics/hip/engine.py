@@ -63,6 +63,10 @@ SPPF_FUSED = os.environ.get("DY_SPPF_FUSED", "1") != "0"
 # foreground anchors only): csrc/head_rows.hip reads the loss's assignment instead of a zero-filled dense gradient.  Only inside a
 # StepPlan trace (the plan binds the assignment buffer and tells the loss not to zero the rest); DY_HEAD_ROWS=0: the dense kernels.
 HEAD_ROWS = BIAS_WGRAD and os.environ.get("DY_HEAD_ROWS", "1") != "0"
+# ... and its forward fused with the loss's box decode (dy_head_box_decode): inside a StepPlan trace the 64 fp32 logits per anchor are
+# never written -- the assigner gets the decoded box, the loss recomputes the logits of foreground anchors.  DY_HEAD_DECODE=0: the
+# conv writes its logits and the loss decodes them.
+HEAD_DECODE = HEAD_ROWS and os.environ.get("DY_HEAD_DECODE", "1") != "0"
 BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
 BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
 
@@ -785,6 +789,20 @@ class Engine:
                 rows_level = None
             self.tape.append(lambda: self._conv_bias_bwd(spec, x, dy_ptr_fn, rows_level=rows_level))
 
+    def rows_capable(self, spec):
+        return (self.rows_used is not None and self.tape is not None and spec.ks == 1 and spec.ld is None and spec.acc_bias is not None
+                and spec.bias is not None and bool(self.L.dy_conv1x1_rows_supported(spec.cin, spec.cout)))
+
+    def conv_bias_decode(self, spec: ConvSpec, x: Act, dy_ptr_fn, rows_level):
+        """Detect's final box conv of level ``rows_level`` inside a StepPlan trace (caller checked ``rows_capable``): no logits are
+        written; the plan launches dy_head_box_decode once the loss workspace is bound (``pending_decode``), the backward is the rows
+        form."""
+        self._use(x)
+        self.rows_used.add(rows_level)
+        self.pending_decode.append((spec, x, rows_level))
+        self.tape.append(lambda: self._conv_bias_bwd(spec, x, dy_ptr_fn, rows_level=rows_level))
+
+    pending_decode = None
     rows_used = None   # set() while a StepPlan traces its forward: the detection levels whose box conv can take the rows form
     loss_rows = None   # (assignment pointer, anchors per image, first anchor of each level) once the plan has bound the loss
 

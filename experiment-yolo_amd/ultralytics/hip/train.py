@@ -126,6 +126,7 @@ class StepPlan:
             x = self.import_input()
             from .engine import HEAD_ROWS
             eng.rows_used, eng.loss_rows = (set() if HEAD_ROWS else None), None
+            eng.pending_decode = [] if HEAD_ROWS else None
             ho = model.forward_act(x)
             crit.bind(ho, self.nmax, gscale=self.state[0:1])
             crit.__dict__["_last"] = crit
@@ -133,8 +134,21 @@ class StepPlan:
             # every level's box conv can be back-propagated from the foreground rows of its gradient: the loss need not zero the rest
             rows = eng.rows_used is not None and len(eng.rows_used) == len(ho.box)
             crit._args.dbox_rows_only = 1 if rows else 0
+            crit._args.box_from_input = 0
             if rows:
                 eng.loss_rows = crit.assignment_rows()
+            if eng.pending_decode:
+                # the head left its box logits unwritten: decoded boxes go straight into the loss workspace, the loss recomputes the
+                # logits of foreground anchors from the final conv's operands
+                assert rows and len(eng.pending_decode) == len(ho.box)
+                asg, A, a0 = eng.loss_rows
+                a = crit._args
+                a.box_from_input = 1
+                for spec, xin, l in eng.pending_decode:
+                    eng.call("dy_head_box_decode", xin.ptr, xin.ld, spec.weight.data_ptr(), spec.bias.data_ptr(), crit.pred_box_ptr(), A, a0[l],
+                             xin.N, xin.H, xin.W, spec.cin, spec.cout)
+                    a.box_in[l], a.box_in_ld[l] = xin.ptr, xin.ld
+                    a.box_w[l], a.box_b[l] = spec.weight.data_ptr(), spec.bias.data_ptr()
             eng.call("dy_detection_loss", C.byref(crit._args))
             self.fb_split = len(eng.rec.ops)  # [0, fb_split) = forward + loss, the rest = backward (forward_only / backward_accumulate)
             eng.deferred_wgrad = []
@@ -151,7 +165,7 @@ class StepPlan:
             eng.flush_wgrad()
         finally:
             eng.deferred_wgrad = None
-            eng.rows_used = eng.loss_rows = None
+            eng.rows_used = eng.loss_rows = eng.pending_decode = None
             eng.side_wgrad = False
             eng.acc_zeroed = False
             eng.arena = None

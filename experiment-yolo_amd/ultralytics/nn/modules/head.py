@@ -21,6 +21,13 @@ class HeadOut:
     def __init__(self, box, cls, nc, strides):
         self.box, self.cls, self.nc, self.strides = box, cls, nc, strides
         self.dbox = self.dcls = None
+        self.fill_box = None  # inside a StepPlan trace the box logits are not written (dy_head_box_decode); callable that writes them
+
+    def materialize(self):
+        """Write the box logits if the forward left them out (the recorded training step never reads them): an eager launch of the
+        plain final convs over the activations still resident from the last step."""
+        if self.fill_box is not None:
+            self.fill_box()
 
     def alloc_grads(self):
         if self.dbox is None:
@@ -29,6 +36,7 @@ class HeadOut:
 
     def as_reference_list(self):
         """[(B, no, H, W)] fp32 views/copies in the reference's training-output format (head.py:45-48)."""
+        self.materialize()
         return [torch.cat((b, c[..., : self.nc]), -1).permute(0, 3, 1, 2) for b, c in zip(self.box, self.cls)]
 
 
@@ -98,13 +106,29 @@ class Detect(HipModule):
         if eng.tape is not None:
             ho.alloc_grads()
             eng.hold(*ho.dbox, *ho.dcls)
+        from ...hip.engine import HEAD_DECODE
+        # inside a StepPlan trace, when every level's box conv qualifies: forward fused with the loss's decode, backward from rows
+        fused = HEAD_DECODE and eng.pending_decode is not None and all(eng.rows_capable(rt.specs[(id(self), "cv2", l)]) for l in range(len(xs)))
+        lazy = []
         for l, x in enumerate(xs):
             a = self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(x))
             c = self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(x))
-            eng.conv_bias(rt.specs[(id(self), "cv2", l)], a, boxes[l].data_ptr(), nb, True,
-                          lambda l=l: (ho.dbox[l].data_ptr(), nb), rows_level=l)
+            if fused:
+                eng.conv_bias_decode(rt.specs[(id(self), "cv2", l)], a, lambda l=l: (ho.dbox[l].data_ptr(), nb), l)
+                lazy.append((rt.specs[(id(self), "cv2", l)], a, boxes[l]))
+            else:
+                eng.conv_bias(rt.specs[(id(self), "cv2", l)], a, boxes[l].data_ptr(), nb, True,
+                              lambda l=l: (ho.dbox[l].data_ptr(), nb), rows_level=l)
             eng.conv_bias(rt.specs[(id(self), "cv3", l)], c, clss[l].data_ptr(), ncp, True,
                           lambda l=l: (ho.dcls[l].data_ptr(), ncp))
+        if lazy:
+            from ...hip import DY_EPI_BIAS, DY_EPI_F32OUT
+
+            def fill():
+                assert eng.rec is None, "box logits can only be materialised outside a trace"
+                for spec, a, buf in lazy:
+                    eng._conv_raw(spec, a, buf.data_ptr(), nb, DY_EPI_BIAS | DY_EPI_F32OUT, 0, spec.bias)
+            ho.fill_box = fill
         return ho
 
     def _export(self, rt, y):

@@ -205,6 +205,14 @@ class v8DetectionLoss:
             a0 += a.H[l] * a.W[l]
         return self._ws.data_ptr() + o[1].value, self.A, first
 
+    def pred_box_ptr(self):
+        """Device pointer of the decoded boxes (B, A, 4) inside the bound workspace (what dy_head_box_decode fills)."""
+        from ..hip import lib
+        a = self._args
+        o = [C.c_size_t() for _ in range(3)]
+        lib().dy_loss_workspace_layout(a.B, self.A, a.nmax, *[C.byref(x) for x in o])
+        return self._ws.data_ptr() + o[0].value
+
     def debug_assignment(self):
         """(target_gt_idx (B,A) with -1 for background, target score (B,A), pred boxes (B,A,4)) of the last call."""
         from ..hip import lib

@@ -272,6 +272,12 @@ typedef struct DyLossArgs {
   void* workspace;               /* dy_loss_workspace_bytes(B, A, nmax) bytes */
   int dbox_rows_only;            /* non-zero: dbox is written at foreground anchors only and NOT zeroed elsewhere -- for a consumer that
                                     reads it through the assignment (dy_conv1x1_rows_backward); 0: every row is defined */
+  int box_from_input;            /* non-zero: box[] is not read.  pred_box in the workspace was written by dy_head_box_decode, and the DFL
+                                    logits of foreground anchors are recomputed from the final box convolution's operands: */
+  const void* box_in[4];         /* its input (B,H,W,box_in_ld) fp16, 64 channels */
+  int box_in_ld[4];
+  const float* box_w[4];         /* its fp32 weight (64,64) and bias (64) */
+  const float* box_b[4];
 } DyLossArgs;
 size_t dy_loss_workspace_bytes(int B, int A, int nmax);
 /* byte offsets of pred_box (B,A,4 f32, grid units), assigned gt index (B,A i32, -1 = background) and target score
@@ -285,6 +291,10 @@ int dy_detection_loss(const DyLossArgs* args, hipStream_t stream);
  * dy_wgrad_reduce_batched (descriptor: cin 64, cout 64, ks 1); bias gradient: fp64 sums into bias_acc [DY_BN_COPIES][64] (finished by
  * dy_wgrad_reduce_desc_bias); input gradient dx (may be NULL): W^T dy on foreground pixels, zeros (or untouched when dx_accumulate)
  * elsewhere.  Rows of dy whose anchor is background are never read.  Supported: cin == cout == 64. */
+/* Forward of the same convolution fused with the loss's bbox_decode (utils/loss.py:347-354): pred_box (B, A, 4) in grid units, the
+ * buffer at off_pred_box of the loss workspace; no logits are written (DyLossArgs.box_from_input). */
+int dy_head_box_decode(const void* x, int ldx, const float* weight, const float* bias, float* pred_box, int A, int a0, int n, int h,
+                       int w, int cin, int cout, hipStream_t stream);
 int dy_conv1x1_rows_supported(int cin, int cout);
 int dy_conv1x1_rows_slabs(void);
 int dy_conv1x1_rows_backward(const void* x, int ldx, const void* dy, int lddy, const int* assigned, int A, int a0,

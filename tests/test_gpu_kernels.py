@@ -630,3 +630,29 @@ def test_bn_backward_reduce_rows_equals_the_dense_pass_on_a_row_sparse_gradient(
     torch.cuda.synchronize()
     a, b = acc_d.sum(0), acc_r.sum(0)
     assert torch.isfinite(b).all() and relerr(b, a) < 2e-6
+
+
+def test_head_box_decode_equals_conv_then_bbox_decode():
+    """dy_head_box_decode (Detect's final box conv fused with the loss's bbox_decode, reference nn/modules/head.py:38-40 +
+    utils/loss.py:347-354 + utils/tal.py:311-318 dist2bbox) against the fp32 composition: logits = x W^T + b with the fp16-rounded
+    weight, softmax over the 16 bins of each side, expectation, anchor -/+ distance; ragged pixel count, anchors of other levels
+    around this level's range."""
+    from ultralytics.hip import check, lib
+    L = lib()
+    torch.manual_seed(8)
+    B, H, W, A0 = 3, 7, 11, 19
+    hw, A = H * W, 19 + 77 + 5
+    x = torch.randn(B * hw, 64).half().cuda()
+    w = (torch.randn(64, 64) / 4).cuda()
+    b = torch.randn(64).cuda()
+    pb = torch.full((B, A, 4), -7.0, device="cuda")
+    check(L.dy_head_box_decode(x.data_ptr(), 64, w.data_ptr(), b.data_ptr(), pb.data_ptr(), A, A0, B, H, W, 64, 64,
+                               torch.cuda.current_stream().cuda_stream), "decode")
+    torch.cuda.synchronize()
+    logits = x.float() @ w.half().float().t() + b
+    e = (torch.softmax(logits.view(B, hw, 4, 16), -1) * torch.arange(16, device="cuda")).sum(-1)
+    iy, ix = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
+    anc = torch.stack([ix, iy], -1).reshape(hw, 2).float() + 0.5
+    ref = torch.cat([anc - e[..., :2], anc + e[..., 2:]], -1)
+    assert float((pb[:, A0:A0 + hw] - ref).abs().max()) < 2e-5
+    assert bool((pb[:, :A0] == -7.0).all()) and bool((pb[:, A0 + hw:] == -7.0).all())
