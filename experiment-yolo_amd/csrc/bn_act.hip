@@ -464,13 +464,27 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_rows_kernel(BwdRedRowsA
   const long npix = (long)a.B * a.hw;
   const long chunk = (npix + gridDim.x - 1) / gridDim.x;
   const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < npix ? lo + chunk : npix;
-  for (long p0 = lo; p0 < hi; p0 += 256) {
-    const long p = p0 + tid;
-    bool fg = false;
-    if (p < hi) {
-      const int b = (int)(p / a.hw), r = (int)(p - (long)b * a.hw);
-      fg = a.flag[(size_t)b * a.A + a.a0 + r] >= 0;
+  // the flags of eight trips are requested together: one trip at a time the loop was a chain of 25 dependent memory latencies at
+  // 160x160
+  constexpr int FB = 8;
+  int fl[FB];
+  for (long p0 = lo, trip = 0; p0 < hi; p0 += 256, ++trip) {
+    if ((trip & (FB - 1)) == 0) {
+#pragma unroll
+      for (int k = 0; k < FB; ++k) {
+        const long pk = p0 + (long)k * 256 + tid;
+        fl[k] = -1;
+        if (pk < hi) {
+          const int b = (int)(pk / a.hw), r = (int)(pk - (long)b * a.hw);
+          fl[k] = a.flag[(size_t)b * a.A + a.a0 + r];
+        }
+      }
     }
+    int mine = -1;
+#pragma unroll
+    for (int k = 0; k < FB; ++k)
+      if ((trip & (FB - 1)) == k) mine = fl[k];
+    const bool fg = mine >= 0;
     const unsigned long long m = __ballot(fg);
     if (lane == 0) s_cnt[wave] = __popcll(m);
     __syncthreads();

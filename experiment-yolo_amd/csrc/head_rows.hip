@@ -7,6 +7,8 @@
 // reading anything.  Deterministic: every workgroup walks its pixels in order.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "dealyolo_hip.h"
 
@@ -35,13 +37,27 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(RowsArgs a) {
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.f;
   float bs = 0.f;
-  for (long p0 = lo; p0 < hi; p0 += 256) {
-    const long p = p0 + tid;
-    bool fg = false;
-    if (p < hi) {
-      const int b = (int)(p / a.hw), r = (int)(p - (long)b * a.hw);
-      fg = a.flag[(size_t)b * a.A + a.a0 + r] >= 0;
+  // the flags of eight trips are requested together: one trip at a time the loop was a chain of 25 dependent memory latencies at
+  // 160x160 (40 us for a pass that moves 6.5 MB)
+  constexpr int FB = 8;
+  int fl[FB];
+  for (long p0 = lo, trip = 0; p0 < hi; p0 += 256, ++trip) {
+    if ((trip & (FB - 1)) == 0) {
+#pragma unroll
+      for (int k = 0; k < FB; ++k) {
+        const long pk = p0 + (long)k * 256 + tid;
+        fl[k] = -1;
+        if (pk < hi) {
+          const int b = (int)(pk / a.hw), r = (int)(pk - (long)b * a.hw);
+          fl[k] = a.flag[(size_t)b * a.A + a.a0 + r];
+        }
+      }
     }
+    int mine = -1;
+#pragma unroll
+    for (int k = 0; k < FB; ++k)
+      if ((trip & (FB - 1)) == k) mine = fl[k];
+    const bool fg = mine >= 0;
     const unsigned long long m = __ballot(fg);
     if (lane == 0) s_cnt[wave] = __popcll(m);
     __syncthreads();
@@ -120,6 +136,16 @@ __global__ __launch_bounds__(256) void rows_dgrad_kernel(RowsArgs a) {
 // One wave = 64 pixels: B fragments straight from global memory (a pixel's 64 channels are 128 contiguous bytes), A fragments from
 // an LDS copy of the weights whose rows are permuted so that a lane ends up with the 16 bins of ONE side of its pixel: MFMA row
 // 16 m + 4 q + j holds channel 16 q + 4 m + j.  The arithmetic after the accumulators is decode_kernel's, association included.
+// exp(x) for x <= 0 (softmax terms after the maximum is taken off): 2^(x log2 e) with the product carried in two floats -- v_exp_f32 of
+// the head, first-order correction by the tail.  About 1 ulp; 7 instructions against ~20 of the library call, and this kernel runs
+// 64 of them per anchor (DY_DECODE_LIBM_EXP=1 restores expf).
+static __device__ __forceinline__ float exp_nonpos(float x) {
+  const float t = x * 1.44269502f;
+  float r = __builtin_fmaf(x, 1.44269502f, -t);
+  r = __builtin_fmaf(x, 1.92596299e-8f, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, r * 0.693147182f, e);
+}
 struct BoxDecArgs {
   const f16* x;
   const float* w;     // fp32 master [64][64]
@@ -127,7 +153,9 @@ struct BoxDecArgs {
   float* pred_box;    // (B, A, 4) grid units
   int ldx, A, a0, hw, W, B;
 };
+template <bool LIBM>
 __global__ __launch_bounds__(256) void head_box_decode_kernel(BoxDecArgs a) {
+  auto ex = [](float x) { return LIBM ? expf(x) : exp_nonpos(x); };
   constexpr int PITCH = 160;  // bytes per weight row: 10 sixteen-byte slots (== 2 mod 4: conflict-free for ds_read_b128's lane groups)
   __shared__ __attribute__((aligned(16))) char s_w[64 * PITCH];
   __shared__ float s_b[64];
@@ -178,7 +206,7 @@ __global__ __launch_bounds__(256) void head_box_decode_kernel(BoxDecArgs a) {
       float den4[4], num4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // decode_kernel's quarters: four consecutive bins, then (q0 + q1) + (q2 + q3)
-        const float e0 = expf(v[g * 4] - mx), e1 = expf(v[g * 4 + 1] - mx), e2 = expf(v[g * 4 + 2] - mx), e3 = expf(v[g * 4 + 3] - mx);
+        const float e0 = ex(v[g * 4] - mx), e1 = ex(v[g * 4 + 1] - mx), e2 = ex(v[g * 4 + 2] - mx), e3 = ex(v[g * 4 + 3] - mx);
         const float k0 = (float)(g * 4);
         den4[g] = (e0 + e1) + (e2 + e3);
         num4[g] = e0 * k0 + e1 * (k0 + 1.f) + e2 * (k0 + 2.f) + e3 * (k0 + 3.f);
@@ -200,7 +228,9 @@ extern "C" int dy_head_box_decode(const void* x, int ldx, const float* weight, c
   const long npix = (long)n * h * w;
   long blocks = (npix + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(head_box_decode_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
+  static const bool libm = getenv("DY_DECODE_LIBM_EXP") && atoi(getenv("DY_DECODE_LIBM_EXP")) != 0;
+  if (libm) hipLaunchKernelGGL(head_box_decode_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(head_box_decode_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
