@@ -59,6 +59,8 @@ BIAS_WGRAD = BN_ACC and os.environ.get("DY_BIAS_WGRAD", "1") != "0"
 # SPPF's three chained 5x5 pools (and their backward chain) as one launch each with the map resident in LDS, when it fits
 # (Engine.sppf_pools; =0: three dy_maxpool5 / dy_maxpool5_backward launches).
 SPPF_FUSED = os.environ.get("DY_SPPF_FUSED", "1") != "0"
+# Add's backward hands the sum's gradient buffer to an operand that has no other consumer instead of copying it (Engine.add).
+ADD_ALIAS = os.environ.get("DY_ADD_ALIAS", "1") != "0"
 # Detect's final box convolution back-propagated from the ROWS of its output gradient (the loss writes box / DFL gradients for
 # foreground anchors only): csrc/head_rows.hip reads the loss's assignment instead of a zero-filled dense gradient.  Only inside a
 # StepPlan trace (the plan binds the assignment buffer and tells the loss not to zero the rest); DY_HEAD_ROWS=0: the dense kernels.
@@ -900,8 +902,19 @@ class Engine:
         self.call("dy_add", a.ptr, a.ld, b.ptr, b.ld, 0 if c is None else c.ptr, 0 if c is None else c.ld, y.ptr, y.ld, a.npix, a.C)
         if self.tape is not None:
             def bwd():
+                shared = False
                 for t in xs:
                     if not t.needs_grad:
+                        continue
+                    if (ADD_ALIAS and not shared and t.st.gbuf is None and not t.st.gwritten and t.c0 == 0 and t.C == t.st.C
+                            and y.c0 == 0 and y.C == y.st.C and y.st.gbuf is not None and tuple(t.st.buf.shape) == tuple(y.st.buf.shape)
+                            and self._uses.get(id(t.st)) == {(t.c0, t.C): 1}):
+                        # d(sum)/d(operand) is the identity: an operand whose ONLY forward use was this sum, and which has no gradient
+                        # yet, takes the sum's gradient buffer as its own instead of a copy of it (nothing writes y's gradient after
+                        # this point, and nothing else will write t's).  One operand per sum: two sharers could see each other's writers.
+                        t.st.gbuf = y.st.gbuf
+                        t.grad_target()
+                        shared = True
                         continue
                     acc = t.grad_target()
                     if acc:
