@@ -74,6 +74,21 @@ static __device__ __forceinline__ f32x2 act_fwd2_fast(f32x2 z) {
   if (ACT == DY_ACT_LEAKY) return (f32x2){z[0] > 0.f ? z[0] : 0.1f * z[0], z[1] > 0.f ? z[1] : 0.1f * z[1]};
   return z;
 }
+// y = fp16(SiLU(raw * scale + shift)) for one 8-channel granule, bit for bit what bn_act_apply_kernel<DY_ACT_SILU, ., true> stores:
+// consumers that read a Conv's RAW output and apply BatchNorm + SiLU themselves (csrc/head_rows.hip, the loss's logit recompute)
+// see the tensor the apply launch would have written.
+static __device__ __forceinline__ half8 bn_silu_apply8(const half8& xv, const float* sc, const float* sh) {
+  half8 out;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const f32x2 z = act_fwd2_fast<DY_ACT_SILU>(__builtin_elementwise_fma((f32x2){(float)xv[j], (float)xv[j + 1]}, (f32x2){sc[j], sc[j + 1]},
+                                                                         (f32x2){sh[j], sh[j + 1]}));
+    const half2_ oh = __builtin_convertvector(z, half2_);
+    out[j] = oh[0];
+    out[j + 1] = oh[1];
+  }
+  return out;
+}
 // d act / dz for a PAIR of values: everything except v_exp / v_rcp is a 2-wide packed fp32 instruction (v_pk_fma_f32 ...), which
 // is what makes the BatchNorm backward cheap enough to run inside a staging loop.  sigmoid' form: s + z*s*(1-s), s*(1-s) = s - s^2.
 template <int ACT>

@@ -21,6 +21,7 @@ struct RowsArgs {
   float* slabs;      // [gridDim.x][64][64] fp32 partial weight gradients for dy_wgrad_reduce_batched
   double* bias_acc;  // [DY_BN_COPIES][64]
   int ldx, lddy, lddx, A, a0, hw, B, dx_acc;
+  const float* xcoef;  // non-null: x is the RAW output of the Conv below ([4][64]: scale, shift, ..); BatchNorm + SiLU applied on load
 };
 
 // ---- weight + bias gradient over the foreground pixels of this workgroup's pixel range
@@ -71,7 +72,11 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(RowsArgs a) {
     __syncthreads();
     for (int i = 0; i < total; ++i) {
       const long q = p0 + s_list[i];
-      if (tid < 8) *reinterpret_cast<uint4*>(s_x + tid * 8) = *reinterpret_cast<const uint4*>(a.x + q * a.ldx + tid * 8);
+      if (tid < 8) {
+        half8 xv = *reinterpret_cast<const half8*>(a.x + q * a.ldx + tid * 8);
+        if (a.xcoef) xv = bn_silu_apply8(xv, a.xcoef + tid * 8, a.xcoef + 64 + tid * 8);
+        *reinterpret_cast<half8*>(s_x + tid * 8) = xv;
+      }
       else if (tid < 16) *reinterpret_cast<uint4*>(s_dy + (tid - 8) * 8) = *reinterpret_cast<const uint4*>(a.dy + q * a.lddy + (tid - 8) * 8);
       __syncthreads();
       const float g = (float)s_dy[co];
@@ -152,6 +157,7 @@ struct BoxDecArgs {
   const float* bias;  // [64]
   float* pred_box;    // (B, A, 4) grid units
   int ldx, A, a0, hw, W, B;
+  const float* xcoef;  // non-null: x is the RAW output of the Conv below; its BatchNorm + SiLU apply happens on load, no apply launch
 };
 template <bool LIBM>
 __global__ __launch_bounds__(256) void head_box_decode_kernel(BoxDecArgs a) {
@@ -169,6 +175,16 @@ __global__ __launch_bounds__(256) void head_box_decode_kernel(BoxDecArgs a) {
   __syncthreads();
   const long npix = (long)a.B * a.hw;
   const float invw = 1.0f / (float)a.W;
+  float csc[2][8], csh[2][8];  // this lane's 16 input channels: ks * 32 + q * 8 + j
+  if (a.xcoef) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        csc[ks][j] = a.xcoef[ks * 32 + q * 8 + j];
+        csh[ks][j] = a.xcoef[64 + ks * 32 + q * 8 + j];
+      }
+  }
   for (long base = ((long)blockIdx.x * 4 + wave) * 64; base < npix; base += (long)gridDim.x * 256) {
     half8 bf[4][2];
 #pragma unroll
@@ -179,6 +195,13 @@ __global__ __launch_bounds__(256) void head_box_decode_kernel(BoxDecArgs a) {
         if (pix < npix) bf[t][ks] = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + ks * 32 + q * 8);
         else bf[t][ks] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
       }
+    }
+    if (a.xcoef) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          if (base + t * 16 + p < npix) bf[t][ks] = bn_silu_apply8(bf[t][ks], csc[ks], csh[ks]);
     }
     f32x4 acc[4][4];
 #pragma unroll
@@ -220,11 +243,11 @@ __global__ __launch_bounds__(256) void head_box_decode_kernel(BoxDecArgs a) {
     }
   }
 }
-extern "C" int dy_head_box_decode(const void* x, int ldx, const float* weight, const float* bias, float* pred_box, int A, int a0, int n,
-                                  int h, int w, int cin, int cout, hipStream_t stream) {
+extern "C" int dy_head_box_decode(const void* x, int ldx, const float* x_coef, const float* weight, const float* bias, float* pred_box, int A,
+                                  int a0, int n, int h, int w, int cin, int cout, hipStream_t stream) {
   if (cin != 64 || cout != 64 || !x || !weight || !bias || !pred_box || n < 1 || h < 1 || w < 1 || a0 < 0 || a0 + h * w > A) return DY_ERR_ARG;
   if ((ldx & 7) || ((uintptr_t)x & 15)) return DY_ERR_ALIGN;
-  BoxDecArgs a{(const f16*)x, weight, bias, pred_box, ldx, A, a0, h * w, w, n};
+  BoxDecArgs a{(const f16*)x, weight, bias, pred_box, ldx, A, a0, h * w, w, n, x_coef};
   const long npix = (long)n * h * w;
   long blocks = (npix + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -237,7 +260,7 @@ extern "C" int dy_head_box_decode(const void* x, int ldx, const float* weight, c
 
 extern "C" int dy_conv1x1_rows_supported(int cin, int cout) { return cin == 64 && cout == 64; }
 extern "C" int dy_conv1x1_rows_slabs(void) { return 256; }
-extern "C" int dy_conv1x1_rows_backward(const void* x, int ldx, const void* dy, int lddy, const int* assigned, int A, int a0,
+extern "C" int dy_conv1x1_rows_backward(const void* x, int ldx, const float* x_coef, const void* dy, int lddy, const int* assigned, int A, int a0,
                                         const float* weight, void* dx, int lddx, int dx_accumulate, float* slabs, double* bias_acc,
                                         int n, int h, int w, int cin, int cout, hipStream_t stream) {
   if (!dy_conv1x1_rows_supported(cin, cout) || !x || !dy || !assigned || !weight || !slabs || !bias_acc || n < 1 || h < 1 || w < 1 ||
@@ -246,7 +269,7 @@ extern "C" int dy_conv1x1_rows_backward(const void* x, int ldx, const void* dy, 
   if ((ldx & 7) || (lddy & 7) || (dx && (lddx & 7)) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) ||
       ((uintptr_t)slabs & 15))
     return DY_ERR_ALIGN;
-  RowsArgs a{(const f16*)x, (const f16*)dy, assigned, weight, (f16*)dx, slabs, bias_acc, ldx, lddy, lddx, A, a0, h * w, n, dx_accumulate};
+  RowsArgs a{(const f16*)x, (const f16*)dy, assigned, weight, (f16*)dx, slabs, bias_acc, ldx, lddy, lddx, A, a0, h * w, n, dx_accumulate, x_coef};
   hipLaunchKernelGGL(rows_wgrad_kernel, dim3(dy_conv1x1_rows_slabs()), dim3(256), 0, stream, a);
   if (dx) {
     int gx = (h * w + 31) / 32;

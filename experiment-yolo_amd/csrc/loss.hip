@@ -28,6 +28,7 @@ struct Level {
   int ldin = 0;
   const float* w = nullptr;
   const float* bias = nullptr;
+  const float* incoef = nullptr;  // non-null: xin is the RAW output of the Conv below ([4][64] scale, shift, ..): applied here
 };
 struct LossCtx {
   Level lv[4];
@@ -578,7 +579,8 @@ __global__ __launch_bounds__(256) void box_loss_kernel(LossCtx c) {
       const float* wr = L.w + lane * 64;
       float sacc = 0.f;
       for (int k8 = 0; k8 < 64; k8 += 8) {
-        const half8 xv = *reinterpret_cast<const half8*>(xr + k8);
+        half8 xv = *reinterpret_cast<const half8*>(xr + k8);
+        if (L.incoef) xv = bn_silu_apply8(xv, L.incoef + k8, L.incoef + 64 + k8);
 #pragma unroll
         for (int k = 0; k < 8; ++k) sacc += (float)(f16)wr[k8 + k] * (float)xv[k];
       }
@@ -780,6 +782,7 @@ extern "C" int dy_detection_loss(const DyLossArgs* d, hipStream_t stream) {
       if (!d->box_in[l] || !d->box_w[l] || !d->box_b[l] || (d->box_in_ld[l] & 7)) return DY_ERR_ARG;
       c.lv[l].box = nullptr;
       c.lv[l].xin = (const f16*)d->box_in[l]; c.lv[l].ldin = d->box_in_ld[l]; c.lv[l].w = d->box_w[l]; c.lv[l].bias = d->box_b[l];
+      c.lv[l].incoef = d->box_in_coef[l];
     }
     a0 += d->H[l] * d->W[l];
   }

@@ -53,7 +53,7 @@ class DyLossArgs(C.Structure):
                 ("img_w", f32), ("img_h", f32), ("hyp_box", f32), ("hyp_cls", f32), ("hyp_dfl", f32),
                 ("use_wiou", i32), ("use_nwd", i32), ("iou_ratio", f32), ("gscale", vp), ("scalars", vp),
                 ("workspace", vp), ("dbox_rows_only", i32), ("box_from_input", i32), ("box_in", vp * 4), ("box_in_ld", i32 * 4),
-                ("box_w", vp * 4), ("box_b", vp * 4)]
+                ("box_w", vp * 4), ("box_b", vp * 4), ("box_in_coef", vp * 4)]
 
 
 # name -> (restype, argtypes); every exported symbol of include/dealyolo_hip.h appears here (tests/test_abi.py)
@@ -112,10 +112,10 @@ SIGNATURES = {
     "dy_maxpool5": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "dy_maxpool5_backward": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dy_bn_act_bwd_reduce_rows": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
-    "dy_head_box_decode": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_head_box_decode": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_conv1x1_rows_supported": (i32, [i32, i32]),
     "dy_conv1x1_rows_slabs": (i32, []),
-    "dy_conv1x1_rows_backward": (i32, [vp, i32, vp, i32, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dy_conv1x1_rows_backward": (i32, [vp, i32, vp, vp, i32, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dy_sppf_pool3_supported": (i32, [i32, i32, i32]),
     "dy_sppf_pool3": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
     "dy_sppf_pool3_backward": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -69,6 +69,10 @@ HEAD_ROWS = BIAS_WGRAD and os.environ.get("DY_HEAD_ROWS", "1") != "0"
 # never written -- the assigner gets the decoded box, the loss recomputes the logits of foreground anchors.  DY_HEAD_DECODE=0: the
 # conv writes its logits and the loss decodes them.
 HEAD_DECODE = HEAD_ROWS and os.environ.get("DY_HEAD_DECODE", "1") != "0"
+# ... and the Conv in front of it (cv2[l][1]) without an apply launch: its activated output is read by those kernels and by the loss's
+# foreground-logit recompute only, all of which take (raw, coefficient table) and apply BatchNorm + SiLU where they load
+# (common.h::bn_silu_apply8 -- the packed form of the apply kernel, hence only with DY_SILU_FAST on).  DY_HEAD_APPLY=0: apply launch.
+HEAD_APPLY = HEAD_DECODE and os.environ.get("DY_SILU_FAST", "1") != "0" and os.environ.get("DY_HEAD_APPLY", "1") != "0"
 BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
 BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
 
@@ -268,6 +272,7 @@ class Engine:
         self._uses = {}       # ... forward consumers per storage {id(st): {(c0, C): count}} ...
         self._prod = {}       # ... and the Conv (spec, raw Act) that produced a slice: dataflow facts of the trace in progress that
         self._reduced = set() # decide where a BatchNorm backward reduce can ride on the dgrad that writes its gradient (BN_DGRED)
+        self._unapplied = {}  # activations whose apply launch was left out: {(id(st), c0, C): (raw Act, spec)} (conv_bn_act, defer_apply)
         self._rows_grad = {}  # slices whose gradient was written by dy_conv1x1_rows_backward alone: {(id(st), c0, C): (assigned, A, a0)}
         self.training = False
         self._tmp_int = C.c_int(0)
@@ -341,7 +346,7 @@ class Engine:
             self.reset_dataflow()
 
     def reset_dataflow(self):
-        self._gw.clear(); self._uses.clear(); self._prod.clear(); self._reduced.clear(); self._rows_grad.clear()
+        self._gw.clear(); self._uses.clear(); self._prod.clear(); self._reduced.clear(); self._rows_grad.clear(); self._unapplied.clear()
 
     def _use(self, *xs):
         """Forward bookkeeping: ``x`` will receive a gradient contribution from the op being traced."""
@@ -544,9 +549,12 @@ class Engine:
         p = spec.ks // 2
         return (x.H + 2 * p - spec.ks) // spec.stride + 1, (x.W + 2 * p - spec.ks) // spec.stride + 1
 
-    def conv_bn_act(self, spec: ConvSpec, x: Act, out: Act | None = None, res: Act | None = None):
+    def conv_bn_act(self, spec: ConvSpec, x: Act, out: Act | None = None, res: Act | None = None, defer_apply=False):
         """Conv.forward (reference nn/modules/conv.py:49-55) with training-mode BatchNorm; optional fused residual
-        (Bottleneck.forward, nn/modules/block.py:333-335).  In eval mode BN uses running statistics."""
+        (Bottleneck.forward, nn/modules/block.py:333-335).  In eval mode BN uses running statistics.  ``defer_apply`` (training,
+        accumulator path, no residual; the caller guarantees that every consumer of the result asks ``unapplied()`` for (raw, spec)
+        instead of reading it): the apply launch only leaves the coefficient table and the running statistics behind (zero pixels),
+        the returned activation is never written."""
         if isinstance(x, ImageAct):
             if (self.training and STEM_DIRECT and spec.acc_f is not None and (spec.cin, spec.cout, spec.ks, spec.stride) == (3, 16, 3, 2)
                     and spec.act == DY_ACT_SILU and res is None and spec.ld is None):
@@ -566,10 +574,13 @@ class Engine:
         if acc:
             # statistics through the fp64 accumulator: conv adds, the apply kernel below finishes them in its prologue
             self._conv_raw(spec, x, raw.ptr, raw.ld, DY_EPI_STATS | DY_EPI_STATS_ACC, self._acc_ready(spec.acc_f))
+            deferred = bool(defer_apply and res is None and spec.act == DY_ACT_SILU and self.tape is not None)
             self.call("dy_bn_act_apply_acc", raw.ptr, raw.ld, 0 if res is None else res.ptr, 0 if res is None else res.ld, y.ptr,
                       y.ld, spec.acc_f.data_ptr(), bn["weight"].data_ptr(), bn["bias"].data_ptr(), bn["running_mean"].data_ptr(),
-                      bn["running_var"].data_ptr(), spec.coef.data_ptr(), npix, spec.cout, spec.act, float(npix), spec.bn_eps,
-                      spec.bn_mom)
+                      bn["running_var"].data_ptr(), spec.coef.data_ptr(), 0 if deferred else npix, spec.cout, spec.act, float(npix),
+                      spec.bn_eps, spec.bn_mom)
+            if deferred:
+                self._unapplied[(id(y.st), y.c0, y.C)] = (raw, spec)
         elif self.training:
             nparts = self.L.dy_conv_num_partials(x.N, x.H, x.W, x.C, spec.cout, spec.ks, spec.stride, 1)
             part = self.scratch("partials", nparts * 2 * ((spec.cout + 15) // 16 * 16) * 4 + 4096)
@@ -795,6 +806,10 @@ class Engine:
         return (self.rows_used is not None and self.tape is not None and spec.ks == 1 and spec.ld is None and spec.acc_bias is not None
                 and spec.bias is not None and bool(self.L.dy_conv1x1_rows_supported(spec.cin, spec.cout)))
 
+    def unapplied(self, x):
+        """(raw Act, producing spec) when ``x`` was produced with ``defer_apply`` -- its own buffer holds nothing -- else None."""
+        return self._unapplied.get((id(x.st), x.c0, x.C))
+
     def conv_bias_decode(self, spec: ConvSpec, x: Act, dy_ptr_fn, rows_level):
         """Detect's final box conv of level ``rows_level`` inside a StepPlan trace (caller checked ``rows_capable``): no logits are
         written; the plan launches dy_head_box_decode once the loss workspace is bound (``pending_decode``), the backward is the rows
@@ -822,10 +837,13 @@ class Engine:
             if x.needs_grad and not acc and self._sole_consumer_of_conv(x) is not None:
                 # x is a Conv's output whose only forward use was this conv: its gradient has the same rows, and nothing else
                 self._rows_grad[(id(x.st), x.c0, x.C)] = (asg, A, a0[rows_level])
-            self.call("dy_conv1x1_rows_backward", x.ptr, x.ld, dyp, ld, asg, A, a0[rows_level], spec.weight.data_ptr(),
+            src = self.unapplied(x)
+            xp, xld, xcoef = (x.ptr, x.ld, 0) if src is None else (src[0].ptr, src[0].ld, src[1].coef.data_ptr())
+            self.call("dy_conv1x1_rows_backward", xp, xld, xcoef, dyp, ld, asg, A, a0[rows_level], spec.weight.data_ptr(),
                       x.gptr if x.needs_grad else 0, x.ld, acc, slabs.data_ptr(), self._acc_ready(spec.acc_bias), x.N, Ho, Wo,
                       spec.cin, spec.cout)
             return
+        assert self.unapplied(x) is None, f"{spec.name}: the dense backward needs the activated input that was never written"
         if (BIAS_WGRAD and defer and not accumulate and self.deferred_wgrad is not None and spec.acc_bias is not None and spec.ld is None
                 and not self.side_wgrad):
             # the bias gradient rides on the weight-gradient kernel (sum of dY while it is staged) and the batched slab reduction

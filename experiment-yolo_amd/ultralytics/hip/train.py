@@ -145,9 +145,11 @@ class StepPlan:
                 a = crit._args
                 a.box_from_input = 1
                 for spec, xin, l in eng.pending_decode:
-                    eng.call("dy_head_box_decode", xin.ptr, xin.ld, spec.weight.data_ptr(), spec.bias.data_ptr(), crit.pred_box_ptr(), A, a0[l],
+                    src = eng.unapplied(xin)  # the Conv in front left its apply out: (raw, its spec)
+                    xp, xld, xcoef = (xin.ptr, xin.ld, 0) if src is None else (src[0].ptr, src[0].ld, src[1].coef.data_ptr())
+                    eng.call("dy_head_box_decode", xp, xld, xcoef, spec.weight.data_ptr(), spec.bias.data_ptr(), crit.pred_box_ptr(), A, a0[l],
                              xin.N, xin.H, xin.W, spec.cin, spec.cout)
-                    a.box_in[l], a.box_in_ld[l] = xin.ptr, xin.ld
+                    a.box_in[l], a.box_in_ld[l], a.box_in_coef[l] = xp, xld, xcoef
                     a.box_w[l], a.box_b[l] = spec.weight.data_ptr(), spec.bias.data_ptr()
             eng.call("dy_detection_loss", C.byref(crit._args))
             self.fb_split = len(eng.rec.ops)  # [0, fb_split) = forward + loss, the rest = backward (forward_only / backward_accumulate)

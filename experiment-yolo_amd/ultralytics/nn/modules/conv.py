@@ -52,11 +52,11 @@ class Conv(HipModule):
         p = k // 2
         return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
 
-    def forward_act(self, x, out=None, res=None):
+    def forward_act(self, x, out=None, res=None, defer_apply=False):
         eng = self.rt.eng
         spec = self.rt.spec(self)
         if hasattr(self, "bn"):
-            return eng.conv_bn_act(spec, x, out, res)
+            return eng.conv_bn_act(spec, x, out, res, defer_apply=defer_apply)
         return eng.conv_fused(spec, x, out, res)
 
     forward_fuse = HipModule.forward

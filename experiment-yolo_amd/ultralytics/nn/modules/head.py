@@ -106,16 +106,18 @@ class Detect(HipModule):
         if eng.tape is not None:
             ho.alloc_grads()
             eng.hold(*ho.dbox, *ho.dcls)
-        from ...hip.engine import HEAD_DECODE
+        from ...hip.engine import HEAD_APPLY, HEAD_DECODE
         # inside a StepPlan trace, when every level's box conv qualifies: forward fused with the loss's decode, backward from rows
         fused = HEAD_DECODE and eng.pending_decode is not None and all(eng.rows_capable(rt.specs[(id(self), "cv2", l)]) for l in range(len(xs)))
         lazy = []
         for l, x in enumerate(xs):
-            a = self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(x))
+            # fused: ``a`` is read by dy_head_box_decode, the rows backward and the loss only -- all of which apply BatchNorm + SiLU
+            # themselves, so the Conv in front leaves its apply launch out
+            a = self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(x), defer_apply=fused and HEAD_APPLY)
             c = self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(x))
             if fused:
                 eng.conv_bias_decode(rt.specs[(id(self), "cv2", l)], a, lambda l=l: (ho.dbox[l].data_ptr(), nb), l)
-                lazy.append((rt.specs[(id(self), "cv2", l)], a, boxes[l]))
+                lazy.append((rt.specs[(id(self), "cv2", l)], a, boxes[l], eng.unapplied(a)))
             else:
                 eng.conv_bias(rt.specs[(id(self), "cv2", l)], a, boxes[l].data_ptr(), nb, True,
                               lambda l=l: (ho.dbox[l].data_ptr(), nb), rows_level=l)
@@ -126,7 +128,10 @@ class Detect(HipModule):
 
             def fill():
                 assert eng.rec is None, "box logits can only be materialised outside a trace"
-                for spec, a, buf in lazy:
+                for spec, a, buf, src in lazy:
+                    if src is not None:  # the activated input was never written either
+                        raw, ps = src
+                        eng.call("dy_bn_act_apply", raw.ptr, raw.ld, 0, 0, a.ptr, a.ld, ps.coef.data_ptr(), a.npix, ps.cout, ps.act)
                     eng._conv_raw(spec, a, buf.data_ptr(), nb, DY_EPI_BIAS | DY_EPI_F32OUT, 0, spec.bias)
             ho.fill_box = fill
         return ho

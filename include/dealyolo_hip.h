@@ -278,6 +278,8 @@ typedef struct DyLossArgs {
   int box_in_ld[4];
   const float* box_w[4];         /* its fp32 weight (64,64) and bias (64) */
   const float* box_b[4];
+  const float* box_in_coef[4];   /* NULL, or the BatchNorm coefficient table [4][64] of the Conv that produced box_in when box_in is that
+                                    Conv's RAW output (no apply launch ran): BatchNorm + SiLU are applied where the rows are read */
 } DyLossArgs;
 size_t dy_loss_workspace_bytes(int B, int A, int nmax);
 /* byte offsets of pred_box (B,A,4 f32, grid units), assigned gt index (B,A i32, -1 = background) and target score
@@ -293,11 +295,14 @@ int dy_detection_loss(const DyLossArgs* args, hipStream_t stream);
  * elsewhere.  Rows of dy whose anchor is background are never read.  Supported: cin == cout == 64. */
 /* Forward of the same convolution fused with the loss's bbox_decode (utils/loss.py:347-354): pred_box (B, A, 4) in grid units, the
  * buffer at off_pred_box of the loss workspace; no logits are written (DyLossArgs.box_from_input). */
-int dy_head_box_decode(const void* x, int ldx, const float* weight, const float* bias, float* pred_box, int A, int a0, int n, int h,
-                       int w, int cin, int cout, hipStream_t stream);
+/* x_coef (both entries; may be NULL): x is the RAW output of the Conv below and x_coef its coefficient table [4][64] (scale, shift,
+ * mean, invstd as dy_bn_act_apply_acc leaves them): BatchNorm + SiLU are applied on load -- what nn/modules/conv.py:49-55 computes,
+ * without the launch and the tensor in between. */
+int dy_head_box_decode(const void* x, int ldx, const float* x_coef, const float* weight, const float* bias, float* pred_box, int A, int a0,
+                       int n, int h, int w, int cin, int cout, hipStream_t stream);
 int dy_conv1x1_rows_supported(int cin, int cout);
 int dy_conv1x1_rows_slabs(void);
-int dy_conv1x1_rows_backward(const void* x, int ldx, const void* dy, int lddy, const int* assigned, int A, int a0,
+int dy_conv1x1_rows_backward(const void* x, int ldx, const float* x_coef, const void* dy, int lddy, const int* assigned, int A, int a0,
                              const float* weight, void* dx, int lddx, int dx_accumulate, float* slabs, double* bias_acc, int n,
                              int h, int w, int cin, int cout, hipStream_t stream);
 /* TaskAlignedAssigner.forward utils/tal.py:39-88 as a call of its own (topk 10, alpha 0.5, beta 6.0: what v8DetectionLoss builds,

@@ -587,7 +587,7 @@ def test_conv1x1_rows_backward_reads_foreground_rows_only(acc):
     slabs = torch.full((ns, 64, 64), float("nan"), device="cuda")
     bacc = torch.zeros(DY_BN_COPIES, 64, dtype=torch.float64, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    check(L.dy_conv1x1_rows_backward(x.data_ptr(), 64, dyc.data_ptr(), 64, asg.cuda().data_ptr(), A, A0, w.data_ptr(), dx.data_ptr(), 64, acc,
+    check(L.dy_conv1x1_rows_backward(x.data_ptr(), 64, 0, dyc.data_ptr(), 64, asg.cuda().data_ptr(), A, A0, w.data_ptr(), dx.data_ptr(), 64, acc,
                                      slabs.data_ptr(), bacc.data_ptr(), B, H, W, 64, 64, s), "rows")
     torch.cuda.synchronize()
     d = torch.nan_to_num(dy.float(), nan=0.0).cuda()
@@ -646,7 +646,7 @@ def test_head_box_decode_equals_conv_then_bbox_decode():
     w = (torch.randn(64, 64) / 4).cuda()
     b = torch.randn(64).cuda()
     pb = torch.full((B, A, 4), -7.0, device="cuda")
-    check(L.dy_head_box_decode(x.data_ptr(), 64, w.data_ptr(), b.data_ptr(), pb.data_ptr(), A, A0, B, H, W, 64, 64,
+    check(L.dy_head_box_decode(x.data_ptr(), 64, 0, w.data_ptr(), b.data_ptr(), pb.data_ptr(), A, A0, B, H, W, 64, 64,
                                torch.cuda.current_stream().cuda_stream), "decode")
     torch.cuda.synchronize()
     logits = x.float() @ w.half().float().t() + b
@@ -656,3 +656,16 @@ def test_head_box_decode_equals_conv_then_bbox_decode():
     ref = torch.cat([anc - e[..., :2], anc + e[..., 2:]], -1)
     assert float((pb[:, A0:A0 + hw] - ref).abs().max()) < 2e-5
     assert bool((pb[:, :A0] == -7.0).all()) and bool((pb[:, A0 + hw:] == -7.0).all())
+    # the same from the RAW output of the Conv in front + its coefficient table: what feeding the tensor the apply launch writes gives
+    raw = torch.randn(B * hw, 64).half().cuda()
+    coef = torch.stack([torch.rand(64) + 0.5, torch.randn(64) * 0.3, torch.zeros(64), torch.ones(64)]).cuda().contiguous()
+    y = torch.empty_like(raw)
+    s_ = torch.cuda.current_stream().cuda_stream
+    check(L.dy_bn_act_apply(raw.data_ptr(), 64, 0, 0, y.data_ptr(), 64, coef.data_ptr(), B * hw, 64, 1, s_), "apply")
+    pb1, pb2 = torch.zeros((B, A, 4), device="cuda"), torch.zeros((B, A, 4), device="cuda")
+    check(L.dy_head_box_decode(y.data_ptr(), 64, 0, w.data_ptr(), b.data_ptr(), pb1.data_ptr(), A, A0, B, H, W, 64, 64, s_), "decode")
+    check(L.dy_head_box_decode(raw.data_ptr(), 64, coef.data_ptr(), w.data_ptr(), b.data_ptr(), pb2.data_ptr(), A, A0, B, H, W, 64, 64, s_), "decode")
+    torch.cuda.synchronize()
+    d = float((pb1 - pb2).abs().max())
+    print("decode from (raw, coef) vs from the applied tensor:", d)
+    assert d < 2e-3  # the plain apply kernel (library division) vs the packed form: an fp16 output differs in its last bit now and then
