@@ -279,3 +279,182 @@ extern "C" int dy_conv1x1_rows_backward(const void* x, int ldx, const float* x_c
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
+
+// ================================================================================================================================
+// Detect's final CLASS convolution (reference nn/modules/head.py:41-42: Conv2d(c3, nc, 1) with bias; nc <= 8 here) as stand-alone
+// element-wise kernels.  Eight output channels make no matrix tile; as a generic conv launch the layer moved 157 MB at 2.7 TB/s on the
+// 160x160 level, after an apply launch of its own for the Conv in front.  Here PARTS = cin / 8 lanes share a pixel (one 16-byte granule
+// each, fully coalesced), apply that Conv's BatchNorm + SiLU to the RAW granule they load, multiply with the 8 x 8 weight block they own
+// and meet in two / three shuffle steps.  The backward does the same walk once for all three gradients: weight (per-lane 8 x 8
+// accumulators, summed over the workgroup at the end, one slab per workgroup), bias (fp64 accumulator) and input (W^T dy, written
+// as the gradient of the Conv in front).
+struct ClsArgs {
+  const f16* x;        // [npix][ldx]: RAW output of the Conv in front when xcoef is set, else its activated output
+  const float* xcoef;  // [4][cin] scale, shift, ..
+  const float* w;      // fp32 master [nc][cin]
+  const float* bias;   // [nc]
+  float* y;            // forward: logits [npix][8] fp32
+  const f16* dy;       // backward: [npix][8]
+  f16* dx;             // backward: [npix][lddx] gradient of the activated input (may be NULL)
+  float* slabs;        // backward: [gridDim.x][16][cin] fp32
+  double* bias_acc;    // backward: [DY_BN_COPIES][8]
+  int ldx, lddx, nc, dx_acc;
+  long npix;
+};
+template <int CIN>
+__global__ __launch_bounds__(256) void cls_head_fwd_kernel(ClsArgs a) {
+  constexpr int PARTS = CIN / 8, PPB = 256 / PARTS;
+  __shared__ float s_w[8][CIN], s_b[8];
+  for (int i = threadIdx.x; i < 8 * CIN; i += 256) s_w[i / CIN][i % CIN] = (i / CIN) < a.nc ? (float)(f16)a.w[i] : 0.f;
+  if (threadIdx.x < 8) s_b[threadIdx.x] = threadIdx.x < a.nc ? a.bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int part = threadIdx.x % PARTS, k0 = part * 8;
+  float sc[8], sh[8];
+  if (a.xcoef) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = a.xcoef[k0 + j]; sh[j] = a.xcoef[CIN + k0 + j]; }
+  }
+  for (long pix = (long)blockIdx.x * PPB + threadIdx.x / PARTS; pix < a.npix; pix += (long)gridDim.x * PPB) {
+    half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + k0);
+    if (a.xcoef) xv = bn_silu_apply8(xv, sc, sh);
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t += s_w[c][k0 + j] * (float)xv[j];
+      o[c] = t;
+    }
+#pragma unroll
+    for (int m = 1; m < PARTS; m <<= 1)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] += __shfl_xor(o[c], m, 64);
+    if (part == 0) {
+      float* dst = a.y + pix * 8;
+      *reinterpret_cast<float4*>(dst) = make_float4(o[0] + s_b[0], o[1] + s_b[1], o[2] + s_b[2], o[3] + s_b[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4] + s_b[4], o[5] + s_b[5], o[6] + s_b[6], o[7] + s_b[7]);
+    }
+  }
+}
+template <int CIN>
+__global__ __launch_bounds__(256) void cls_head_bwd_kernel(ClsArgs a) {
+  constexpr int PARTS = CIN / 8, PPB = 256 / PARTS;
+  __shared__ float s_w[8][CIN];
+  __shared__ float s_red[4][PARTS][64];
+  __shared__ float s_bs[4][8];
+  for (int i = threadIdx.x; i < 8 * CIN; i += 256) s_w[i / CIN][i % CIN] = (i / CIN) < a.nc ? (float)(f16)a.w[i] : 0.f;
+  __syncthreads();
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, part = tid % PARTS, k0 = part * 8;
+  float sc[8], sh[8];
+  if (a.xcoef) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = a.xcoef[k0 + j]; sh[j] = a.xcoef[CIN + k0 + j]; }
+  }
+  float acc[8][8], bs[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    bs[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[c][j] = 0.f;
+  }
+  // a workgroup owns a contiguous pixel range (its sums have one order whatever the grid)
+  const long chunk = ((a.npix + gridDim.x - 1) / gridDim.x + PPB - 1) / PPB * PPB;
+  const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < a.npix ? lo + chunk : a.npix;
+  for (long pix = lo + tid / PARTS; pix < hi; pix += PPB) {
+    half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + k0);
+    const half8 dv = *reinterpret_cast<const half8*>(a.dy + pix * 8);
+    if (a.xcoef) xv = bn_silu_apply8(xv, sc, sh);
+    float d[8], g[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) d[c] = (float)dv[c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc[c][j] += d[c] * (float)xv[j];
+        g[j] += s_w[c][k0 + j] * d[c];
+      }
+      if (part == 0) bs[c] += d[c];
+    }
+    if (a.dx) {
+      f16* dst = a.dx + pix * a.lddx + k0;
+      half8 o;
+      if (a.dx_acc) {
+        const half8 old = *reinterpret_cast<const half8*>(dst);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)old[j] + g[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)g[j];
+      }
+      *reinterpret_cast<half8*>(dst) = o;
+    }
+  }
+  // lanes with the same channel part (lane % PARTS) -> one lane per wave, waves -> LDS, then one slab [16][CIN] per workgroup
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = acc[c][j];
+#pragma unroll
+      for (int m = PARTS; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+      acc[c][j] = v;
+    }
+    float b = bs[c];
+#pragma unroll
+    for (int m = PARTS; m < 64; m <<= 1) b += __shfl_xor(b, m, 64);
+    bs[c] = b;
+  }
+  if (lane < PARTS) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_red[wave][lane][c * 8 + j] = acc[c][j];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s_bs[wave][c] = bs[c];
+  }
+  __syncthreads();
+  float* slab = a.slabs + (size_t)blockIdx.x * 16 * CIN;
+  for (int i = tid; i < 16 * CIN; i += 256) {
+    const int co = i / CIN, ci = i - co * CIN;
+    float v = 0.f;
+    if (co < 8) {
+      const int pp = ci >> 3, j = ci & 7;
+      v = (s_red[0][pp][co * 8 + j] + s_red[1][pp][co * 8 + j]) + (s_red[2][pp][co * 8 + j] + s_red[3][pp][co * 8 + j]);
+    }
+    slab[i] = v;
+  }
+  if (tid < 8) {
+    const float b = (s_bs[0][tid] + s_bs[1][tid]) + (s_bs[2][tid] + s_bs[3][tid]);
+    if (b != 0.f) unsafeAtomicAdd(a.bias_acc + (size_t)(blockIdx.x % DY_BN_COPIES) * 8 + tid, (double)b);
+  }
+}
+extern "C" int dy_cls_head_supported(int cin, int nc) { return (cin == 32 || cin == 64) && nc >= 1 && nc <= 8; }
+extern "C" int dy_cls_head_slabs(void) { return 512; }
+extern "C" int dy_cls_head_forward(const void* x, int ldx, const float* x_coef, const float* weight, const float* bias, float* logits,
+                                   long npix, int cin, int nc, hipStream_t stream) {
+  if (!dy_cls_head_supported(cin, nc) || !x || !weight || !bias || !logits || npix < 1) return DY_ERR_ARG;
+  if ((ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)logits & 15)) return DY_ERR_ALIGN;
+  ClsArgs a{(const f16*)x, x_coef, weight, bias, logits, nullptr, nullptr, nullptr, nullptr, ldx, 0, nc, 0, npix};
+  const int ppb = 256 / (cin / 8);
+  long blocks = (npix + ppb - 1) / ppb;
+  if (blocks > 4096) blocks = 4096;
+  if (cin == 32) hipLaunchKernelGGL(cls_head_fwd_kernel<32>, dim3((int)blocks), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(cls_head_fwd_kernel<64>, dim3((int)blocks), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+extern "C" int dy_cls_head_backward(const void* x, int ldx, const float* x_coef, const void* dy, const float* weight, void* dx, int lddx,
+                                    int dx_accumulate, float* slabs, double* bias_acc, long npix, int cin, int nc, hipStream_t stream) {
+  if (!dy_cls_head_supported(cin, nc) || !x || !dy || !weight || !slabs || !bias_acc || npix < 1) return DY_ERR_ARG;
+  if ((ldx & 7) || (dx && (lddx & 7)) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return DY_ERR_ALIGN;
+  ClsArgs a{(const f16*)x, x_coef, weight, nullptr, nullptr, (const f16*)dy, (f16*)dx, slabs, bias_acc, ldx, lddx, nc, dx_accumulate, npix};
+  if (cin == 32) hipLaunchKernelGGL(cls_head_bwd_kernel<32>, dim3(dy_cls_head_slabs()), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(cls_head_bwd_kernel<64>, dim3(dy_cls_head_slabs()), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}

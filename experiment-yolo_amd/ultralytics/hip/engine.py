@@ -72,6 +72,9 @@ HEAD_DECODE = HEAD_ROWS and os.environ.get("DY_HEAD_DECODE", "1") != "0"
 # ... and the Conv in front of it (cv2[l][1]) without an apply launch: its activated output is read by those kernels and by the loss's
 # foreground-logit recompute only, all of which take (raw, coefficient table) and apply BatchNorm + SiLU where they load
 # (common.h::bn_silu_apply8 -- the packed form of the apply kernel, hence only with DY_SILU_FAST on).  DY_HEAD_APPLY=0: apply launch.
+# Detect's final class conv (nc <= 8) as stand-alone element-wise kernels, forward and one-walk backward (csrc/head_rows.hip,
+# dy_cls_head_*), inside a StepPlan trace; with HEAD_APPLY the Conv in front leaves its apply out here too.  DY_HEAD_CLS=0: generic conv.
+HEAD_CLS = BIAS_WGRAD and os.environ.get("DY_HEAD_CLS", "1") != "0"
 HEAD_APPLY = HEAD_DECODE and os.environ.get("DY_SILU_FAST", "1") != "0" and os.environ.get("DY_HEAD_APPLY", "1") != "0"
 BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
 BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
@@ -805,6 +808,30 @@ class Engine:
     def rows_capable(self, spec):
         return (self.rows_used is not None and self.tape is not None and spec.ks == 1 and spec.ld is None and spec.acc_bias is not None
                 and spec.bias is not None and bool(self.L.dy_conv1x1_rows_supported(spec.cin, spec.cout)))
+
+    def cls_capable(self, spec, ncp):
+        return (HEAD_CLS and self.pending_decode is not None and self.tape is not None and spec.ks == 1 and spec.ld is None and ncp == 8
+                and spec.acc_bias is not None and spec.bias is not None and bool(self.L.dy_cls_head_supported(spec.cin, spec.cout)))
+
+    def conv_bias_cls(self, spec: ConvSpec, x: Act, y_ptr, dy_ptr_fn):
+        """Detect's final class conv inside a StepPlan trace (caller checked ``cls_capable``): dy_cls_head_forward now, one
+        dy_cls_head_backward launch for the weight, bias and input gradients later."""
+        self._use(x)
+        src = self.unapplied(x)
+        xp, xld, xcoef = (x.ptr, x.ld, 0) if src is None else (src[0].ptr, src[0].ld, src[1].coef.data_ptr())
+        self.call("dy_cls_head_forward", xp, xld, xcoef, spec.weight.data_ptr(), spec.bias.data_ptr(), y_ptr, x.npix, spec.cin, spec.cout)
+
+        def bwd():
+            dyp, ld = dy_ptr_fn()
+            assert ld == 8 and self.deferred_wgrad is not None and not self.side_wgrad
+            ns = self.L.dy_cls_head_slabs()
+            slabs = self.transient((ns * 16 * spec.cin,), torch.float32)
+            self.hold(slabs)
+            self.deferred_wgrad.append((spec, slabs, ns, spec.acc_bias))
+            acc = x.grad_target() if x.needs_grad else 0
+            self.call("dy_cls_head_backward", xp, xld, xcoef, dyp, spec.weight.data_ptr(), x.gptr if x.needs_grad else 0, x.ld, acc,
+                      slabs.data_ptr(), self._acc_ready(spec.acc_bias), x.npix, spec.cin, spec.cout)
+        self.tape.append(bwd)
 
     def unapplied(self, x):
         """(raw Act, producing spec) when ``x`` was produced with ``defer_apply`` -- its own buffer holds nothing -- else None."""

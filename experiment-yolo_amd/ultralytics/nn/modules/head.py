@@ -114,15 +114,19 @@ class Detect(HipModule):
             # fused: ``a`` is read by dy_head_box_decode, the rows backward and the loss only -- all of which apply BatchNorm + SiLU
             # themselves, so the Conv in front leaves its apply launch out
             a = self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(x), defer_apply=fused and HEAD_APPLY)
-            c = self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(x))
+            cspec = rt.specs[(id(self), "cv3", l)]
+            cls_fused = eng.cls_capable(cspec, ncp)
+            c = self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(x), defer_apply=cls_fused and HEAD_APPLY)
             if fused:
                 eng.conv_bias_decode(rt.specs[(id(self), "cv2", l)], a, lambda l=l: (ho.dbox[l].data_ptr(), nb), l)
                 lazy.append((rt.specs[(id(self), "cv2", l)], a, boxes[l], eng.unapplied(a)))
             else:
                 eng.conv_bias(rt.specs[(id(self), "cv2", l)], a, boxes[l].data_ptr(), nb, True,
                               lambda l=l: (ho.dbox[l].data_ptr(), nb), rows_level=l)
-            eng.conv_bias(rt.specs[(id(self), "cv3", l)], c, clss[l].data_ptr(), ncp, True,
-                          lambda l=l: (ho.dcls[l].data_ptr(), ncp))
+            if cls_fused:
+                eng.conv_bias_cls(cspec, c, clss[l].data_ptr(), lambda l=l: (ho.dcls[l].data_ptr(), ncp))
+            else:
+                eng.conv_bias(cspec, c, clss[l].data_ptr(), ncp, True, lambda l=l: (ho.dcls[l].data_ptr(), ncp))
         if lazy:
             from ...hip import DY_EPI_BIAS, DY_EPI_F32OUT
 

@@ -300,6 +300,17 @@ int dy_detection_loss(const DyLossArgs* args, hipStream_t stream);
  * without the launch and the tensor in between. */
 int dy_head_box_decode(const void* x, int ldx, const float* x_coef, const float* weight, const float* bias, float* pred_box, int A, int a0,
                        int n, int h, int w, int cin, int cout, hipStream_t stream);
+/* Detect's final CLASS convolution (nn/modules/head.py:41-42, Conv2d(c3, nc, 1) with bias) for nc <= 8, cin 32 or 64, as stand-alone
+ * kernels.  Forward: logits (npix, 8) fp32, channels >= nc written as 0.  x_coef as above (RAW input + the coefficient table of the
+ * Conv in front, or NULL for an activated input).  Backward, one walk: weight gradient as dy_cls_head_slabs() fp32 slabs [16][cin] for
+ * dy_wgrad_reduce_batched, bias gradient as fp64 sums in bias_acc [DY_BN_COPIES][8], input gradient dx = W^T dy (stored, or added
+ * when dx_accumulate; may be NULL).  dy: (npix, 8) fp16. */
+int dy_cls_head_supported(int cin, int nc);
+int dy_cls_head_slabs(void);
+int dy_cls_head_forward(const void* x, int ldx, const float* x_coef, const float* weight, const float* bias, float* logits, long npix,
+                        int cin, int nc, hipStream_t stream);
+int dy_cls_head_backward(const void* x, int ldx, const float* x_coef, const void* dy, const float* weight, void* dx, int lddx,
+                         int dx_accumulate, float* slabs, double* bias_acc, long npix, int cin, int nc, hipStream_t stream);
 int dy_conv1x1_rows_supported(int cin, int cout);
 int dy_conv1x1_rows_slabs(void);
 int dy_conv1x1_rows_backward(const void* x, int ldx, const float* x_coef, const void* dy, int lddy, const int* assigned, int A, int a0,

@@ -669,3 +669,47 @@ def test_head_box_decode_equals_conv_then_bbox_decode():
     d = float((pb1 - pb2).abs().max())
     print("decode from (raw, coef) vs from the applied tensor:", d)
     assert d < 2e-3  # the plain apply kernel (library division) vs the packed form: an fp16 output differs in its last bit now and then
+
+
+@pytest.mark.parametrize("cin,nc,coef", [(32, 6, True), (64, 8, False), (32, 1, True)])
+def test_cls_head_kernels_equal_the_dense_products(cin, nc, coef):
+    """dy_cls_head_forward / dy_cls_head_backward (Detect's final class conv, reference nn/modules/head.py:41-42) against fp32 torch
+    products: logits, weight / bias gradient (slabs + fp64 sums) and the input gradient, from an activated input and from the RAW
+    output of the Conv in front + its coefficient table; ragged pixel count."""
+    from ultralytics.hip import DY_BN_COPIES, check, lib
+    L = lib()
+    torch.manual_seed(12)
+    npix = 3 * 37 * 23 + 5
+    raw = torch.randn(npix, cin).half().cuda()
+    w = (torch.randn(nc, cin) / 4).cuda()
+    b = torch.randn(nc).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    if coef:
+        cf = torch.stack([torch.rand(cin) + 0.5, torch.randn(cin) * 0.3, torch.zeros(cin), torch.ones(cin)]).cuda().contiguous()
+        z = raw.float() * cf[0] + cf[1]
+        x = (z * torch.sigmoid(z)).half()
+        xp, cp = raw.data_ptr(), cf.data_ptr()
+    else:
+        x, xp, cp = raw, raw.data_ptr(), 0
+    logits = torch.full((npix, 8), 3.0, device="cuda")
+    check(L.dy_cls_head_forward(xp, cin, cp, w.data_ptr(), b.data_ptr(), logits.data_ptr(), npix, cin, nc, s), "fwd")
+    ref = x.float() @ w.half().float().t() + b
+    torch.cuda.synchronize()
+    assert relerr(logits[:, :nc], ref) < 2e-3 and bool((logits[:, nc:] == 0).all())
+    dy = torch.zeros(npix, 8, dtype=torch.float16, device="cuda")
+    dy[:, :nc] = torch.randn(npix, nc).half()
+    ns = L.dy_cls_head_slabs()
+    slabs = torch.full((ns, 16, cin), float("nan"), device="cuda")
+    bacc = torch.zeros(DY_BN_COPIES, 8, dtype=torch.float64, device="cuda")
+    dx0 = torch.randn(npix, cin).half().cuda()
+    for acc in (0, 1):
+        dx = dx0.clone()
+        bacc.zero_()
+        check(L.dy_cls_head_backward(xp, cin, cp, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), cin, acc, slabs.data_ptr(), bacc.data_ptr(),
+                                     npix, cin, nc, s), "bwd")
+        torch.cuda.synchronize()
+        dw = slabs.sum(0)
+        assert relerr(dw[:nc], dy[:, :nc].float().t() @ x.float()) < 2e-3 and bool((dw[nc:] == 0).all())
+        assert relerr(bacc.sum(0)[:nc].float(), dy[:, :nc].float().sum(0)) < 1e-5
+        dx_ref = dy[:, :nc].float() @ w.half().float() + (dx0.float() if acc else 0.0)
+        assert relerr(dx.float(), dx_ref) < 2e-3
