@@ -536,7 +536,7 @@ extern "C" int dy_bn_act_bwd_reduce_rows(const void* dy, int lddy, const void* x
   const int cpp = C >> 3;
   if (cpp > 256 || !acc || !assigned || n < 1 || hw < 1 || a0 < 0 || a0 + hw > A) return DY_ERR_ARG;
   BwdRedRowsArgs a{(const f16*)dy, (const f16*)x, coef, acc, assigned, lddy, ldx, C, A, a0, hw, n};
-  DY_ACT_DISPATCH(bn_act_bwd_reduce_rows_kernel, dim3(256), stream, a);
+  DY_ACT_DISPATCH(bn_act_bwd_reduce_rows_kernel, dim3(1024), stream, a);  // four workgroups per CU: the walk is latency-bound
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

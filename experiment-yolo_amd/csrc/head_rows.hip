@@ -28,7 +28,7 @@ struct RowsArgs {
 __global__ __launch_bounds__(256) void rows_wgrad_kernel(RowsArgs a) {
   __shared__ int s_list[256];
   __shared__ int s_cnt[4];
-  __shared__ __attribute__((aligned(16))) f16 s_x[64], s_dy[64];
+  __shared__ __attribute__((aligned(16))) f16 s_x[16 * 64], s_dy[16 * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int co = tid >> 2, ci0 = (tid & 3) * 16;
   const long npix = (long)a.B * a.hw;
@@ -70,19 +70,29 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(RowsArgs a) {
     }
     if (fg) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = tid;  // ordered: ascending pixel
     __syncthreads();
-    for (int i = 0; i < total; ++i) {
-      const long q = p0 + s_list[i];
-      if (tid < 8) {
-        half8 xv = *reinterpret_cast<const half8*>(a.x + q * a.ldx + tid * 8);
-        if (a.xcoef) xv = bn_silu_apply8(xv, a.xcoef + tid * 8, a.xcoef + 64 + tid * 8);
-        *reinterpret_cast<half8*>(s_x + tid * 8) = xv;
+    // the rows of up to 16 foreground pixels are staged per barrier pair: thread (i, g) brings granule g of pixel i (8 of x, 8 of dy)
+    for (int i0 = 0; i0 < total; i0 += 16) {
+      const int nb = total - i0 < 16 ? total - i0 : 16;
+      {
+        const int i = tid >> 4, g = tid & 15;
+        if (i < nb) {
+          const long q = p0 + s_list[i0 + i];
+          if (g < 8) {
+            half8 xv = *reinterpret_cast<const half8*>(a.x + q * a.ldx + g * 8);
+            if (a.xcoef) xv = bn_silu_apply8(xv, a.xcoef + g * 8, a.xcoef + 64 + g * 8);
+            *reinterpret_cast<half8*>(s_x + i * 64 + g * 8) = xv;
+          } else {
+            *reinterpret_cast<uint4*>(s_dy + i * 64 + (g - 8) * 8) = *reinterpret_cast<const uint4*>(a.dy + q * a.lddy + (g - 8) * 8);
+          }
+        }
       }
-      else if (tid < 16) *reinterpret_cast<uint4*>(s_dy + (tid - 8) * 8) = *reinterpret_cast<const uint4*>(a.dy + q * a.lddy + (tid - 8) * 8);
       __syncthreads();
-      const float g = (float)s_dy[co];
+      for (int i = 0; i < nb; ++i) {
+        const float g = (float)s_dy[i * 64 + co];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) acc[k] += g * (float)s_x[ci0 + k];
-      if ((tid & 3) == 0) bs += g;
+        for (int k = 0; k < 16; ++k) acc[k] += g * (float)s_x[i * 64 + ci0 + k];
+        if ((tid & 3) == 0) bs += g;
+      }
       __syncthreads();
     }
   }
@@ -259,7 +269,12 @@ extern "C" int dy_head_box_decode(const void* x, int ldx, const float* x_coef, c
 }
 
 extern "C" int dy_conv1x1_rows_supported(int cin, int cout) { return cin == 64 && cout == 64; }
-extern "C" int dy_conv1x1_rows_slabs(void) { return 256; }
+// workgroups (= fp32 slabs of 16 KB) of the weight-gradient walk: four per CU, so that one's flag / row latencies lie under another's
+// arithmetic (256: 144 -> 96 us per call at 160x160 with everything else in place; 1024: see profiles/r03_stage_ab.md)
+extern "C" int dy_conv1x1_rows_slabs(int n, int h, int w) {
+  const long ns = (long)n * h * w / 2048;  // measured per call at 160 / 80 / 40 (batch 64): 256 slabs 96 / 28 / 20 us, 1024 slabs 79 / 30 / 26 us
+  return ns < 64 ? 64 : (ns > 1024 ? 1024 : (int)ns);
+}
 extern "C" int dy_conv1x1_rows_backward(const void* x, int ldx, const float* x_coef, const void* dy, int lddy, const int* assigned, int A, int a0,
                                         const float* weight, void* dx, int lddx, int dx_accumulate, float* slabs, double* bias_acc,
                                         int n, int h, int w, int cin, int cout, hipStream_t stream) {
@@ -270,10 +285,10 @@ extern "C" int dy_conv1x1_rows_backward(const void* x, int ldx, const float* x_c
       ((uintptr_t)slabs & 15))
     return DY_ERR_ALIGN;
   RowsArgs a{(const f16*)x, (const f16*)dy, assigned, weight, (f16*)dx, slabs, bias_acc, ldx, lddy, lddx, A, a0, h * w, n, dx_accumulate, x_coef};
-  hipLaunchKernelGGL(rows_wgrad_kernel, dim3(dy_conv1x1_rows_slabs()), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(rows_wgrad_kernel, dim3(dy_conv1x1_rows_slabs(n, h, w)), dim3(256), 0, stream, a);
   if (dx) {
-    int gx = (h * w + 31) / 32;
-    if (gx > 128) gx = 128;
+    int gx = (h * w + 1023) / 1024;  // every workgroup copies the 16 KB weight into LDS first: give it >= 1024 pixels
+    if (gx > 16) gx = 16;
     hipLaunchKernelGGL(rows_dgrad_kernel, dim3(gx, n), dim3(256), 0, stream, a);
   }
   DY_CHECK_LAUNCH();

@@ -574,15 +574,26 @@ __global__ __launch_bounds__(256) void box_loss_kernel(LossCtx c) {
     float logit;
     if (L.box) {
       logit = L.box[off];
-    } else {  // lane = output channel (side * 16 + bin): one row of the 64x64 weight against this pixel's 64 input channels
-      const f16* xr = L.xin + (((size_t)b * L.H + iy) * L.W + ix) * L.ldin;
-      const float* wr = L.w + lane * 64;
+    } else {
+      // lane = output channel (side * 16 + bin) AND input channel: every lane brings one input value (BatchNorm + SiLU applied to it
+      // when the layer input is the RAW output of the Conv in front -- the pair form of the apply kernel, so the same bits), the 64
+      // values go round by shuffle against the lane's row of the weight (rounded to fp16 as the packed form the conv multiplies with)
+      const float xraw = (float)L.xin[(((size_t)b * L.H + iy) * L.W + ix) * L.ldin + lane];
+      float yv = xraw;
+      if (L.incoef) {
+        const float z = __builtin_fmaf(xraw, L.incoef[lane], L.incoef[64 + lane]);
+        const f32x2 a2 = act_fwd2_fast<DY_ACT_SILU>((f32x2){z, z});
+        yv = (float)(f16)a2[0];
+      }
+      const float4* wr = reinterpret_cast<const float4*>(L.w + lane * 64);
       float sacc = 0.f;
-      for (int k8 = 0; k8 < 64; k8 += 8) {
-        half8 xv = *reinterpret_cast<const half8*>(xr + k8);
-        if (L.incoef) xv = bn_silu_apply8(xv, L.incoef + k8, L.incoef + 64 + k8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sacc += (float)(f16)wr[k8 + k] * (float)xv[k];
+#pragma unroll 4
+      for (int k4 = 0; k4 < 16; ++k4) {
+        const float4 w4 = wr[k4];
+        sacc += (float)(f16)w4.x * __shfl(yv, k4 * 4, 64);
+        sacc += (float)(f16)w4.y * __shfl(yv, k4 * 4 + 1, 64);
+        sacc += (float)(f16)w4.z * __shfl(yv, k4 * 4 + 2, 64);
+        sacc += (float)(f16)w4.w * __shfl(yv, k4 * 4 + 3, 64);
       }
       logit = sacc + L.bias[lane];
     }

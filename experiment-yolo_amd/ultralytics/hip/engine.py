@@ -856,7 +856,7 @@ class Engine:
         if (rows_level is not None and self.loss_rows is not None and defer and not accumulate and self.deferred_wgrad is not None
                 and not self.side_wgrad):
             asg, A, a0 = self.loss_rows
-            ns = self.L.dy_conv1x1_rows_slabs()
+            ns = self.L.dy_conv1x1_rows_slabs(x.N, Ho, Wo)
             slabs = self.transient((ns * spec.cout * spec.cin,), torch.float32)
             self.hold(slabs)
             self.deferred_wgrad.append((spec, slabs, ns, spec.acc_bias))

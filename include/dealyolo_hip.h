@@ -289,7 +289,7 @@ int dy_detection_loss(const DyLossArgs* args, hipStream_t stream);
 /* Backward of Detect's final box convolution (nn/modules/head.py:38-40, Conv2d(c2, 4*reg_max, 1) with bias) from a gradient that has
  * ROWS: utils/loss.py:436-445 gives box / DFL terms to foreground anchors only, every other row of d(box logits) is zero.
  * assigned: the loss's per-anchor gt index (B, A) int32, -1 = background (workspace + off_asg_gt of dy_loss_workspace_layout);
- * this level's pixel (b, r) is anchor a0 + r.  Weight gradient: dy_conv1x1_rows_slabs() fp32 slabs [64][64] for
+ * this level's pixel (b, r) is anchor a0 + r.  Weight gradient: dy_conv1x1_rows_slabs(n, h, w) fp32 slabs [64][64] for
  * dy_wgrad_reduce_batched (descriptor: cin 64, cout 64, ks 1); bias gradient: fp64 sums into bias_acc [DY_BN_COPIES][64] (finished by
  * dy_wgrad_reduce_desc_bias); input gradient dx (may be NULL): W^T dy on foreground pixels, zeros (or untouched when dx_accumulate)
  * elsewhere.  Rows of dy whose anchor is background are never read.  Supported: cin == cout == 64. */
@@ -312,7 +312,7 @@ int dy_cls_head_forward(const void* x, int ldx, const float* x_coef, const float
 int dy_cls_head_backward(const void* x, int ldx, const float* x_coef, const void* dy, const float* weight, void* dx, int lddx,
                          int dx_accumulate, float* slabs, double* bias_acc, long npix, int cin, int nc, hipStream_t stream);
 int dy_conv1x1_rows_supported(int cin, int cout);
-int dy_conv1x1_rows_slabs(void);
+int dy_conv1x1_rows_slabs(int n, int h, int w);
 int dy_conv1x1_rows_backward(const void* x, int ldx, const float* x_coef, const void* dy, int lddy, const int* assigned, int A, int a0,
                              const float* weight, void* dx, int lddx, int dx_accumulate, float* slabs, double* bias_acc, int n,
                              int h, int w, int cin, int cout, hipStream_t stream);

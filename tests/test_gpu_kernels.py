@@ -583,7 +583,7 @@ def test_conv1x1_rows_backward_reads_foreground_rows_only(acc):
     dyc = dy.cuda()
     dx0 = h16(torch.randn(npix, 64)).cuda().half()
     dx = dx0.clone()
-    ns = L.dy_conv1x1_rows_slabs()
+    ns = L.dy_conv1x1_rows_slabs(B, H, W)
     slabs = torch.full((ns, 64, 64), float("nan"), device="cuda")
     bacc = torch.zeros(DY_BN_COPIES, 64, dtype=torch.float64, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
