@@ -3,6 +3,7 @@
 // (reference nn/modules/block.py:166-171), element-wise adds (Add / Bottleneck shortcut, gradient fan-in) and strided
 // channel-slice copies (Concat, reference nn/modules/conv.py:338-348, when a producer cannot write in place).
 // All are HBM-bound byte movers: 16 bytes per lane, pixel-major so that wave accesses are contiguous.
+#include <cstdlib>
 #include "common.h"
 #include "dealyolo_hip.h"
 
@@ -973,6 +974,128 @@ __global__ __launch_bounds__(256) void scalseq_bwd_all_kernel(SsBwdAllArgs a) {
     }
   }
 }
+// The same pass with a wave = (64 / cpp) adjacent COLUMNS x the 4 rows of one level-2 row: a lane owns one column (one 8-channel granule
+// of it), so every load of r0 / dY / dr0 is a row of consecutive pixels across the wave -- full lines -- where the kernel above gave a
+// lane a 4x4 block and touched 16 half-used lines per instruction (2.1 TB/s in the statistics pass).  The level-1 / level-2 sums meet by
+// shuffle (column pairs: lane ^ cpp; column quads: + lane ^ 2 cpp); the lane of the first column of a pair / quad adds them to the
+// statistics or stores dr1 / dr2.  Needs cpp | 64 and W a multiple of 64 / cpp; the kernel above takes every other shape.
+__global__ __launch_bounds__(256) void scalseq_bwd_cols_kernel(SsBwdAllArgs a) {
+  const int cpp = a.C >> 3, PW = 64 / cpp;
+  const int h1 = a.H >> 1, w1 = a.W >> 1, h2 = a.H >> 2, w2 = a.W >> 2;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int part = lane % cpp, col = lane / cpp, c0 = part * 8;
+  float sc[8], sh[8], mean[8], inv[8], mg[8], mgx[8], ps[8], px[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = a.coef[c0 + j];
+    sh[j] = a.coef[a.C + c0 + j];
+    mean[j] = a.coef[2 * a.C + c0 + j];
+    inv[j] = a.coef[3 * a.C + c0 + j];
+    mg[j] = a.mode ? a.bwdcoef[c0 + j] : 0.f;
+    mgx[j] = a.mode ? a.bwdcoef[a.C + c0 + j] : 0.f;
+    ps[j] = px[j] = 0.f;
+  }
+  const int chunks = a.W / PW;
+  const long items = (long)a.N * h2 * chunks;
+  for (long it = (long)blockIdx.x * 4 + wave; it < items; it += (long)gridDim.x * 4) {
+    const int xc = (int)(it % chunks);
+    const long t = it / chunks;
+    const int y2 = (int)(t % h2);
+    const long n = t / h2;
+    const int x = xc * PW + col;
+    const long lp2 = (n * h2 + y2) * w2 + (x >> 2);
+    const half8 own2 = *reinterpret_cast<const half8*>(a.r[2] + lp2 * a.ld[2] + c0);
+    float z2[8], gs2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float zz = (float)own2[j] * sc[j] + sh[j];
+      z2[j] = zz > 0.f ? zz : 0.1f * zz;
+      gs2[j] = 0.f;
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int y1 = y2 * 2 + hf;
+      const long lp1 = (n * h1 + y1) * w1 + (x >> 1);
+      const half8 own1 = *reinterpret_cast<const half8*>(a.r[1] + lp1 * a.ld[1] + c0);
+      float z1[8], gs1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float zz = (float)own1[j] * sc[j] + sh[j];
+        z1[j] = zz > 0.f ? zz : 0.1f * zz;
+        gs1[j] = 0.f;
+      }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const long pos = (n * a.H + (y1 * 2 + rr)) * a.W + x;
+        const half8 own0 = *reinterpret_cast<const half8*>(a.r[0] + pos * a.ld[0] + c0);
+        const half8 g = *reinterpret_cast<const half8*>(a.dy + pos * a.lddy + c0);
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float zz0 = (float)own0[j] * sc[j] + sh[j];
+          const float z0 = zz0 > 0.f ? zz0 : 0.1f * zz0;
+          int am = 0;  // first maximum wins (max_pool3d over the depth axis), as above
+          float zb = z0;
+          if (z1[j] > zb) { am = 1; zb = z1[j]; }
+          if (z2[j] > zb) { am = 2; zb = z2[j]; }
+          const float gg = (float)g[j] * (zb > 0.f ? 1.f : 0.1f);
+          const float g0 = am == 0 ? gg : 0.f;
+          gs1[j] += am == 1 ? gg : 0.f;
+          gs2[j] += am == 2 ? gg : 0.f;
+          const float xh0 = ((float)own0[j] - mean[j]) * inv[j];
+          if (a.mode == 0) {
+            ps[j] += g0;
+            px[j] += g0 * xh0;
+          } else {
+            o[j] = (f16)(sc[j] * (g0 - mg[j] - xh0 * mgx[j]));
+          }
+        }
+        if (a.mode) *reinterpret_cast<half8*>(a.dr[0] + pos * a.lddr[0] + c0) = o;
+      }
+      half8 o1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float tot = gs1[j] + __shfl_xor(gs1[j], cpp, 64);  // the column pair of this level-1 pixel
+        const float xh = ((float)own1[j] - mean[j]) * inv[j];
+        if (a.mode == 0) {
+          if (!(col & 1)) { ps[j] += tot; px[j] += tot * xh; }
+        } else {
+          o1[j] = (f16)(sc[j] * (tot - 4.f * mg[j] - 4.f * xh * mgx[j]));
+        }
+      }
+      if (a.mode && !(col & 1)) *reinterpret_cast<half8*>(a.dr[1] + lp1 * a.lddr[1] + c0) = o1;
+    }
+    half8 o2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float tot = gs2[j] + __shfl_xor(gs2[j], cpp, 64);
+      tot += __shfl_xor(tot, 2 * cpp, 64);  // the four columns of this level-2 pixel
+      const float xh = ((float)own2[j] - mean[j]) * inv[j];
+      if (a.mode == 0) {
+        if (!(col & 3)) { ps[j] += tot; px[j] += tot * xh; }
+      } else {
+        o2[j] = (f16)(sc[j] * (tot - 16.f * mg[j] - 16.f * xh * mgx[j]));
+      }
+    }
+    if (a.mode && !(col & 3)) *reinterpret_cast<half8*>(a.dr[2] + lp2 * a.lddr[2] + c0) = o2;
+  }
+  if (a.mode == 0) {
+    __shared__ float red[2][256][9];
+    const int rows = 256 / cpp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[0][tid][j] = ps[j];
+      red[1][tid][j] = px[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * a.C; i += 256) {
+      const int which = i / a.C, c = i - which * a.C, pp = c >> 3, j = c & 7;
+      float sum = 0.f;
+      for (int r = 0; r < rows; ++r) sum += red[which][r * cpp + pp][j];  // thread index = (wave * 64 / cpp + column) * cpp + part
+      a.partials[((size_t)blockIdx.x * 2 + which) * a.C + c] = sum;
+    }
+  }
+}
 extern "C" int dy_scalseq_tail_backward_all(const void* r0, int ld0, const void* r1, int ld1, const void* r2, int ld2,
                                             const void* dy, int lddy, void* dr0, int lddr0, void* dr1, int lddr1,
                                             void* dr2, int lddr2, const float* coef, const float* bwdcoef,
@@ -988,6 +1111,18 @@ extern "C" int dy_scalseq_tail_backward_all(const void* r0, int ld0, const void*
   if (blocks > 2048) blocks = 2048;
   if (mode == 0 && blocks > max_partials) blocks = max_partials;
   if (blocks < 1) blocks = 1;
+  static const bool cols_ok = !(getenv("DY_SCALSEQ_COLS") && atoi(getenv("DY_SCALSEQ_COLS")) == 0);
+  const int cpp = C >> 3;
+  if (cols_ok && cpp <= 16 && 64 % cpp == 0 && w % (64 / cpp) == 0) {
+    long wblocks = ((long)n * (h >> 2) * (w / (64 / cpp)) + 3) / 4;
+    if (wblocks > 2048) wblocks = 2048;
+    if (mode == 0 && wblocks > max_partials) wblocks = max_partials;
+    if (wblocks < 1) wblocks = 1;
+    if (nparts) *nparts = (int)wblocks;
+    hipLaunchKernelGGL(scalseq_bwd_cols_kernel, dim3((int)wblocks), dim3(256), 0, stream, a);
+    DY_CHECK_LAUNCH();
+    return DY_OK;
+  }
   if (nparts) *nparts = (int)blocks;
   hipLaunchKernelGGL(scalseq_bwd_all_kernel, dim3((int)blocks), dim3(256), 0, stream, a);
   DY_CHECK_LAUNCH();

@@ -340,13 +340,15 @@ def test_wgrad_deferred_batched_reduce_matches_immediate():
         assert torch.equal(sp.gweight, r)  # same slabs, same summation order
 
 
-def test_scalseq_backward_all_levels_matches_per_level():
-    """dy_scalseq_tail_backward_all (one pass per mode) against the per-level entry point it replaced in the engine."""
+@pytest.mark.parametrize("H,W,Cc", [(16, 24, 16), (16, 32, 32), (8, 64, 16), (12, 16, 64)])
+def test_scalseq_backward_all_levels_matches_per_level(H, W, Cc):
+    """dy_scalseq_tail_backward_all (one pass per mode) against the per-level entry point it replaced in the engine.  (16, 24, 16) takes
+    the block-per-lane kernel (24 columns are no multiple of 32), the other shapes the column-per-lane one."""
     import ctypes as C
     eng = _eng()
     L = eng.L
     torch.manual_seed(5)
-    N, H, W, Cc = 2, 16, 24, 16
+    N = 2
     s = torch.cuda.current_stream().cuda_stream
     r = [torch.randn(N, H >> l, W >> l, Cc, device="cuda").half() for l in range(3)]
     dy = torch.randn(N, H, W, Cc, device="cuda").half()
