@@ -61,6 +61,8 @@ BIAS_WGRAD = BN_ACC and os.environ.get("DY_BIAS_WGRAD", "1") != "0"
 SPPF_FUSED = os.environ.get("DY_SPPF_FUSED", "1") != "0"
 # Add's backward hands the sum's gradient buffer to an operand that has no other consumer instead of copying it (Engine.add).
 ADD_ALIAS = os.environ.get("DY_ADD_ALIAS", "1") != "0"
+# The Add that follows ScalSeq (ASF models) folded into ScalSeq's tail kernel as a residual operand (nn/tasks.py, forward_act).
+SCALSEQ_ADD = os.environ.get("DY_SCALSEQ_ADD", "1") != "0"
 # Detect's final box convolution back-propagated from the ROWS of its output gradient (the loss writes box / DFL gradients for
 # foreground anchors only): csrc/head_rows.hip reads the loss's assignment instead of a zero-filled dense gradient.  Only inside a
 # StepPlan trace (the plan binds the assignment buffer and tells the loss not to zero the rest); DY_HEAD_ROWS=0: the dense kernels.
@@ -1034,10 +1036,11 @@ class Engine:
         return y
 
     # ---- ScalSeq (reference nn/extra_modules/block.py:3426-3443) --------------------------------------------------
-    def scalseq(self, conv3d: ConvSpec, bn3d, coef, bwdcoef, gbn, ps, out: Act | None = None):
+    def scalseq(self, conv3d: ConvSpec, bn3d, coef, bwdcoef, gbn, ps, out: Act | None = None, res: Act | None = None):
         """ps = [p3 (full res), p4 (1/2), p5 (1/4)] already channel-matched.  conv3d: 1x1x1 conv with bias applied to
         every scale at its native resolution (a 1x1 conv commutes with nearest up-sampling); BatchNorm3d statistics
-        are those of the up-sampled (B,3,H,W) volume, i.e. level l weighs 4**l."""
+        are those of the up-sampled (B,3,H,W) volume, i.e. level l weighs 4**l.  ``res``: a tensor added to the result (the ``Add`` that
+        follows ScalSeq in the ASF models, reference nn/extra_modules/block.py:3479-3484, folded into the tail kernel)."""
         p3 = ps[0]
         N, H, W, Cc = p3.N, p3.H, p3.W, conv3d.cout
         assert ps[1].H * 2 == H and ps[2].H * 4 == H and ps[1].W * 2 == W and ps[2].W * 4 == W, "ScalSeq needs exact 2x/4x pyramids"
@@ -1064,10 +1067,20 @@ class Engine:
             self.call("dy_bn_eval_coef", bn3d["weight"].data_ptr(), bn3d["bias"].data_ptr(), bn3d["running_mean"].data_ptr(),
                       bn3d["running_var"].data_ptr(), coef.data_ptr(), Cc, BN3D_EPS)
         y = out if out is not None else self.new_act(N, H, W, Cc)
-        self.call("dy_scalseq_tail", raws[0].ptr, raws[0].ld, raws[1].ptr, raws[1].ld, raws[2].ptr, raws[2].ld, 0, 0, y.ptr,
-                  y.ld, coef.data_ptr(), N, H, W, Cc)
+        if res is not None:
+            assert (res.N, res.H, res.W, res.C) == (N, H, W, Cc)
+            self._use(res)
+        self.call("dy_scalseq_tail", raws[0].ptr, raws[0].ld, raws[1].ptr, raws[1].ld, raws[2].ptr, raws[2].ld,
+                  0 if res is None else res.ptr, 0 if res is None else res.ld, y.ptr, y.ld, coef.data_ptr(), N, H, W, Cc)
         if self.tape is not None:
-            self.tape.append(lambda: self._scalseq_bwd(conv3d, coef, bwdcoef, gbn, ps, raws, y))
+            def bwd():
+                if res is not None and res.needs_grad:  # d(sum)/d(res) = identity, as in Engine.add
+                    if res.grad_target():
+                        self.call("dy_add", res.gptr, res.ld, y.gptr, y.ld, 0, 0, res.gptr, res.ld, res.npix, res.C)
+                    else:
+                        self.call("dy_copy_slice", y.gptr, y.ld, res.gptr, res.ld, res.npix, res.C)
+                self._scalseq_bwd(conv3d, coef, bwdcoef, gbn, ps, raws, y)
+            self.tape.append(bwd)
         return y
 
     def _scalseq_bwd(self, conv3d, coef, bwdcoef, gbn, ps, raws, y):

@@ -43,14 +43,14 @@ class ScalSeq(HipModule):
         sp.bwdcoef3d = rt.eng.f32(2 * sp.cout)
         sp.gbn3d = (rt.gviews[id(self.bn.weight)], rt.gviews[id(self.bn.bias)])
 
-    def forward_act(self, xs, out=None):
+    def forward_act(self, xs, out=None, res=None):
         p3, p4, p5 = xs
         if hasattr(self, "conv0"):
             p3 = self.conv0.forward_act(p3)
         p4 = self.conv1.forward_act(p4)
         p5 = self.conv2.forward_act(p5)
         sp = self.rt.specs[(id(self), "conv3d")]
-        return self.rt.eng.scalseq(sp, sp.bn3d, sp.coef3d, sp.bwdcoef3d, sp.gbn3d, [p3, p4, p5], out)
+        return self.rt.eng.scalseq(sp, sp.bn3d, sp.coef3d, sp.bwdcoef3d, sp.gbn3d, [p3, p4, p5], out, res=res)
 
 
 class Add(HipModule):

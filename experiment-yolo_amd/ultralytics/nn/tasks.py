@@ -174,9 +174,15 @@ class BaseModel(HipModule):
         if isinstance(x, ImageAct) and not (type(self.model[0]) is Conv and self.model[0].f == -1 and 0 not in plan):
             x = x.materialize()  # only a plain Conv stem reads the image batch directly (csrc/stem.hip)
         n_backbone = len(self.yaml.get("backbone", [])) if isinstance(getattr(self, "yaml", None), dict) else 0
+        from ..hip.engine import SCALSEQ_ADD
+        folded = None
         for m in self.model:
             if m.i == n_backbone and eng.tape is not None:
                 eng.tape_mark = len(eng.tape)  # backward closures from here on belong to the neck + head (StepPlan's gradient buckets)
+            if folded is not None and m.i == folded:
+                folded = None  # this Add was computed by the ScalSeq in front of it (x is the sum already)
+                ys.append(x if m.i in self.save else None)
+                continue
             if m.f != -1:
                 x = ys[m.f] if isinstance(m.f, int) else [x if j == -1 else ys[j] for j in m.f]
             dst = None
@@ -196,6 +202,17 @@ class BaseModel(HipModule):
                     cats[ci] = (eng.new_storage(src0.N, oh, ow, sum(widths)), widths)
                 st, widths = cats[ci]
                 dst = st.act(sum(widths[:pos]), widths[pos])
+            nxt = self.model[m.i + 1] if m.i + 1 < len(self.model) else None
+            if (SCALSEQ_ADD and self.__dict__.get("_capture") is None  # (a per-layer capture wants ScalSeq's own output to exist)
+                    and isinstance(m, ScalSeq) and dst is None and isinstance(nxt, Add) and nxt.i not in plan
+                    and m.i not in self.save and isinstance(nxt.f, (list, tuple)) and len(nxt.f) == 2
+                    and sum(1 for j in nxt.f if j == -1 or j == m.i) == 1):
+                # ScalSeq -> Add([other, -1]) (reference yolov8-ASF*.yaml): the sum rides on ScalSeq's tail kernel
+                other = [j for j in nxt.f if not (j == -1 or j == m.i)][0]
+                x = m.forward_act(x, res=ys[other])
+                folded = nxt.i
+                ys.append(None)
+                continue
             x = m.forward_act(x, dst) if dst is not None else m.forward_act(x)
             ys.append(x if m.i in self.save else None)
             if self.__dict__.get("_capture") is not None:  # tests: per-layer outputs (engine Acts) of this forward
