@@ -1075,7 +1075,13 @@ class Engine:
         if self.tape is not None:
             def bwd():
                 if res is not None and res.needs_grad:  # d(sum)/d(res) = identity, as in Engine.add
-                    if res.grad_target():
+                    if (ADD_ALIAS and res.st.gbuf is None and not res.st.gwritten and res.c0 == 0 and res.C == res.st.C and y.c0 == 0
+                            and y.C == y.st.C and y.st.gbuf is not None and tuple(res.st.buf.shape) == tuple(y.st.buf.shape)):
+                        # res has no gradient yet: it takes y's gradient buffer as its own.  Every writer of y's gradient has run, its
+                        # one reader (the ScalSeq backward below) runs before anything can be added to res's gradient.
+                        res.st.gbuf = y.st.gbuf
+                        res.grad_target()
+                    elif res.grad_target():
                         self.call("dy_add", res.gptr, res.ld, y.gptr, y.ld, 0, 0, res.gptr, res.ld, res.npix, res.C)
                     else:
                         self.call("dy_copy_slice", y.gptr, y.ld, res.gptr, res.ld, res.npix, res.C)
