@@ -82,6 +82,7 @@ class v8DetectionLoss:
         a = self._args
         a.nl, a.B, a.nc, a.ncp = len(ho.box), ho.box[0].shape[0], self.nc, ho.cls[0].shape[-1]
         a.nmax = nmax
+        a.dbox_rows_only = a.box_from_input = 0  # a StepPlan trace switches them on AFTER binding (hip/train.py); every other caller is dense
         A = 0
         for l in range(a.nl):
             a.box[l], a.cls[l] = ho.box[l].data_ptr(), ho.cls[l].data_ptr()
