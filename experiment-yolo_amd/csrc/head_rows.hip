@@ -161,6 +161,15 @@ static __device__ __forceinline__ float exp_nonpos(float x) {
   const float e = __builtin_amdgcn_exp2f(t);
   return __builtin_fmaf(e, r * 0.693147182f, e);
 }
+// the same for a pair (element-wise identical arithmetic: v_pk_mul / v_pk_fma around the two v_exp)
+static __device__ __forceinline__ f32x2 exp_nonpos2(f32x2 x) {
+  const f32x2 l2e = {1.44269502f, 1.44269502f}, l2e_lo = {1.92596299e-8f, 1.92596299e-8f}, ln2 = {0.693147182f, 0.693147182f};
+  const f32x2 t = x * l2e;
+  f32x2 r = __builtin_elementwise_fma(x, l2e, -t);
+  r = __builtin_elementwise_fma(x, l2e_lo, r);
+  const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  return __builtin_elementwise_fma(e, r * ln2, e);
+}
 struct BoxDecArgs {
   const f16* x;
   const float* w;     // fp32 master [64][64]
@@ -239,7 +248,14 @@ __global__ __launch_bounds__(256) void head_box_decode_kernel(BoxDecArgs a) {
       float den4[4], num4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // decode_kernel's quarters: four consecutive bins, then (q0 + q1) + (q2 + q3)
-        const float e0 = ex(v[g * 4] - mx), e1 = ex(v[g * 4 + 1] - mx), e2 = ex(v[g * 4 + 2] - mx), e3 = ex(v[g * 4 + 3] - mx);
+        float e0, e1, e2, e3;
+        if (LIBM) {
+          e0 = ex(v[g * 4] - mx); e1 = ex(v[g * 4 + 1] - mx); e2 = ex(v[g * 4 + 2] - mx); e3 = ex(v[g * 4 + 3] - mx);
+        } else {
+          const f32x2 m2 = {mx, mx};
+          const f32x2 ea = exp_nonpos2((f32x2){v[g * 4], v[g * 4 + 1]} - m2), eb = exp_nonpos2((f32x2){v[g * 4 + 2], v[g * 4 + 3]} - m2);
+          e0 = ea[0]; e1 = ea[1]; e2 = eb[0]; e3 = eb[1];
+        }
         const float k0 = (float)(g * 4);
         den4[g] = (e0 + e1) + (e2 + e3);
         num4[g] = e0 * k0 + e1 * (k0 + 1.f) + e2 * (k0 + 2.f) + e3 * (k0 + 3.f);
