@@ -782,6 +782,8 @@ extern "C" int dy_tal_assign(const float* const* scores, const int* H, const int
   return DY_OK;
 }
 
+// sizeof(DyLossArgs) as this library was compiled: a binding that lays the block out differently must notice before its first call
+extern "C" int dy_loss_args_bytes(void) { return (int)sizeof(DyLossArgs); }
 extern "C" int dy_detection_loss(const DyLossArgs* d, hipStream_t stream) {
   if (d->nl < 1 || d->nl > 4 || d->nmax < 1 || (d->ncp & 7) || d->nc > d->ncp) return DY_ERR_ARG;
   LossCtx c{};

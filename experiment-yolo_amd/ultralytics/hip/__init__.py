@@ -59,6 +59,7 @@ class DyLossArgs(C.Structure):
 # name -> (restype, argtypes); every exported symbol of include/dealyolo_hip.h appears here (tests/test_abi.py)
 SIGNATURES = {
     "dy_abi_version": (i32, []),
+    "dy_loss_args_bytes": (i32, []),
     "dy_conv_geometry": (i32, [i32, i32, i32, i32, ip, ip, ip, ip, ip, ip, ip, ip]),
     "dy_pack_weights": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dy_pack_desc_bytes": (i32, []),
@@ -161,6 +162,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        if L.dy_loss_args_bytes() != C.sizeof(DyLossArgs):  # a stale .so (or a stale binding) would read garbage pointers
+            raise RuntimeError(f"{LIB_PATH} was built with a DyLossArgs of {L.dy_loss_args_bytes()} bytes, this binding lays out "
+                               f"{C.sizeof(DyLossArgs)}: rebuild the library (make -C experiment-yolo_amd/csrc)")
         _LIB = L
     return _LIB
 

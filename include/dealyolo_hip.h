@@ -281,6 +281,7 @@ typedef struct DyLossArgs {
   const float* box_in_coef[4];   /* NULL, or the BatchNorm coefficient table [4][64] of the Conv that produced box_in when box_in is that
                                     Conv's RAW output (no apply launch ran): BatchNorm + SiLU are applied where the rows are read */
 } DyLossArgs;
+int dy_loss_args_bytes(void); /* sizeof(DyLossArgs) in the library: bindings compare it with their own layout */
 size_t dy_loss_workspace_bytes(int B, int A, int nmax);
 /* byte offsets of pred_box (B,A,4 f32, grid units), assigned gt index (B,A i32, -1 = background) and target score
  * (B,A f32) inside the workspace after a call -- used by the parity tests */

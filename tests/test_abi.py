@@ -69,6 +69,9 @@ def test_conv_kernel_name_helper():
     assert L.dy_wgrad_kernel_name_at(64, 160, 160, 64, 64, 3, 1, buf, 128) == 0 and buf.value == b"conv_wgrad_kernel<3, 1, 4, 4, 0>"
     assert L.dy_wgrad_kernel_name_at(64, 40, 40, 64, 64, 3, 1, buf, 128) == 0 and buf.value == b"conv_wgrad_kernel<3, 1, 2, 2, 0>", buf.value
     assert L.dy_wgrad_reduce_desc_bytes() >= 64
+    # the argument block of dy_detection_loss has the same size on both sides of the boundary (lib() refuses to load otherwise)
+    from ultralytics.hip import DyLossArgs
+    assert L.dy_loss_args_bytes() == C.sizeof(DyLossArgs)
 
 
 def test_header_is_plain_c(tmp_path):
