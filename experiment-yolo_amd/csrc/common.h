@@ -1,5 +1,6 @@
 // Shared device helpers for the DEAL-YOLO gfx950 kernels (wave64, MFMA 16x16x32 f16).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,11 +29,18 @@ static __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 // sum over the 16 lanes that share (lane >> 4)
+// Sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), result in every lane.  Four v_add_f32 with a DPP operand -- quad
+// swaps, then row_half_mirror (lane i <-> 7 - i of its half row: the other quad, whose lanes all hold their quad's sum) and row_mirror
+// (i <-> 15 - i: the other half row) -- instead of four __shfl_xor, which the compiler lowers to ds_bpermute / ds_swizzle: each of those
+// is an LDS-pipe round trip, and the statistics tail of the conv kernel does 128 of them per lane on 8 waves at once.
 static __device__ __forceinline__ float quad16_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1, 0, 3, 2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2, 3, 0, 1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
   return v;
 }
 static __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
