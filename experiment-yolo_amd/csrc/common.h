@@ -33,14 +33,28 @@ static __device__ __forceinline__ float wave_max(float v) {
 // swaps, then row_half_mirror (lane i <-> 7 - i of its half row: the other quad, whose lanes all hold their quad's sum) and row_mirror
 // (i <-> 15 - i: the other half row) -- instead of four __shfl_xor, which the compiler lowers to ds_bpermute / ds_swizzle: each of those
 // is an LDS-pipe round trip, and the statistics tail of the conv kernel does 128 of them per lane on 8 waves at once.
+template <int CTRL>
+static __device__ __forceinline__ float dpp_read(float x) {  // x of the lane the DPP control names (0 where there is none)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+#define DY_DPP_QUAD_1032 0xB1   // quad_perm [1, 0, 3, 2]: lane ^ 1
+#define DY_DPP_QUAD_2301 0x4E   // quad_perm [2, 3, 0, 1]: lane ^ 2
+#define DY_DPP_HALF_MIRROR 0x141
+#define DY_DPP_ROW_MIRROR 0x140
+#define DY_DPP_ROW_SHL(n) (0x100 + (n))  // lane + n inside its row of 16
+static __device__ __forceinline__ float quad_sum(float v) {  // over the 4 lanes of a quad
+  v += dpp_read<DY_DPP_QUAD_1032>(v);
+  v += dpp_read<DY_DPP_QUAD_2301>(v);
+  return v;
+}
+static __device__ __forceinline__ float half_row_sum(float v) {  // over the 8 lanes of a half row
+  v = quad_sum(v);
+  v += dpp_read<DY_DPP_HALF_MIRROR>(v);
+  return v;
+}
 static __device__ __forceinline__ float quad16_sum(float v) {
-  auto dpp = [](float x, auto ctrl) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
-  };
-  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1, 0, 3, 2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2, 3, 0, 1]
-  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
-  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
+  v = half_row_sum(v);
+  v += dpp_read<DY_DPP_ROW_MIRROR>(v);
   return v;
 }
 static __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }

@@ -357,9 +357,7 @@ __global__ __launch_bounds__(256) void cls_head_fwd_kernel(ClsArgs a) {
       o[c] = t;
     }
 #pragma unroll
-    for (int m = 1; m < PARTS; m <<= 1)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) o[c] += __shfl_xor(o[c], m, 64);
+    for (int c = 0; c < 8; ++c) o[c] = PARTS == 4 ? quad_sum(o[c]) : half_row_sum(o[c]);  // the pixel's lanes: one quad / one half row (DPP)
     if (part == 0) {
       float* dst = a.y + pix * 8;
       *reinterpret_cast<float4*>(dst) = make_float4(o[0] + s_b[0], o[1] + s_b[1], o[2] + s_b[2], o[3] + s_b[3]);

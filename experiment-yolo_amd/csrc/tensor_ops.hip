@@ -1055,7 +1055,9 @@ __global__ __launch_bounds__(256) void scalseq_bwd_cols_kernel(SsBwdAllArgs a) {
       half8 o1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float tot = gs1[j] + __shfl_xor(gs1[j], cpp, 64);  // the column pair of this level-1 pixel
+        // the column pair of this level-1 pixel.  Four parts per pixel (C = 32): a column is a quad and the lane that uses the total is
+        // in the pair's first column, so "lane + 4 of my row" is the partner (one DPP add); other widths take the shuffle
+        const float tot = gs1[j] + (cpp == 4 ? dpp_read<DY_DPP_ROW_SHL(4)>(gs1[j]) : __shfl_xor(gs1[j], cpp, 64));
         const float xh = ((float)own1[j] - mean[j]) * inv[j];
         if (a.mode == 0) {
           if (!(col & 1)) { ps[j] += tot; px[j] += tot * xh; }
@@ -1068,8 +1070,14 @@ __global__ __launch_bounds__(256) void scalseq_bwd_cols_kernel(SsBwdAllArgs a) {
     half8 o2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float tot = gs2[j] + __shfl_xor(gs2[j], cpp, 64);
-      tot += __shfl_xor(tot, 2 * cpp, 64);  // the four columns of this level-2 pixel
+      float tot;  // the four columns of this level-2 pixel (cpp == 4: one DPP row; its first quad ends with the sum of all four)
+      if (cpp == 4) {
+        tot = gs2[j] + dpp_read<DY_DPP_ROW_SHL(4)>(gs2[j]);
+        tot += dpp_read<DY_DPP_ROW_SHL(8)>(tot);
+      } else {
+        tot = gs2[j] + __shfl_xor(gs2[j], cpp, 64);
+        tot += __shfl_xor(tot, 2 * cpp, 64);
+      }
       const float xh = ((float)own2[j] - mean[j]) * inv[j];
       if (a.mode == 0) {
         if (!(col & 3)) { ps[j] += tot; px[j] += tot * xh; }
