@@ -1283,6 +1283,13 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
 // ----------------------------------------------------------------------------------------------------------------
 static int pp_trows(int cc, int mt, int ks, int stride, int nch);
 static int pick_cc(int cin_p, int ks, int stride) {
+  static const int forced = getenv("DY_CONV_CC") ? atoi(getenv("DY_CONV_CC")) : 0;  // measurement switch, read once
+  if (forced && cin_p % forced == 0) return forced;
+  // 64-channel stride-2 3x3: 16-channel chunks.  A stride-2 halo tile is 9 x 65 pixels for 4 x 32 outputs, so the staged bytes per MFMA
+  // are four times a stride-1 tile's; with 32-channel chunks the tile + weights only fit for 32-wide cout groups, i.e. 64->128 staged
+  // its input four times.  16-channel chunks leave room for the 64-wide group: 78.1 -> 61.0 us (64->128 @80x80), 43.1 -> 32.7 (64->64);
+  // narrower inputs lose with them (32->64 @160: 36.4 -> 44.2), gpurun_out/s2_sweep.log.
+  if (ks == 3 && stride == 2 && cin_p == 64) return 16;
   const int cap = (ks == 3 && stride == 2) ? 32 : 64;
   if (cin_p <= cap && (cin_p == 8 || cin_p == 16 || cin_p == 32 || cin_p == 64)) return cin_p;
   if (cin_p % 64 == 0 && cap >= 64) return 64;
