@@ -12,6 +12,14 @@
 #include "common.h"
 #include "dealyolo_hip.h"
 
+// Several detection levels in ONE launch: the kernels below take a table of per-level argument blocks and blockIdx.y (blockIdx.z where y
+// is the image) picks the level, so the small levels' workgroups -- latency-bound walks over a few thousand pixels -- run beside the
+// large level's instead of after it, and three launches per kind become one.
+template <typename T>
+struct Levels {
+  int nl;
+  T lv[4];
+};
 struct RowsArgs {
   const f16* x;      // [npix][ldx] layer input (activated), cin = 64 channels
   const f16* dy;     // [npix][lddy] gradient of the 64 box logits; only rows whose flag >= 0 hold data
@@ -22,17 +30,20 @@ struct RowsArgs {
   double* bias_acc;  // [DY_BN_COPIES][64]
   int ldx, lddy, lddx, A, a0, hw, B, dx_acc;
   const float* xcoef;  // non-null: x is the RAW output of the Conv below ([4][64]: scale, shift, ..); BatchNorm + SiLU applied on load
+  int nblk, dgx;       // workgroups of the weight-gradient walk (= slabs) / of the input-gradient kernel per image, for THIS level
 };
 
 // ---- weight + bias gradient over the foreground pixels of this workgroup's pixel range
-__global__ __launch_bounds__(256) void rows_wgrad_kernel(RowsArgs a) {
+__global__ __launch_bounds__(256) void rows_wgrad_kernel(Levels<RowsArgs> L) {
+  const RowsArgs& a = L.lv[blockIdx.y];
+  if ((int)blockIdx.x >= a.nblk) return;
   __shared__ int s_list[256];
   __shared__ int s_cnt[4];
   __shared__ __attribute__((aligned(16))) f16 s_x[16 * 64], s_dy[16 * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int co = tid >> 2, ci0 = (tid & 3) * 16;
   const long npix = (long)a.B * a.hw;
-  const long chunk = (npix + gridDim.x - 1) / gridDim.x;
+  const long chunk = (npix + a.nblk - 1) / a.nblk;
   const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < npix ? lo + chunk : npix;
   float acc[16];
 #pragma unroll
@@ -104,13 +115,15 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(RowsArgs a) {
 
 // ---- input gradient: dx[p] = W^T dy[p] on foreground pixels (weights rounded to fp16 as the packed form the dense kernel multiplies
 // with, fp32 sum over the output channels in ascending order), zeros elsewhere; blockIdx.y = image
-__global__ __launch_bounds__(256) void rows_dgrad_kernel(RowsArgs a) {
+__global__ __launch_bounds__(256) void rows_dgrad_kernel(Levels<RowsArgs> L) {
+  const RowsArgs& a = L.lv[blockIdx.z];
+  if (!a.dx || (int)blockIdx.x >= a.dgx || (int)blockIdx.y >= a.B) return;
   __shared__ float s_w[64 * 65];  // [co][ci], pitch 65
   for (int i = threadIdx.x; i < 64 * 64; i += 256) s_w[(i >> 6) * 65 + (i & 63)] = (float)(f16)a.w[i];
   __syncthreads();
   const int b = blockIdx.y, part = threadIdx.x & 7, ci0 = part * 8;
   const int* const fl = a.flag + (size_t)b * a.A + a.a0;
-  for (int r = (int)(blockIdx.x * 32 + (threadIdx.x >> 3)); r < a.hw; r += (int)gridDim.x * 32) {
+  for (int r = (int)(blockIdx.x * 32 + (threadIdx.x >> 3)); r < a.hw; r += a.dgx * 32) {
     const long p = (long)b * a.hw + r;
     f16* const dst = a.dx + p * a.lddx + ci0;
     if (fl[r] < 0) {
@@ -177,9 +190,12 @@ struct BoxDecArgs {
   float* pred_box;    // (B, A, 4) grid units
   int ldx, A, a0, hw, W, B;
   const float* xcoef;  // non-null: x is the RAW output of the Conv below; its BatchNorm + SiLU apply happens on load, no apply launch
+  int nblk;
 };
 template <bool LIBM>
-__global__ __launch_bounds__(256) void head_box_decode_kernel(BoxDecArgs a) {
+__global__ __launch_bounds__(256) void head_box_decode_kernel(Levels<BoxDecArgs> L) {
+  const BoxDecArgs& a = L.lv[blockIdx.y];
+  if ((int)blockIdx.x >= a.nblk) return;
   auto ex = [](float x) { return LIBM ? expf(x) : exp_nonpos(x); };
   constexpr int PITCH = 160;  // bytes per weight row: 10 sixteen-byte slots (== 2 mod 4: conflict-free for ds_read_b128's lane groups)
   __shared__ __attribute__((aligned(16))) char s_w[64 * PITCH];
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(256) void head_box_decode_kernel(BoxDecArgs a) {
         csh[ks][j] = a.xcoef[64 + ks * 32 + q * 8 + j];
       }
   }
-  for (long base = ((long)blockIdx.x * 4 + wave) * 64; base < npix; base += (long)gridDim.x * 256) {
+  for (long base = ((long)blockIdx.x * 4 + wave) * 64; base < npix; base += (long)a.nblk * 256) {
     half8 bf[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -269,19 +285,42 @@ __global__ __launch_bounds__(256) void head_box_decode_kernel(BoxDecArgs a) {
     }
   }
 }
-extern "C" int dy_head_box_decode(const void* x, int ldx, const float* x_coef, const float* weight, const float* bias, float* pred_box, int A,
-                                  int a0, int n, int h, int w, int cin, int cout, hipStream_t stream) {
+static int box_decode_fill(BoxDecArgs& a, const void* x, int ldx, const float* x_coef, const float* weight, const float* bias, float* pred_box,
+                           int A, int a0, int n, int h, int w, int cin, int cout) {
   if (cin != 64 || cout != 64 || !x || !weight || !bias || !pred_box || n < 1 || h < 1 || w < 1 || a0 < 0 || a0 + h * w > A) return DY_ERR_ARG;
   if ((ldx & 7) || ((uintptr_t)x & 15)) return DY_ERR_ALIGN;
-  BoxDecArgs a{(const f16*)x, weight, bias, pred_box, ldx, A, a0, h * w, w, n, x_coef};
-  const long npix = (long)n * h * w;
-  long blocks = (npix + 255) / 256;
+  long blocks = ((long)n * h * w + 255) / 256;
   if (blocks > 2048) blocks = 2048;
+  a = BoxDecArgs{(const f16*)x, weight, bias, pred_box, ldx, A, a0, h * w, w, n, x_coef, (int)blocks};
+  return DY_OK;
+}
+static int box_decode_launch(const Levels<BoxDecArgs>& L, hipStream_t stream) {
+  int gx = 1;
+  for (int l = 0; l < L.nl; ++l) gx = L.lv[l].nblk > gx ? L.lv[l].nblk : gx;
   static const bool libm = getenv("DY_DECODE_LIBM_EXP") && atoi(getenv("DY_DECODE_LIBM_EXP")) != 0;
-  if (libm) hipLaunchKernelGGL(head_box_decode_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(head_box_decode_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, a);
+  if (libm) hipLaunchKernelGGL(head_box_decode_kernel<true>, dim3(gx, L.nl), dim3(256), 0, stream, L);
+  else hipLaunchKernelGGL(head_box_decode_kernel<false>, dim3(gx, L.nl), dim3(256), 0, stream, L);
   DY_CHECK_LAUNCH();
   return DY_OK;
+}
+extern "C" int dy_head_box_decode(const void* x, int ldx, const float* x_coef, const float* weight, const float* bias, float* pred_box, int A,
+                                  int a0, int n, int h, int w, int cin, int cout, hipStream_t stream) {
+  Levels<BoxDecArgs> L{};
+  L.nl = 1;
+  const int rc = box_decode_fill(L.lv[0], x, ldx, x_coef, weight, bias, pred_box, A, a0, n, h, w, cin, cout);
+  return rc != DY_OK ? rc : box_decode_launch(L, stream);
+}
+extern "C" int dy_head_box_decode_levels(int nl, const void* const* x, const int* ldx, const float* const* x_coef, const float* const* weight,
+                                         const float* const* bias, float* pred_box, int A, const int* a0, int n, const int* h, const int* w,
+                                         int cin, int cout, hipStream_t stream) {
+  if (nl < 1 || nl > 4) return DY_ERR_ARG;
+  Levels<BoxDecArgs> L{};
+  L.nl = nl;
+  for (int l = 0; l < nl; ++l) {
+    const int rc = box_decode_fill(L.lv[l], x[l], ldx[l], x_coef ? x_coef[l] : nullptr, weight[l], bias[l], pred_box, A, a0[l], n, h[l], w[l], cin, cout);
+    if (rc != DY_OK) return rc;
+  }
+  return box_decode_launch(L, stream);
 }
 
 extern "C" int dy_conv1x1_rows_supported(int cin, int cout) { return cin == 64 && cout == 64; }
@@ -291,24 +330,55 @@ extern "C" int dy_conv1x1_rows_slabs(int n, int h, int w) {
   const long ns = (long)n * h * w / 2048;  // measured per call at 160 / 80 / 40 (batch 64): 256 slabs 96 / 28 / 20 us, 1024 slabs 79 / 30 / 26 us
   return ns < 64 ? 64 : (ns > 1024 ? 1024 : (int)ns);
 }
-extern "C" int dy_conv1x1_rows_backward(const void* x, int ldx, const float* x_coef, const void* dy, int lddy, const int* assigned, int A, int a0,
-                                        const float* weight, void* dx, int lddx, int dx_accumulate, float* slabs, double* bias_acc,
-                                        int n, int h, int w, int cin, int cout, hipStream_t stream) {
+static int rows_fill(RowsArgs& a, const void* x, int ldx, const float* x_coef, const void* dy, int lddy, const int* assigned, int A, int a0,
+                     const float* weight, void* dx, int lddx, int dx_accumulate, float* slabs, double* bias_acc, int n, int h, int w, int cin,
+                     int cout) {
   if (!dy_conv1x1_rows_supported(cin, cout) || !x || !dy || !assigned || !weight || !slabs || !bias_acc || n < 1 || h < 1 || w < 1 ||
       a0 < 0 || a0 + h * w > A)
     return DY_ERR_ARG;
   if ((ldx & 7) || (lddy & 7) || (dx && (lddx & 7)) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) ||
       ((uintptr_t)slabs & 15))
     return DY_ERR_ALIGN;
-  RowsArgs a{(const f16*)x, (const f16*)dy, assigned, weight, (f16*)dx, slabs, bias_acc, ldx, lddy, lddx, A, a0, h * w, n, dx_accumulate, x_coef};
-  hipLaunchKernelGGL(rows_wgrad_kernel, dim3(dy_conv1x1_rows_slabs(n, h, w)), dim3(256), 0, stream, a);
-  if (dx) {
-    int gx = (h * w + 1023) / 1024;  // every workgroup copies the 16 KB weight into LDS first: give it >= 1024 pixels
-    if (gx > 16) gx = 16;
-    hipLaunchKernelGGL(rows_dgrad_kernel, dim3(gx, n), dim3(256), 0, stream, a);
+  int gx = (h * w + 1023) / 1024;  // every input-gradient workgroup copies the 16 KB weight into LDS first: give it >= 1024 pixels
+  if (gx > 16) gx = 16;
+  a = RowsArgs{(const f16*)x, (const f16*)dy, assigned, weight, (f16*)dx, slabs, bias_acc, ldx, lddy, lddx, A, a0, h * w, n, dx_accumulate, x_coef,
+               dy_conv1x1_rows_slabs(n, h, w), gx};
+  return DY_OK;
+}
+static int rows_launch(const Levels<RowsArgs>& L, hipStream_t stream) {
+  int gw = 1, gd = 0, nb = 1;
+  for (int l = 0; l < L.nl; ++l) {
+    gw = L.lv[l].nblk > gw ? L.lv[l].nblk : gw;
+    if (L.lv[l].dx) gd = L.lv[l].dgx > gd ? L.lv[l].dgx : gd;
+    nb = L.lv[l].B > nb ? L.lv[l].B : nb;
   }
+  hipLaunchKernelGGL(rows_wgrad_kernel, dim3(gw, L.nl), dim3(256), 0, stream, L);
+  if (gd) hipLaunchKernelGGL(rows_dgrad_kernel, dim3(gd, nb, L.nl), dim3(256), 0, stream, L);
   DY_CHECK_LAUNCH();
   return DY_OK;
+}
+extern "C" int dy_conv1x1_rows_backward(const void* x, int ldx, const float* x_coef, const void* dy, int lddy, const int* assigned, int A, int a0,
+                                        const float* weight, void* dx, int lddx, int dx_accumulate, float* slabs, double* bias_acc,
+                                        int n, int h, int w, int cin, int cout, hipStream_t stream) {
+  Levels<RowsArgs> L{};
+  L.nl = 1;
+  const int rc = rows_fill(L.lv[0], x, ldx, x_coef, dy, lddy, assigned, A, a0, weight, dx, lddx, dx_accumulate, slabs, bias_acc, n, h, w, cin, cout);
+  return rc != DY_OK ? rc : rows_launch(L, stream);
+}
+extern "C" int dy_conv1x1_rows_backward_levels(int nl, const void* const* x, const int* ldx, const float* const* x_coef, const void* const* dy,
+                                               const int* lddy, const int* assigned, int A, const int* a0, const float* const* weight,
+                                               void* const* dx, const int* lddx, const int* dx_accumulate, float* const* slabs,
+                                               double* const* bias_acc, int n, const int* h, const int* w, int cin, int cout,
+                                               hipStream_t stream) {
+  if (nl < 1 || nl > 4) return DY_ERR_ARG;
+  Levels<RowsArgs> L{};
+  L.nl = nl;
+  for (int l = 0; l < nl; ++l) {
+    const int rc = rows_fill(L.lv[l], x[l], ldx[l], x_coef ? x_coef[l] : nullptr, dy[l], lddy[l], assigned, A, a0[l], weight[l], dx[l], lddx[l],
+                             dx_accumulate[l], slabs[l], bias_acc[l], n, h[l], w[l], cin, cout);
+    if (rc != DY_OK) return rc;
+  }
+  return rows_launch(L, stream);
 }
 
 // ================================================================================================================================
@@ -331,9 +401,12 @@ struct ClsArgs {
   double* bias_acc;    // backward: [DY_BN_COPIES][8]
   int ldx, lddx, nc, dx_acc;
   long npix;
+  int nblk;
 };
 template <int CIN>
-__global__ __launch_bounds__(256) void cls_head_fwd_kernel(ClsArgs a) {
+__global__ __launch_bounds__(256) void cls_head_fwd_kernel(Levels<ClsArgs> L) {
+  const ClsArgs& a = L.lv[blockIdx.y];
+  if ((int)blockIdx.x >= a.nblk) return;
   constexpr int PARTS = CIN / 8, PPB = 256 / PARTS;
   __shared__ float s_w[8][CIN], s_b[8];
   for (int i = threadIdx.x; i < 8 * CIN; i += 256) s_w[i / CIN][i % CIN] = (i / CIN) < a.nc ? (float)(f16)a.w[i] : 0.f;
@@ -345,7 +418,7 @@ __global__ __launch_bounds__(256) void cls_head_fwd_kernel(ClsArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = a.xcoef[k0 + j]; sh[j] = a.xcoef[CIN + k0 + j]; }
   }
-  for (long pix = (long)blockIdx.x * PPB + threadIdx.x / PARTS; pix < a.npix; pix += (long)gridDim.x * PPB) {
+  for (long pix = (long)blockIdx.x * PPB + threadIdx.x / PARTS; pix < a.npix; pix += (long)a.nblk * PPB) {
     half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + k0);
     if (a.xcoef) xv = bn_silu_apply8(xv, sc, sh);
     float o[8];
@@ -366,7 +439,9 @@ __global__ __launch_bounds__(256) void cls_head_fwd_kernel(ClsArgs a) {
   }
 }
 template <int CIN>
-__global__ __launch_bounds__(256) void cls_head_bwd_kernel(ClsArgs a) {
+__global__ __launch_bounds__(256) void cls_head_bwd_kernel(Levels<ClsArgs> L) {
+  const ClsArgs& a = L.lv[blockIdx.y];
+  if ((int)blockIdx.x >= a.nblk) return;
   constexpr int PARTS = CIN / 8, PPB = 256 / PARTS;
   __shared__ float s_w[8][CIN];
   __shared__ float s_red[4][PARTS][64];
@@ -387,7 +462,7 @@ __global__ __launch_bounds__(256) void cls_head_bwd_kernel(ClsArgs a) {
     for (int j = 0; j < 8; ++j) acc[c][j] = 0.f;
   }
   // a workgroup owns a contiguous pixel range (its sums have one order whatever the grid)
-  const long chunk = ((a.npix + gridDim.x - 1) / gridDim.x + PPB - 1) / PPB * PPB;
+  const long chunk = ((a.npix + a.nblk - 1) / a.nblk + PPB - 1) / PPB * PPB;
   const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < a.npix ? lo + chunk : a.npix;
   for (long pix = lo + tid / PARTS; pix < hi; pix += PPB) {
     half8 xv = *reinterpret_cast<const half8*>(a.x + pix * a.ldx + k0);
@@ -464,26 +539,73 @@ __global__ __launch_bounds__(256) void cls_head_bwd_kernel(ClsArgs a) {
 }
 extern "C" int dy_cls_head_supported(int cin, int nc) { return (cin == 32 || cin == 64) && nc >= 1 && nc <= 8; }
 extern "C" int dy_cls_head_slabs(void) { return 512; }
-extern "C" int dy_cls_head_forward(const void* x, int ldx, const float* x_coef, const float* weight, const float* bias, float* logits,
-                                   long npix, int cin, int nc, hipStream_t stream) {
-  if (!dy_cls_head_supported(cin, nc) || !x || !weight || !bias || !logits || npix < 1) return DY_ERR_ARG;
-  if ((ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)logits & 15)) return DY_ERR_ALIGN;
-  ClsArgs a{(const f16*)x, x_coef, weight, bias, logits, nullptr, nullptr, nullptr, nullptr, ldx, 0, nc, 0, npix};
-  const int ppb = 256 / (cin / 8);
-  long blocks = (npix + ppb - 1) / ppb;
-  if (blocks > 4096) blocks = 4096;
-  if (cin == 32) hipLaunchKernelGGL(cls_head_fwd_kernel<32>, dim3((int)blocks), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(cls_head_fwd_kernel<64>, dim3((int)blocks), dim3(256), 0, stream, a);
+static int cls_fill(ClsArgs& a, bool backward, const void* x, int ldx, const float* x_coef, const float* weight, const float* bias, float* logits,
+                    const void* dy, void* dx, int lddx, int dx_accumulate, float* slabs, double* bias_acc, long npix, int cin, int nc) {
+  if (!dy_cls_head_supported(cin, nc) || !x || !weight || npix < 1) return DY_ERR_ARG;
+  if (!backward && (!bias || !logits)) return DY_ERR_ARG;
+  if (backward && (!dy || !slabs || !bias_acc)) return DY_ERR_ARG;
+  if ((ldx & 7) || (dx && (lddx & 7)) || ((uintptr_t)x & 15) || ((uintptr_t)logits & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15))
+    return DY_ERR_ALIGN;
+  int nblk;
+  if (backward) {
+    nblk = dy_cls_head_slabs();
+  } else {
+    const int ppb = 256 / (cin / 8);
+    long blocks = (npix + ppb - 1) / ppb;
+    nblk = (int)(blocks > 4096 ? 4096 : blocks);
+  }
+  a = ClsArgs{(const f16*)x, x_coef, weight, bias, logits, (const f16*)dy, (f16*)dx, slabs, bias_acc, ldx, lddx, nc, dx_accumulate, npix, nblk};
+  return DY_OK;
+}
+static int cls_launch(const Levels<ClsArgs>& L, bool backward, int cin, hipStream_t stream) {
+  int gx = 1;
+  for (int l = 0; l < L.nl; ++l) gx = L.lv[l].nblk > gx ? L.lv[l].nblk : gx;
+  const dim3 grid(gx, L.nl);
+  if (!backward && cin == 32) hipLaunchKernelGGL(cls_head_fwd_kernel<32>, grid, dim3(256), 0, stream, L);
+  else if (!backward) hipLaunchKernelGGL(cls_head_fwd_kernel<64>, grid, dim3(256), 0, stream, L);
+  else if (cin == 32) hipLaunchKernelGGL(cls_head_bwd_kernel<32>, grid, dim3(256), 0, stream, L);
+  else hipLaunchKernelGGL(cls_head_bwd_kernel<64>, grid, dim3(256), 0, stream, L);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }
+extern "C" int dy_cls_head_forward(const void* x, int ldx, const float* x_coef, const float* weight, const float* bias, float* logits,
+                                   long npix, int cin, int nc, hipStream_t stream) {
+  Levels<ClsArgs> L{};
+  L.nl = 1;
+  const int rc = cls_fill(L.lv[0], false, x, ldx, x_coef, weight, bias, logits, nullptr, nullptr, 0, 0, nullptr, nullptr, npix, cin, nc);
+  return rc != DY_OK ? rc : cls_launch(L, false, cin, stream);
+}
 extern "C" int dy_cls_head_backward(const void* x, int ldx, const float* x_coef, const void* dy, const float* weight, void* dx, int lddx,
                                     int dx_accumulate, float* slabs, double* bias_acc, long npix, int cin, int nc, hipStream_t stream) {
-  if (!dy_cls_head_supported(cin, nc) || !x || !dy || !weight || !slabs || !bias_acc || npix < 1) return DY_ERR_ARG;
-  if ((ldx & 7) || (dx && (lddx & 7)) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return DY_ERR_ALIGN;
-  ClsArgs a{(const f16*)x, x_coef, weight, nullptr, nullptr, (const f16*)dy, (f16*)dx, slabs, bias_acc, ldx, lddx, nc, dx_accumulate, npix};
-  if (cin == 32) hipLaunchKernelGGL(cls_head_bwd_kernel<32>, dim3(dy_cls_head_slabs()), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(cls_head_bwd_kernel<64>, dim3(dy_cls_head_slabs()), dim3(256), 0, stream, a);
-  DY_CHECK_LAUNCH();
-  return DY_OK;
+  Levels<ClsArgs> L{};
+  L.nl = 1;
+  const int rc = cls_fill(L.lv[0], true, x, ldx, x_coef, weight, nullptr, nullptr, dy, dx, lddx, dx_accumulate, slabs, bias_acc, npix, cin, nc);
+  return rc != DY_OK ? rc : cls_launch(L, true, cin, stream);
+}
+extern "C" int dy_cls_head_forward_levels(int nl, const void* const* x, const int* ldx, const float* const* x_coef, const float* const* weight,
+                                          const float* const* bias, float* const* logits, const long* npix, int cin, int nc,
+                                          hipStream_t stream) {
+  if (nl < 1 || nl > 4) return DY_ERR_ARG;
+  Levels<ClsArgs> L{};
+  L.nl = nl;
+  for (int l = 0; l < nl; ++l) {
+    const int rc = cls_fill(L.lv[l], false, x[l], ldx[l], x_coef ? x_coef[l] : nullptr, weight[l], bias[l], logits[l], nullptr, nullptr, 0, 0, nullptr,
+                            nullptr, npix[l], cin, nc);
+    if (rc != DY_OK) return rc;
+  }
+  return cls_launch(L, false, cin, stream);
+}
+extern "C" int dy_cls_head_backward_levels(int nl, const void* const* x, const int* ldx, const float* const* x_coef, const void* const* dy,
+                                           const float* const* weight, void* const* dx, const int* lddx, const int* dx_accumulate,
+                                           float* const* slabs, double* const* bias_acc, const long* npix, int cin, int nc,
+                                           hipStream_t stream) {
+  if (nl < 1 || nl > 4) return DY_ERR_ARG;
+  Levels<ClsArgs> L{};
+  L.nl = nl;
+  for (int l = 0; l < nl; ++l) {
+    const int rc = cls_fill(L.lv[l], true, x[l], ldx[l], x_coef ? x_coef[l] : nullptr, weight[l], nullptr, nullptr, dy[l], dx[l], lddx[l],
+                            dx_accumulate[l], slabs[l], bias_acc[l], npix[l], cin, nc);
+    if (rc != DY_OK) return rc;
+  }
+  return cls_launch(L, true, cin, stream);
 }

@@ -118,6 +118,10 @@ SIGNATURES = {
     "dy_cls_head_slabs": (i32, []),
     "dy_cls_head_forward": (i32, [vp, i32, vp, vp, vp, vp, i64, i32, i32, vp]),
     "dy_cls_head_backward": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, i64, i32, i32, vp]),
+    "dy_head_box_decode_levels": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, vp]),
+    "dy_conv1x1_rows_backward_levels": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp]),
+    "dy_cls_head_forward_levels": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "dy_cls_head_backward_levels": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "dy_conv1x1_rows_supported": (i32, [i32, i32]),
     "dy_conv1x1_rows_slabs": (i32, [i32, i32, i32]),
     "dy_conv1x1_rows_backward": (i32, [vp, i32, vp, vp, i32, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -77,6 +77,8 @@ HEAD_DECODE = HEAD_ROWS and os.environ.get("DY_HEAD_DECODE", "1") != "0"
 # Detect's final class conv (nc <= 8) as stand-alone element-wise kernels, forward and one-walk backward (csrc/head_rows.hip,
 # dy_cls_head_*), inside a StepPlan trace; with HEAD_APPLY the Conv in front leaves its apply out here too.  DY_HEAD_CLS=0: generic conv.
 HEAD_CLS = BIAS_WGRAD and os.environ.get("DY_HEAD_CLS", "1") != "0"
+# The head kernels of all detection levels in one launch per kind (dy_*_levels): the small levels run beside the large one.
+HEAD_BATCH = os.environ.get("DY_HEAD_BATCH", "1") != "0"
 HEAD_APPLY = HEAD_DECODE and os.environ.get("DY_SILU_FAST", "1") != "0" and os.environ.get("DY_HEAD_APPLY", "1") != "0"
 BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
 BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
@@ -833,6 +835,85 @@ class Engine:
             acc = x.grad_target() if x.needs_grad else 0
             self.call("dy_cls_head_backward", xp, xld, xcoef, dyp, spec.weight.data_ptr(), x.gptr if x.needs_grad else 0, x.ld, acc,
                       slabs.data_ptr(), self._acc_ready(spec.acc_bias), x.npix, spec.cin, spec.cout)
+        self.tape.append(bwd)
+
+    @staticmethod
+    def _arr(ctype, vals):
+        return (ctype * len(vals))(*vals)
+
+    def _src(self, x):
+        """(pointer, ld, coefficient-table pointer or 0) a head kernel reads ``x`` through: its RAW twin when the apply was left out."""
+        src = self.unapplied(x)
+        return (x.ptr, x.ld, 0) if src is None else (src[0].ptr, src[0].ld, src[1].coef.data_ptr())
+
+    def head_box_levels(self, items, dy_ptr_fns):
+        """``conv_bias_decode`` for every detection level at once (items = [(spec, x, level)], all levels): the plan launches ONE
+        dy_head_box_decode_levels, the backward is ONE dy_conv1x1_rows_backward_levels -- registered after every level's forward, so it
+        runs first in the backward pass (it needs the loss's gradients only)."""
+        for spec, x, l in items:
+            self._use(x)
+            self.rows_used.add(l)
+            self.pending_decode.append((spec, x, l))
+        self.tape.append(lambda: self._rows_bwd_levels(items, dy_ptr_fns))
+
+    def _rows_bwd_levels(self, items, fns):
+        if not (self.loss_rows is not None and self.deferred_wgrad is not None and not self.side_wgrad):
+            for (spec, x, l), fn in zip(items, fns):
+                self._conv_bias_bwd(spec, x, fn, rows_level=l)
+            return
+        asg, A, a0 = self.loss_rows
+        cols = {k: [] for k in ("x", "ldx", "xc", "dy", "lddy", "a0", "w", "dx", "lddx", "acc", "slabs", "bacc", "h", "w_")}
+        for (spec, x, l), fn in zip(items, fns):
+            dyp, ld = fn()
+            Ho, Wo = self.out_hw(spec, x)
+            ns = self.L.dy_conv1x1_rows_slabs(x.N, Ho, Wo)
+            slabs = self.transient((ns * spec.cout * spec.cin,), torch.float32)
+            self.hold(slabs)
+            self.deferred_wgrad.append((spec, slabs, ns, spec.acc_bias))
+            acc = x.grad_target() if x.needs_grad else 0
+            if x.needs_grad and not acc and self._sole_consumer_of_conv(x) is not None:
+                self._rows_grad[(id(x.st), x.c0, x.C)] = (asg, A, a0[l])
+            xp, xld, xc = self._src(x)
+            for k, v in zip(cols, (xp, xld, xc, dyp, ld, a0[l], spec.weight.data_ptr(), x.gptr if x.needs_grad else 0, x.ld, acc,
+                                   slabs.data_ptr(), self._acc_ready(spec.acc_bias), Ho, Wo)):
+                cols[k].append(v)
+        P, I = C.c_void_p, C.c_int
+        spec0, x0 = items[0][0], items[0][1]
+        self.call("dy_conv1x1_rows_backward_levels", len(items), self._arr(P, cols["x"]), self._arr(I, cols["ldx"]), self._arr(P, cols["xc"]),
+                  self._arr(P, cols["dy"]), self._arr(I, cols["lddy"]), asg, A, self._arr(I, cols["a0"]), self._arr(P, cols["w"]),
+                  self._arr(P, cols["dx"]), self._arr(I, cols["lddx"]), self._arr(I, cols["acc"]), self._arr(P, cols["slabs"]),
+                  self._arr(P, cols["bacc"]), x0.N, self._arr(I, cols["h"]), self._arr(I, cols["w_"]), spec0.cin, spec0.cout)
+
+    def head_cls_levels(self, items):
+        """``conv_bias_cls`` for several levels at once (items = [(spec, x, y_ptr, dy_ptr_fn)], same cin / nc): one forward launch now,
+        one backward launch first thing in the backward pass."""
+        P, I, Lg = C.c_void_p, C.c_int, C.c_long
+        srcs = [self._src(x) for _, x, _, _ in items]
+        for _, x, _, _ in items:
+            self._use(x)
+        spec0 = items[0][0]
+        self.call("dy_cls_head_forward_levels", len(items), self._arr(P, [s_[0] for s_ in srcs]), self._arr(I, [s_[1] for s_ in srcs]),
+                  self._arr(P, [s_[2] for s_ in srcs]), self._arr(P, [sp.weight.data_ptr() for sp, _, _, _ in items]),
+                  self._arr(P, [sp.bias.data_ptr() for sp, _, _, _ in items]), self._arr(P, [yp for _, _, yp, _ in items]),
+                  self._arr(Lg, [x.npix for _, x, _, _ in items]), spec0.cin, spec0.cout)
+
+        def bwd():
+            assert self.deferred_wgrad is not None and not self.side_wgrad
+            dys, dxs, accs, slabs_l, baccs = [], [], [], [], []
+            ns = self.L.dy_cls_head_slabs()
+            for spec, x, _, fn in items:
+                dyp, ld = fn()
+                assert ld == 8
+                slabs = self.transient((ns * 16 * spec.cin,), torch.float32)
+                self.hold(slabs)
+                self.deferred_wgrad.append((spec, slabs, ns, spec.acc_bias))
+                accs.append(x.grad_target() if x.needs_grad else 0)
+                dys.append(dyp); dxs.append(x.gptr if x.needs_grad else 0); slabs_l.append(slabs.data_ptr())
+                baccs.append(self._acc_ready(spec.acc_bias))
+            self.call("dy_cls_head_backward_levels", len(items), self._arr(P, [s_[0] for s_ in srcs]), self._arr(I, [s_[1] for s_ in srcs]),
+                      self._arr(P, [s_[2] for s_ in srcs]), self._arr(P, dys), self._arr(P, [sp.weight.data_ptr() for sp, _, _, _ in items]),
+                      self._arr(P, dxs), self._arr(I, [x.ld for _, x, _, _ in items]), self._arr(I, accs), self._arr(P, slabs_l),
+                      self._arr(P, baccs), self._arr(Lg, [x.npix for _, x, _, _ in items]), spec0.cin, spec0.cout)
         self.tape.append(bwd)
 
     def unapplied(self, x):

@@ -144,13 +144,23 @@ class StepPlan:
                 asg, A, a0 = eng.loss_rows
                 a = crit._args
                 a.box_from_input = 1
+                from .engine import HEAD_BATCH
+                P, I = C.c_void_p, C.c_int
+                rows_ = []
                 for spec, xin, l in eng.pending_decode:
-                    src = eng.unapplied(xin)  # the Conv in front left its apply out: (raw, its spec)
-                    xp, xld, xcoef = (xin.ptr, xin.ld, 0) if src is None else (src[0].ptr, src[0].ld, src[1].coef.data_ptr())
-                    eng.call("dy_head_box_decode", xp, xld, xcoef, spec.weight.data_ptr(), spec.bias.data_ptr(), crit.pred_box_ptr(), A, a0[l],
-                             xin.N, xin.H, xin.W, spec.cin, spec.cout)
+                    xp, xld, xcoef = eng._src(xin)  # the Conv in front may have left its apply out: (raw, ld, coefficient table)
+                    rows_.append((xp, xld, xcoef, spec.weight.data_ptr(), spec.bias.data_ptr(), a0[l], xin.H, xin.W))
                     a.box_in[l], a.box_in_ld[l], a.box_in_coef[l] = xp, xld, xcoef
                     a.box_w[l], a.box_b[l] = spec.weight.data_ptr(), spec.bias.data_ptr()
+                spec0, x0 = eng.pending_decode[0][0], eng.pending_decode[0][1]
+                if HEAD_BATCH:
+                    cols = list(zip(*rows_))
+                    eng.call("dy_head_box_decode_levels", len(rows_), eng._arr(P, cols[0]), eng._arr(I, cols[1]), eng._arr(P, cols[2]),
+                             eng._arr(P, cols[3]), eng._arr(P, cols[4]), crit.pred_box_ptr(), A, eng._arr(I, cols[5]), x0.N,
+                             eng._arr(I, cols[6]), eng._arr(I, cols[7]), spec0.cin, spec0.cout)
+                else:
+                    for xp, xld, xcoef, wp, bp, a0l, h_, w_ in rows_:
+                        eng.call("dy_head_box_decode", xp, xld, xcoef, wp, bp, crit.pred_box_ptr(), A, a0l, x0.N, h_, w_, spec0.cin, spec0.cout)
             eng.call("dy_detection_loss", C.byref(crit._args))
             self.fb_split = len(eng.rec.ops)  # [0, fb_split) = forward + loss, the rest = backward (forward_only / backward_accumulate)
             eng.deferred_wgrad = []

@@ -110,23 +110,37 @@ class Detect(HipModule):
         # inside a StepPlan trace, when every level's box conv qualifies: forward fused with the loss's decode, backward from rows
         fused = HEAD_DECODE and eng.pending_decode is not None and all(eng.rows_capable(rt.specs[(id(self), "cv2", l)]) for l in range(len(xs)))
         lazy = []
+        from ...hip.engine import HEAD_BATCH
+        cspecs = [rt.specs[(id(self), "cv3", l)] for l in range(len(xs))]
+        cls_all = HEAD_BATCH and all(eng.cls_capable(sp, ncp) for sp in cspecs) and len({(sp.cin, sp.cout) for sp in cspecs}) == 1
+        box_items, box_fns, cls_items = [], [], []
         for l, x in enumerate(xs):
             # fused: ``a`` is read by dy_head_box_decode, the rows backward and the loss only -- all of which apply BatchNorm + SiLU
             # themselves, so the Conv in front leaves its apply launch out
             a = self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(x), defer_apply=fused and HEAD_APPLY)
-            cspec = rt.specs[(id(self), "cv3", l)]
+            cspec = cspecs[l]
             cls_fused = eng.cls_capable(cspec, ncp)
             c = self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(x), defer_apply=cls_fused and HEAD_APPLY)
             if fused:
-                eng.conv_bias_decode(rt.specs[(id(self), "cv2", l)], a, lambda l=l: (ho.dbox[l].data_ptr(), nb), l)
+                if HEAD_BATCH:  # all levels in one launch per kind, issued after the loop
+                    box_items.append((rt.specs[(id(self), "cv2", l)], a, l))
+                    box_fns.append(lambda l=l: (ho.dbox[l].data_ptr(), nb))
+                else:
+                    eng.conv_bias_decode(rt.specs[(id(self), "cv2", l)], a, lambda l=l: (ho.dbox[l].data_ptr(), nb), l)
                 lazy.append((rt.specs[(id(self), "cv2", l)], a, boxes[l], eng.unapplied(a)))
             else:
                 eng.conv_bias(rt.specs[(id(self), "cv2", l)], a, boxes[l].data_ptr(), nb, True,
                               lambda l=l: (ho.dbox[l].data_ptr(), nb), rows_level=l)
-            if cls_fused:
+            if cls_all:
+                cls_items.append((cspec, c, clss[l].data_ptr(), lambda l=l: (ho.dcls[l].data_ptr(), ncp)))
+            elif cls_fused:
                 eng.conv_bias_cls(cspec, c, clss[l].data_ptr(), lambda l=l: (ho.dcls[l].data_ptr(), ncp))
             else:
                 eng.conv_bias(cspec, c, clss[l].data_ptr(), ncp, True, lambda l=l: (ho.dcls[l].data_ptr(), ncp))
+        if cls_items:
+            eng.head_cls_levels(cls_items)
+        if box_items:
+            eng.head_box_levels(box_items, box_fns)
         if lazy:
             from ...hip import DY_EPI_BIAS, DY_EPI_F32OUT
 

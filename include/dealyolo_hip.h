@@ -312,6 +312,20 @@ int dy_cls_head_forward(const void* x, int ldx, const float* x_coef, const float
                         int cin, int nc, hipStream_t stream);
 int dy_cls_head_backward(const void* x, int ldx, const float* x_coef, const void* dy, const float* weight, void* dx, int lddx,
                          int dx_accumulate, float* slabs, double* bias_acc, long npix, int cin, int nc, hipStream_t stream);
+/* The four head entries for SEVERAL detection levels in one launch each (nl <= 4; array arguments have nl entries; the same kernels,
+ * blockIdx picks the level): the small levels' latency-bound workgroups run beside the large level's instead of after it. */
+int dy_head_box_decode_levels(int nl, const void* const* x, const int* ldx, const float* const* x_coef, const float* const* weight,
+                              const float* const* bias, float* pred_box, int A, const int* a0, int n, const int* h, const int* w, int cin,
+                              int cout, hipStream_t stream);
+int dy_conv1x1_rows_backward_levels(int nl, const void* const* x, const int* ldx, const float* const* x_coef, const void* const* dy,
+                                    const int* lddy, const int* assigned, int A, const int* a0, const float* const* weight, void* const* dx,
+                                    const int* lddx, const int* dx_accumulate, float* const* slabs, double* const* bias_acc, int n,
+                                    const int* h, const int* w, int cin, int cout, hipStream_t stream);
+int dy_cls_head_forward_levels(int nl, const void* const* x, const int* ldx, const float* const* x_coef, const float* const* weight,
+                               const float* const* bias, float* const* logits, const long* npix, int cin, int nc, hipStream_t stream);
+int dy_cls_head_backward_levels(int nl, const void* const* x, const int* ldx, const float* const* x_coef, const void* const* dy,
+                                const float* const* weight, void* const* dx, const int* lddx, const int* dx_accumulate, float* const* slabs,
+                                double* const* bias_acc, const long* npix, int cin, int nc, hipStream_t stream);
 int dy_conv1x1_rows_supported(int cin, int cout);
 int dy_conv1x1_rows_slabs(int n, int h, int w);
 int dy_conv1x1_rows_backward(const void* x, int ldx, const float* x_coef, const void* dy, int lddy, const int* assigned, int A, int a0,
