@@ -143,8 +143,10 @@ struct BnAccFwd {
   float count, eps, momentum;
 };
 
+// (bx, nb) = this workgroup's index and the workgroup count of ITS tensor: blockIdx.x / gridDim.x for a launch of one tensor, the entry's
+// own count in a group launch (bn_act_apply_group_kernel)
 template <int ACT, bool ACC, bool FAST = false>
-__global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a, BnAccFwd b) {
+static __device__ __forceinline__ void bn_act_apply_body(const ApplyArgs& a, const BnAccFwd& b, const int bx, const int nb) {
   // a thread owns one 8-channel granule for the whole launch: scale/shift live in registers
   const int cpp = a.C >> 3, rows = 256 / cpp;
   const int part = threadIdx.x % cpp, row = threadIdx.x / cpp, c0 = part * 8;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a, BnAccFwd
       const float scl = b.gamma[c] * invstd, shf = b.beta[c] - (float)mean * scl;
       s_coef[c] = scl;
       s_coef[a.C + c] = shf;
-      if (blockIdx.x == 0) {
+      if (bx == 0) {
         b.coef_out[c] = scl;
         b.coef_out[a.C + c] = shf;
         b.coef_out[2 * a.C + c] = (float)mean;
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a, BnAccFwd
     }
     *reinterpret_cast<half8*>(a.y + pix * a.ldy + c0) = out;
   };
-  const long step = (long)gridDim.x * rows;
-  long pix = (long)blockIdx.x * rows + row;
+  const long step = (long)nb * rows;
+  long pix = (long)bx * rows + row;
   for (; pix + step < a.npix; pix += 2 * step) {  // two pixels per trip: both loads issue before the first use
     const half8 x0 = *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0);
     const half8 x1 = *reinterpret_cast<const half8*>(a.x + at(pix + step) * a.ldx + c0);
@@ -218,6 +220,26 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a, BnAccFwd
     one(pix + step, x1);
   }
   if (pix < a.npix) one(pix, *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0));
+}
+
+template <int ACT, bool ACC, bool FAST = false>
+__global__ __launch_bounds__(256) void bn_act_apply_kernel(ApplyArgs a, BnAccFwd b) {
+  bn_act_apply_body<ACT, ACC, FAST>(a, b, (int)blockIdx.x, (int)gridDim.x);
+}
+// Several tensors in ONE launch (blockIdx.y = entry): independent Convs of one stage -- the first convs of Detect's six branches, the
+// zero-pixel coefficient launches of the six second convs -- whose apply passes would otherwise queue behind each other although the
+// small ones cannot fill the chip.
+#define DY_BN_GROUP_MAX 8
+struct ApplyGroup {
+  int n;
+  int nblk[DY_BN_GROUP_MAX];
+  ApplyArgs a[DY_BN_GROUP_MAX];
+  BnAccFwd b[DY_BN_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void bn_act_apply_group_kernel(ApplyGroup g) {
+  const int e = blockIdx.y;
+  if ((int)blockIdx.x >= g.nblk[e]) return;
+  bn_act_apply_body<DY_ACT_SILU, true, true>(g.a[e], g.b[e], (int)blockIdx.x, g.nblk[e]);
 }
 
 // Which passes walk their pixels from the far end (bit 0 forward apply, bit 1 the stand-alone backward apply, bit 2 backward reduce).
@@ -295,6 +317,31 @@ extern "C" int dy_bn_act_apply_acc(const void* x, int ldx, const void* res, int 
   return DY_OK;
 }
 
+extern "C" int dy_bn_group_max(void) { return DY_BN_GROUP_MAX; }
+// dy_bn_act_apply_acc (SiLU, no residual) for n <= dy_bn_group_max() tensors in one launch; array arguments have n entries
+extern "C" int dy_bn_act_apply_acc_group(int n, const void* const* x, const int* ldx, void* const* y, const int* ldy, const double* const* acc,
+                                         const float* const* gamma, const float* const* beta, float* const* running_mean,
+                                         float* const* running_var, float* const* coef, const long* npix, const int* C, const float* count,
+                                         const float* eps, const float* momentum, hipStream_t stream) {
+  if (n < 1 || n > DY_BN_GROUP_MAX) return DY_ERR_ARG;
+  ApplyGroup g{};
+  g.n = n;
+  int gx = 1, cmax = 0;
+  const int rev = ew_reverse();
+  for (int e = 0; e < n; ++e) {
+    if ((C[e] & 7) || (ldx[e] & 7) || (ldy[e] & 7)) return DY_ERR_ALIGN;
+    if ((C[e] >> 3) > 256 || !acc[e] || !gamma[e] || !beta[e] || !running_mean[e] || !running_var[e] || !coef[e]) return DY_ERR_ARG;
+    g.a[e] = ApplyArgs{(const f16*)x[e], nullptr, (f16*)y[e], nullptr, ldx[e], 0, ldy[e], C[e], DY_ACT_SILU, npix[e], rev & 1};
+    g.b[e] = BnAccFwd{acc[e], gamma[e], beta[e], running_mean[e], running_var[e], coef[e], count[e], eps[e], momentum[e]};
+    g.nblk[e] = ew_blocks(npix[e], C[e], "DY_EW_BLOCKS_APPLY_ACC", 8192);
+    gx = g.nblk[e] > gx ? g.nblk[e] : gx;
+    cmax = C[e] > cmax ? C[e] : cmax;
+  }
+  hipLaunchKernelGGL(bn_act_apply_group_kernel, dim3(gx, n), dim3(256), 2 * (size_t)cmax * sizeof(float), stream, g);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- backward
 // pass 1: per-channel partial sums of g = dy * act'(z) and g * xhat
 struct BwdRedArgs {
@@ -311,7 +358,7 @@ struct BwdRedArgs {
 };
 
 template <int ACT, bool RES = false>
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
+static __device__ __forceinline__ void bn_act_bwd_reduce_body(const BwdRedArgs& a, const int bx, const int nb) {
   const int cpp = a.C >> 3, rows = 256 / cpp, tid = threadIdx.x;
   const int part = tid % cpp, row = tid / cpp, c0 = part * 8;
   // The loop accumulates sum(g) and sum(g * x) on the RAW values; sum(g * xhat) = invstd * (sum(g * x) - mean * sum(g)) is formed
@@ -326,8 +373,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
   }
   if (row < rows) {
     // two pixels per trip: four 16-byte loads in flight per lane before the first use
-    const long step = (long)gridDim.x * rows;
-    long pix = (long)blockIdx.x * rows + row;
+    const long step = (long)nb * rows;
+    long pix = (long)bx * rows + row;
     auto at = [&](long p) { return a.rev ? a.npix - 1 - p : p; };
     auto pair = [](const half8& v, int j) { return (f32x2){(float)v[2 * j], (float)v[2 * j + 1]}; };
     // the shortcut's gradient is dy itself: written (first writer) or added (fan-in) here instead of by a launch of its own
@@ -388,9 +435,24 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
     const int which = i / a.C, c = i - which * a.C, pp = c >> 3, j = c & 7;
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += red[which][r * cpp + pp][j];
-    if (a.acc) unsafeAtomicAdd(&a.acc[((size_t)(blockIdx.x % DY_BN_COPIES) * 2 + which) * a.C + c], (double)s);
-    else a.partials[((size_t)blockIdx.x * 2 + which) * a.C + c] = s;
+    if (a.acc) unsafeAtomicAdd(&a.acc[((size_t)(bx % DY_BN_COPIES) * 2 + which) * a.C + c], (double)s);
+    else a.partials[((size_t)bx * 2 + which) * a.C + c] = s;
   }
+}
+
+template <int ACT, bool RES = false>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BwdRedArgs a) {
+  bn_act_bwd_reduce_body<ACT, RES>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+struct BwdRedGroup {  // several tensors in one launch (blockIdx.y = entry), as ApplyGroup
+  int n;
+  int nblk[DY_BN_GROUP_MAX];
+  BwdRedArgs a[DY_BN_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_group_kernel(BwdRedGroup g) {
+  const int e = blockIdx.y;
+  if ((int)blockIdx.x >= g.nblk[e]) return;
+  bn_act_bwd_reduce_body<DY_ACT_SILU, false>(g.a[e], (int)blockIdx.x, g.nblk[e]);
 }
 
 extern "C" int dy_bn_act_bwd_reduce(const void* dy, int lddy, const void* x, int ldx, const float* coef,
@@ -431,6 +493,33 @@ extern "C" int dy_bn_act_bwd_reduce_acc(const void* dy, int lddy, const void* x,
   else if (res_grad && act == DY_ACT_LEAKY) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DY_ACT_LEAKY, true>), dim3((int)blocks), dim3(256), 0, stream, a);
   else if (res_grad) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DY_ACT_NONE, true>), dim3((int)blocks), dim3(256), 0, stream, a);
   else DY_ACT_DISPATCH(bn_act_bwd_reduce_kernel, dim3((int)blocks), stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// dy_bn_act_bwd_reduce_acc (SiLU, no shortcut gradient) for n <= dy_bn_group_max() tensors in one launch
+extern "C" int dy_bn_act_bwd_reduce_acc_group(int n, const void* const* dy, const int* lddy, const void* const* x, const int* ldx,
+                                              const float* const* coef, double* const* acc, const long* npix, const int* C, hipStream_t stream) {
+  if (n < 1 || n > DY_BN_GROUP_MAX) return DY_ERR_ARG;
+  BwdRedGroup g{};
+  g.n = n;
+  int gx = 1;
+  const int rev = ew_reverse();
+  static const long bcap = getenv("DY_EW_BLOCKS_BRED") ? atol(getenv("DY_EW_BLOCKS_BRED")) : 1024;
+  for (int e = 0; e < n; ++e) {
+    if ((C[e] & 7) || C[e] > 2048 || (ldx[e] & 7) || (lddy[e] & 7)) return DY_ERR_ALIGN;
+    const int cpp = C[e] >> 3;
+    if (cpp > 256 || !acc[e] || !dy[e] || !x[e] || !coef[e]) return DY_ERR_ARG;
+    const int rows = 256 / cpp;
+    long blocks = (npix[e] + (long)rows * 8 - 1) / ((long)rows * 8);
+    if (blocks > bcap) blocks = bcap;
+    if (blocks < 1) blocks = 1;
+    g.a[e] = BwdRedArgs{(const f16*)dy[e], (const f16*)x[e], coef[e], nullptr, lddy[e], ldx[e], C[e], DY_ACT_SILU, npix[e], (rev >> 2) & 1, acc[e],
+                        nullptr, 0, 0};
+    g.nblk[e] = (int)blocks;
+    gx = g.nblk[e] > gx ? g.nblk[e] : gx;
+  }
+  hipLaunchKernelGGL(bn_act_bwd_reduce_group_kernel, dim3(gx, n), dim3(256), 0, stream, g);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

@@ -112,6 +112,9 @@ SIGNATURES = {
     "dy_upsample2x": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_maxpool5": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "dy_maxpool5_backward": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_bn_group_max": (i32, []),
+    "dy_bn_act_apply_acc_group": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dy_bn_act_bwd_reduce_acc_group": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dy_bn_act_bwd_reduce_rows": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "dy_head_box_decode": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_cls_head_supported": (i32, [i32, i32]),

@@ -79,6 +79,9 @@ HEAD_DECODE = HEAD_ROWS and os.environ.get("DY_HEAD_DECODE", "1") != "0"
 HEAD_CLS = BIAS_WGRAD and os.environ.get("DY_HEAD_CLS", "1") != "0"
 # The head kernels of all detection levels in one launch per kind (dy_*_levels): the small levels run beside the large one.
 HEAD_BATCH = os.environ.get("DY_HEAD_BATCH", "1") != "0"
+# Independent Convs of one stage (Detect's six first convs, its six second convs) as a GROUP: their conv launches stay, their BatchNorm
+# apply passes are one launch and so are their backward reduces (Engine.conv_bn_act_group, dy_bn_act_*_group).
+BN_GROUP = BN_ACC and os.environ.get("DY_BN_GROUP", "1") != "0"
 HEAD_APPLY = HEAD_DECODE and os.environ.get("DY_SILU_FAST", "1") != "0" and os.environ.get("DY_HEAD_APPLY", "1") != "0"
 BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
 BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
@@ -641,7 +644,68 @@ class Engine:
             self.tape.append(bwd)
         return y
 
-    def _conv_bn_act_bwd(self, spec, x, raw, y, res):
+    def conv_bn_act_group(self, members, defer=None):
+        """``conv_bn_act`` for independent Convs of one stage: members = [(spec, x)] (training, accumulator path, SiLU, no residual, own
+        outputs); ``defer[i]``: member i leaves its apply out (``defer_apply``).  The conv launches are issued one after the other, then
+        ONE dy_bn_act_apply_acc_group; the backward is ONE closure: the dense backward reduces of the members in one launch (a member whose
+        gradient has rows keeps its own rows reduce), then each member's weight / input gradient."""
+        defer = list(defer) if defer is not None else [False] * len(members)
+        ok = (BN_GROUP and self.training and self.tape is not None and 1 < len(members) <= self.L.dy_bn_group_max()
+              and all(sp.acc_f is not None and sp.acc_b is not None and sp.act == DY_ACT_SILU and sp.ld is None and not isinstance(x, ImageAct)
+                      for sp, x in members))
+        if not ok:
+            return [self.conv_bn_act(sp, x, defer_apply=d) for (sp, x), d in zip(members, defer)]
+        outs = []
+        for (spec, x), d in zip(members, defer):
+            assert x.C == spec.cin_phys, (spec.name, x.C, spec.cin_phys)
+            Ho, Wo = self.out_hw(spec, x)
+            raw = self.new_act(x.N, Ho, Wo, spec.cout)
+            y = self.new_act(x.N, Ho, Wo, spec.cout)
+            self._use(x)
+            self._prod[(id(y.st), y.c0, y.C)] = (spec, raw)
+            self._conv_raw(spec, x, raw.ptr, raw.ld, DY_EPI_STATS | DY_EPI_STATS_ACC, self._acc_ready(spec.acc_f))
+            outs.append((spec, x, raw, y, bool(d)))
+        P, I, Lg, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+        bn = [sp.bn for sp, *_ in outs]
+        npx = [y.npix for _, _, _, y, _ in outs]
+        self.call("dy_bn_act_apply_acc_group", len(outs), self._arr(P, [raw.ptr for _, _, raw, _, _ in outs]), self._arr(I, [raw.ld for _, _, raw, _, _ in outs]),
+                  self._arr(P, [y.ptr for _, _, _, y, _ in outs]), self._arr(I, [y.ld for _, _, _, y, _ in outs]),
+                  self._arr(P, [sp.acc_f.data_ptr() for sp, *_ in outs]), self._arr(P, [b["weight"].data_ptr() for b in bn]),
+                  self._arr(P, [b["bias"].data_ptr() for b in bn]), self._arr(P, [b["running_mean"].data_ptr() for b in bn]),
+                  self._arr(P, [b["running_var"].data_ptr() for b in bn]), self._arr(P, [sp.coef.data_ptr() for sp, *_ in outs]),
+                  self._arr(Lg, [0 if d else n for n, (*_, d) in zip(npx, outs)]), self._arr(I, [sp.cout for sp, *_ in outs]),
+                  self._arr(F, [float(n) for n in npx]), self._arr(F, [sp.bn_eps for sp, *_ in outs]), self._arr(F, [sp.bn_mom for sp, *_ in outs]))
+        for spec, x, raw, y, d in outs:
+            if d:
+                self._unapplied[(id(y.st), y.c0, y.C)] = (raw, spec)
+
+        def bwd():
+            dense = []
+            for spec, x, raw, y, _ in outs:
+                assert y.grad_ready(), f"gradient of {spec.name} output incomplete"
+                ykey = (id(y.st), y.c0, y.C)
+                rows = self._rows_grad.get(ykey)
+                if rows is not None and self._gw.get(ykey) == 1:
+                    asg, A, a0 = rows
+                    self.call("dy_bn_act_bwd_reduce_rows", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), self._acc_ready(spec.acc_b),
+                              y.N, y.H * y.W, spec.cout, spec.act, asg, A, a0)
+                else:
+                    dense.append((spec, raw, y))
+            if len(dense) == 1:
+                spec, raw, y = dense[0]
+                self.call("dy_bn_act_bwd_reduce_acc", y.gptr, y.ld, raw.ptr, raw.ld, spec.coef.data_ptr(), self._acc_ready(spec.acc_b), y.npix,
+                          spec.cout, spec.act, 0, 0, 0)
+            elif dense:
+                self.call("dy_bn_act_bwd_reduce_acc_group", len(dense), self._arr(P, [y.gptr for _, _, y in dense]), self._arr(I, [y.ld for _, _, y in dense]),
+                          self._arr(P, [raw.ptr for _, raw, _ in dense]), self._arr(I, [raw.ld for _, raw, _ in dense]),
+                          self._arr(P, [sp.coef.data_ptr() for sp, _, _ in dense]), self._arr(P, [self._acc_ready(sp.acc_b) for sp, _, _ in dense]),
+                          self._arr(Lg, [y.npix for _, _, y in dense]), self._arr(I, [sp.cout for sp, _, _ in dense]))
+            for spec, x, raw, y, _ in reversed(outs):
+                self._conv_bn_act_bwd(spec, x, raw, y, None, reduced=True)
+        self.tape.append(bwd)
+        return [y for _, _, _, y, _ in outs]
+
+    def _conv_bn_act_bwd(self, spec, x, raw, y, res, reduced=False):
         assert y.grad_ready(), f"gradient of {spec.name} output incomplete"
         npix = y.npix
         acc = BN_ACC and spec.acc_b is not None
@@ -661,7 +725,7 @@ class Engine:
         rows = self._rows_grad.get(ykey)
         if rows is not None and self._gw.get(ykey) != 1:
             rows = None  # somebody else wrote into that gradient as well: it is dense
-        if acc and fused_red:
+        if acc and (fused_red or reduced):  # reduced: conv_bn_act_group ran this layer's reduce with its group's
             pass
         elif acc and rows is not None and rg == (0, 0, 0):
             # y's gradient came from dy_conv1x1_rows_backward alone: zero outside the loss's foreground anchors, so are the summands

@@ -114,13 +114,25 @@ class Detect(HipModule):
         cspecs = [rt.specs[(id(self), "cv3", l)] for l in range(len(xs))]
         cls_all = HEAD_BATCH and all(eng.cls_capable(sp, ncp) for sp in cspecs) and len({(sp.cin, sp.cout) for sp in cspecs}) == 1
         box_items, box_fns, cls_items = [], [], []
+        from ...hip.engine import BN_GROUP
+        staged = None
+        if BN_GROUP and eng.pending_decode is not None and eng.tape is not None and 2 * len(xs) <= eng.L.dy_bn_group_max():
+            # inside a StepPlan trace the two stages of the six branches run as groups: six conv launches, ONE apply launch (and ONE
+            # backward reduce launch) per stage instead of six -- the 80x80 / 40x40 levels' passes run beside the 160x160 level's
+            first = eng.conv_bn_act_group([(rt.spec(m[l][0]), x) for l, x in enumerate(xs) for m in (self.cv2, self.cv3)])
+            defer = [(fused if b == 0 else eng.cls_capable(cspecs[l], ncp)) and HEAD_APPLY for l in range(len(xs)) for b in (0, 1)]
+            staged = eng.conv_bn_act_group([(rt.spec(m[l][1]), first[2 * l + b]) for l in range(len(xs)) for b, m in enumerate((self.cv2, self.cv3))],
+                                           defer=defer)
         for l, x in enumerate(xs):
             # fused: ``a`` is read by dy_head_box_decode, the rows backward and the loss only -- all of which apply BatchNorm + SiLU
             # themselves, so the Conv in front leaves its apply launch out
-            a = self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(x), defer_apply=fused and HEAD_APPLY)
             cspec = cspecs[l]
             cls_fused = eng.cls_capable(cspec, ncp)
-            c = self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(x), defer_apply=cls_fused and HEAD_APPLY)
+            if staged is not None:
+                a, c = staged[2 * l], staged[2 * l + 1]
+            else:
+                a = self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(x), defer_apply=fused and HEAD_APPLY)
+                c = self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(x), defer_apply=cls_fused and HEAD_APPLY)
             if fused:
                 if HEAD_BATCH:  # all levels in one launch per kind, issued after the loop
                     box_items.append((rt.specs[(id(self), "cv2", l)], a, l))

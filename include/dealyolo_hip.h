@@ -175,6 +175,16 @@ int dy_bn_act_apply_acc(const void* x, int ldx, const void* res, int ldr, void* 
  * -- it equals dy, and is stored (res_accumulate 0) or added (1) while dy streams through, instead of by a pass of its own */
 int dy_bn_act_bwd_reduce_acc(const void* dy, int lddy, const void* x, int ldx, const float* coef, double* acc, long npix,
                              int C, int act, void* res_grad, int ldrg, int res_accumulate, hipStream_t stream);
+/* The accumulator forms of the forward apply / backward reduce (SiLU, no residual / shortcut operand) for SEVERAL tensors in one launch
+ * (n <= dy_bn_group_max(); array arguments have n entries): independent Convs of one stage, whose passes would otherwise queue behind
+ * each other although the small ones cannot fill the chip. */
+int dy_bn_group_max(void);
+int dy_bn_act_apply_acc_group(int n, const void* const* x, const int* ldx, void* const* y, const int* ldy, const double* const* acc,
+                              const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
+                              float* const* coef, const long* npix, const int* C, const float* count, const float* eps,
+                              const float* momentum, hipStream_t stream);
+int dy_bn_act_bwd_reduce_acc_group(int n, const void* const* dy, const int* lddy, const void* const* x, const int* ldx,
+                                   const float* const* coef, double* const* acc, const long* npix, const int* C, hipStream_t stream);
 /* dy_bn_act_bwd_reduce_acc for a gradient that has ROWS (what dy_conv1x1_rows_backward passes down: zero at every background anchor):
  * the sums visit the foreground pixels of `assigned` (B = n images, A anchors each, this tensor's pixel (b, r) is anchor a0 + r) only */
 int dy_bn_act_bwd_reduce_rows(const void* dy, int lddy, const void* x, int ldx, const float* coef, double* acc, int n, int hw, int C,
