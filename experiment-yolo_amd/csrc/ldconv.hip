@@ -25,12 +25,25 @@ struct LdArgs {
   int N, H, W, h, w, C, Np, stride;
 };
 
+// q = x / d, r = x % d.  A 64-bit division is ~100 VALU instructions on this machine and the index decompositions below need four to
+// eight of them per 16 bytes moved (the sample kernels were bound by them); every tensor these kernels see has fewer than 2^31
+// elements, so the 32-bit form runs -- the 64-bit one stays for the case that one day does not.
+static __device__ __forceinline__ void ld_divmod(long x, int d, long& q, int& r) {
+  if (x >= 0 && x < 0x7fffffffL) {
+    const unsigned xx = (unsigned)x, qq = xx / (unsigned)d;
+    q = (long)qq;
+    r = (int)(xx - qq * (unsigned)d);
+  } else {
+    q = x / d;
+    r = (int)(x - q * d);
+  }
+}
 static __device__ __forceinline__ void ld_coords(const LdArgs& a, long pix, int n, int& r0, int& r1, int& c0, int& c1,
                                                  float& pr, float& pc, bool& in_r, bool& in_c, long& img) {
-  const int ox = (int)(pix % a.w);
-  const long t = pix / a.w;
-  const int oy = (int)(t % a.h);
-  img = t / a.h;
+  int ox, oy;
+  long t;
+  ld_divmod(pix, a.w, t, ox);
+  ld_divmod(t, a.h, img, oy);
   const float* o = a.off + pix * a.ldoff_in;
   const float ur = (float)(oy * a.stride) + (float)a.pn[n] + o[n];            // :446-454
   const float uc = (float)(ox * a.stride) + (float)a.pn[a.Np + n] + o[a.Np + n];
@@ -50,10 +63,10 @@ __global__ __launch_bounds__(256) void ldconv_sample_kernel(LdArgs a) {
   const int cpp = a.C >> 3;
   const long total = (long)a.N * a.h * a.w * a.Np * cpp;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int part = (int)(idx % cpp);
-    long t = idx / cpp;
-    const int n = (int)(t % a.Np);
-    const long pix = t / a.Np;
+    int part, n;
+    long t, pix;
+    ld_divmod(idx, cpp, t, part);
+    ld_divmod(t, a.Np, pix, n);
     int r0, r1, c0, c1;
     float pr, pc;
     bool ir, ic;
@@ -155,9 +168,10 @@ __global__ __launch_bounds__(256) void ldconv_doff_kernel(LdArgs a, int LG, unsi
   const int lane = threadIdx.x & 63, gl = lane & (LG - 1);
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < span; idx += (long)gridDim.x * 256) {
     const bool live = idx < total;
-    const long t = (live ? idx : total - 1) / LG;
-    const int n = (int)(t % a.Np);
-    const long pix = t / a.Np;
+    const long t = (live ? idx : total - 1) / LG;  // LG is a power of two: a shift
+    int n;
+    long pix;
+    ld_divmod(t, a.Np, pix, n);
     int r0, r1, c0, c1;
     float pr, pc;
     bool ir, ic;
