@@ -126,8 +126,12 @@ class YOLO:
             raise RuntimeError("the multi-GPU run returned no weights (rank 0 writes <run>/weights/last.pt or a temporary checkpoint)")
         ck = torch.load(w, map_location="cpu", weights_only=False)
         names = getattr(self.model, "names", None)
-        self.model = DetectionModel(ck["yaml"], verbose=False)  # the ranks' model: the dataset's class count, the trained weights
-        self.model.load_state_dict(ck["model"], strict=True)
+        # the ranks' model: the dataset's class count and -- as attempt_load_one_weight does there (``ckpt.get("ema") or ckpt["model"]``,
+        # reference nn/tasks.py:780) and attempt_load_weights does here -- the EMA weights when the checkpoint carries them, so that
+        # val() / predict() after train(device='0,1') score the same weights as YOLO(last.pt) would
+        self.model = DetectionModel(ck["yaml"], verbose=False)
+        ema = ck.get("ema")
+        self.model.load_state_dict(ema if isinstance(ema, dict) and ema else ck["model"], strict=True)
         if names is not None and len(names) == len(self.model.names):
             self.model.names = names
         tmp = w.startswith(os.path.join(tempfile.gettempdir(), "dealyolo_ddp"))

@@ -264,16 +264,19 @@ class DetectionTrainer:
     def _label_capacity(self, loader):
         """Largest number of boxes one training sample can carry, from the dataset's label table: a mosaic holds four images'
         boxes, MixUp concatenates two samples (reference data/augment.py: Mosaic / MixUp), so up to eight images' boxes meet in
-        one sample.  None for loaders without a label table."""
+        one sample.  The mosaic partners are drawn WITH replacement from a buffer that already holds the index image
+        (data/dataset.py: ``random.choices(list(self.buffer), k=3)``) and MixUp's partner is an independent draw, so the image with
+        the most labels can fill every tile: the bound is tiles x the largest count, not the sum of the largest distinct counts.
+        None for loaders without a label table."""
         ds = getattr(loader, "dataset", None)
         labels = getattr(ds, "labels", None)
         if not labels:
             return None
-        counts = sorted((len(lb["cls"]) for lb in labels), reverse=True) or [1]
+        most = max((len(lb["cls"]) for lb in labels), default=1)
         per = 4 if getattr(ds, "mosaic", 0.0) else 1
         if getattr(self.args, "mixup", 0.0):
             per *= 2
-        return max(8, (sum(counts[:per]) + 7) // 8 * 8)
+        return max(8, (per * most + 7) // 8 * 8)
 
     def _save_dir(self):
         """``project/name`` as in the reference (cfg get_save_dir), created only when one of the two was given explicitly: this

@@ -82,6 +82,9 @@ HEAD_BATCH = os.environ.get("DY_HEAD_BATCH", "1") != "0"
 # Independent Convs of one stage (Detect's six first convs, its six second convs) as a GROUP: their conv launches stay, their BatchNorm
 # apply passes are one launch and so are their backward reduces (Engine.conv_bn_act_group, dy_bn_act_*_group).
 BN_GROUP = BN_ACC and os.environ.get("DY_BN_GROUP", "1") != "0"
+# Detect's levels as BRANCHES of the recorded step (Engine.branch): the 80x80 / 40x40 levels' conv stacks -- launches that cannot fill
+# the chip -- are recorded on side streams and run beside the 160x160 level's, forward and backward (DY_HEAD_STREAMS=0: one stream).
+HEAD_STREAMS = os.environ.get("DY_HEAD_STREAMS", "0") != "0"
 HEAD_APPLY = HEAD_DECODE and os.environ.get("DY_SILU_FAST", "1") != "0" and os.environ.get("DY_HEAD_APPLY", "1") != "0"
 BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
 BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
@@ -246,7 +249,23 @@ class ImageAct:
 
 class Recorder:
     def __init__(self):
-        self.ops = []  # (cfunc, argtuple, name, on_side_stream); cfunc None = fork/join marker
+        self.ops = []  # (cfunc, argtuple, name, stream id); cfunc None = fork/join marker (argtuple = (stream id,)); stream 0 = main
+
+
+class Tape(list):
+    """The backward closures of a trace.  A closure appended while the engine records on a BRANCH (``Engine.branch``: a side stream
+    that runs an independent chain of the graph beside the main one) issues its backward launches on that branch's stream too."""
+
+    def __init__(self, eng):
+        super().__init__()
+        self.eng = eng
+
+    def append(self, f):
+        sid = self.eng.cur_sid
+        if sid:
+            eng, g = self.eng, f
+            f = lambda: eng._on(sid, g)  # noqa: E731
+        super().append(f)
 
 
 class ConvSpec:
@@ -293,28 +312,37 @@ class Engine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def call(self, name, *args, side=False):
-        """Launch (and, while tracing, record) one C-ABI call.  ``side=True`` puts it on the engine's side stream: only for work
-        nothing on the main stream depends on until the next ``join()`` (weight gradients), bracketed by ``fork()``."""
+        """Launch (and, while tracing, record) one C-ABI call on the stream of the branch being recorded (``cur_sid``; 0 = the main
+        stream).  ``side=True`` puts it on side stream 1: only for work nothing on the main stream depends on until the next
+        ``join()`` (weight gradients), bracketed by ``fork()``."""
         fn = getattr(self.L, name)
-        s = self.side_stream.cuda_stream if side else self.stream
+        sid = 1 if side else self.cur_sid
+        s = self._stream_of(sid).cuda_stream if sid else self.stream
         rc = fn(*args, s)
         check(rc, name)
         if self.rec is not None:
-            self.rec.ops.append((fn, args, name, side))
+            self.rec.ops.append((fn, args, name, sid))
 
     # ---- two-stream plumbing: fork = "side waits for everything issued on main so far", join = "main waits for side" ----
     side_wgrad = False      # StepPlan switches it on for its backward trace
-    _side_stream = None
+    cur_sid = 0             # stream id launches go to (0 = the caller's current stream); set by ``branch`` / ``_on``
+    _side_streams = None
     _FORK, _JOIN = "<fork>", "<join>"
+
+    def _stream_of(self, sid):
+        if self._side_streams is None:
+            self._side_streams = {}
+        st = self._side_streams.get(sid)
+        if st is None:
+            st = self._side_streams[sid] = torch.cuda.Stream(self.device)
+        return st
 
     @property
     def side_stream(self):
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(self.device)
-        return self._side_stream
+        return self._stream_of(1)
 
-    def _sync(self, kind):
-        main, side = torch.cuda.current_stream(self.device), self.side_stream
+    def _sync(self, kind, sid=1):
+        main, side = torch.cuda.current_stream(self.device), self._stream_of(sid)
         ev = torch.cuda.Event()
         if kind == self._FORK:
             ev.record(main)
@@ -323,25 +351,60 @@ class Engine:
             ev.record(side)
             main.wait_event(ev)
 
-    def fork(self):
-        self._sync(self._FORK)
+    def fork(self, sid=1):
+        """Side stream ``sid`` waits for everything issued on the main stream so far."""
+        self._sync(self._FORK, sid)
         if self.rec is not None:
-            self.rec.ops.append((None, (), self._FORK, False))
+            self.rec.ops.append((None, (sid,), self._FORK, 0))
 
-    def join(self):
-        self._sync(self._JOIN)
+    def join(self, sid=1):
+        """The main stream waits for everything issued on side stream ``sid`` so far."""
+        self._sync(self._JOIN, sid)
         if self.rec is not None:
-            self.rec.ops.append((None, (), self._JOIN, False))
+            self.rec.ops.append((None, (sid,), self._JOIN, 0))
+
+    # ---- branches: an independent chain of the graph (a detection level's head, ScalSeq beside the neck) recorded on its own stream,
+    # so that its launches -- too small to fill the chip -- run beside the main chain's.  ``fork_branch`` / ``join_branch`` bracket it in
+    # the forward AND leave the mirrored synchronisation on the tape: where the forward joined, the backward forks, and vice versa.
+    def fork_branch(self, sid):
+        assert self.cur_sid == 0
+        self.fork(sid)
+        if self.tape is not None:
+            self.tape.append(lambda: self.join(sid))
+
+    def join_branch(self, sid):
+        assert self.cur_sid == 0
+        self.join(sid)
+        if self.tape is not None:
+            self.tape.append(lambda: self.fork(sid))
+
+    def branch(self, sid):
+        eng = self
+
+        class _Branch:
+            def __enter__(self_b):
+                self_b.prev, eng.cur_sid = eng.cur_sid, sid
+
+            def __exit__(self_b, *exc):
+                eng.cur_sid = self_b.prev
+        return _Branch()
+
+    def _on(self, sid, f):
+        prev, self.cur_sid = self.cur_sid, sid
+        try:
+            f()
+        finally:
+            self.cur_sid = prev
 
     def replay(self, rec, lo=0, hi=None):
         """Re-issue a recorded launch list (or its slice [lo, hi)) on the CURRENT stream (which may be a capturing stream);
         side-stream launches and their fork/join points are reproduced (under capture they become parallel branches of the graph)."""
         s = self.stream
-        for fn, args, name, side in (rec.ops if lo == 0 and hi is None else rec.ops[lo:hi]):
+        for fn, args, name, sid in (rec.ops if lo == 0 and hi is None else rec.ops[lo:hi]):
             if fn is None:
-                self._sync(name)
+                self._sync(name, args[0] if args else 1)
                 continue
-            rc = fn(*args, self.side_stream.cuda_stream if side else s)
+            rc = fn(*args, self._stream_of(sid).cuda_stream if sid else s)
             if rc != 0:
                 check(rc, name)
 
@@ -351,6 +414,10 @@ class Engine:
 
     @tape.setter
     def tape(self, v):
+        if v is not None and not isinstance(v, Tape):
+            t = Tape(self)
+            list.extend(t, v)
+            v = t
         self._tape = v
         if v is not None and len(v) == 0:  # a new trace begins: the dataflow facts of the previous one (keyed by object ids) are void
             self.reset_dataflow()
@@ -742,9 +809,9 @@ class Engine:
                       spec.cout, spec.act, C.byref(n))
             self.call("dy_bn_bwd_finalize", part.data_ptr(), n.value, spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(),
                       spec.bwdcoef.data_ptr(), spec.cout, float(npix), 0)
-        if self.side_wgrad and self.deferred_wgrad is not None:
-            # the weight gradient reads this buffer on the side stream while the main stream moves on to the next layer:
-            # it cannot be the shared scratch
+        if (self.side_wgrad and self.deferred_wgrad is not None) or self.cur_sid:
+            # the weight gradient reads this buffer on the side stream while the main stream moves on to the next layer (or this
+            # layer's backward runs on a branch beside the main chain's): it cannot be the shared scratch
             draw = self.transient((npix * spec.cout,), torch.float16)
             self.hold(draw)
         else:

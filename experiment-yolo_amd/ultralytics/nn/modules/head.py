@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -114,9 +115,27 @@ class Detect(HipModule):
         cspecs = [rt.specs[(id(self), "cv3", l)] for l in range(len(xs))]
         cls_all = HEAD_BATCH and all(eng.cls_capable(sp, ncp) for sp in cspecs) and len({(sp.cin, sp.cout) for sp in cspecs}) == 1
         box_items, box_fns, cls_items = [], [], []
-        from ...hip.engine import BN_GROUP
+        from ...hip.engine import BN_GROUP, HEAD_STREAMS
         staged = None
-        if BN_GROUP and eng.pending_decode is not None and eng.tape is not None and 2 * len(xs) <= eng.L.dy_bn_group_max():
+        if HEAD_STREAMS and eng.pending_decode is not None and eng.tape is not None and eng.cur_sid == 0:
+            # inside a StepPlan trace: every level's two conv stacks are an independent chain until the loss -- level l > 0 is recorded
+            # on side stream l, so the small levels' launches (50-200 workgroups) run beside the 160x160 level's and beside each other
+            staged = [None] * (2 * len(xs))
+            order = os.environ.get("DY_HEAD_STREAMS_ORDER", "")
+            first_alone = order == "after"  # level 0 (chip-filling) on its own first, then the small levels beside each other
+            if first_alone:
+                staged[0] = self.cv2[0][1].forward_act(self.cv2[0][0].forward_act(xs[0]), defer_apply=fused and HEAD_APPLY)
+                staged[1] = self.cv3[0][1].forward_act(self.cv3[0][0].forward_act(xs[0]), defer_apply=eng.cls_capable(cspecs[0], ncp) and HEAD_APPLY)
+            for l in range(1, len(xs)):
+                eng.fork_branch(l)
+            for l in (range(1 if first_alone else 0, len(xs)) if order != "rev" else reversed(range(len(xs)))):
+                with eng.branch(l):
+                    staged[2 * l] = self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(xs[l]), defer_apply=fused and HEAD_APPLY)
+                    staged[2 * l + 1] = self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(xs[l]),
+                                                                   defer_apply=eng.cls_capable(cspecs[l], ncp) and HEAD_APPLY)
+            for l in range(1, len(xs)):
+                eng.join_branch(l)
+        elif BN_GROUP and eng.pending_decode is not None and eng.tape is not None and 2 * len(xs) <= eng.L.dy_bn_group_max():
             # inside a StepPlan trace the two stages of the six branches run as groups: six conv launches, ONE apply launch (and ONE
             # backward reduce launch) per stage instead of six -- the 80x80 / 40x40 levels' passes run beside the 160x160 level's
             first = eng.conv_bn_act_group([(rt.spec(m[l][0]), x) for l, x in enumerate(xs) for m in (self.cv2, self.cv3)])

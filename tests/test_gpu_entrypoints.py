@@ -108,6 +108,16 @@ hist = model.train(data={os.path.join(root, 'data.yaml')!r}, cache=False, imgsz=
                    device=DEVICE, optimizer='SGD', project={str(tmp_path / 'runs')!r}, name='exp', val=False, **dict(zero, **EXTRA))
 rm = model.model.state_dict()['model.0.bn.running_mean']  # zero at construction: moved only by training steps
 print('TRAINED', float(rm.abs().sum()) > 0.0, model.trainer is not None)
+import torch, os
+last = os.path.join({str(tmp_path / 'runs')!r}, 'exp', 'weights', 'last.pt')
+if getattr(model, 'ddp_result', None) is not None and os.path.exists(last):
+    # after the re-launch the parent holds what YOLO(last.pt) would: the checkpoint's EMA weights (reference nn/tasks.py:780,
+    # ``ckpt.get('ema') or ckpt['model']``), not the raw trained ones
+    ck = torch.load(last, map_location='cpu', weights_only=False)
+    sd = model.model.state_dict()
+    same = all(torch.equal(sd[k].cpu().float(), v.float()) for k, v in ck['ema'].items())
+    differs = any(not torch.equal(ck['ema'][k].float(), ck['model'][k].float()) for k in ck['ema'])
+    print('EMA_HANDOVER', same, differs)
 print('RESULT', json.dumps([[float(x) for x in h] for h in hist]), getattr(model, 'ddp_result', None) is not None)
 """
     outs = {}
@@ -119,6 +129,8 @@ print('RESULT', json.dumps([[float(x) for x in h] for h in hist]), getattr(model
         # whichever way the run was launched, the caller's model object holds TRAINED weights afterwards (after the re-launch: rank
         # 0's checkpoint loaded back, reference engine/model.py:612-616) -- m.val() / m.predict() never see the untouched copy
         assert [l for l in p.stdout.splitlines() if l.startswith("TRAINED")][-1].split()[1] == "True", p.stdout[-2000:]
+        if dev.startswith("'0,1'"):
+            assert [l for l in p.stdout.splitlines() if l.startswith("EMA_HANDOVER")][-1].split()[1:] == ["True", "True"], p.stdout[-2000:]
     single, ddp = outs["'0'"], outs["'0,1'"]
     assert single[0].shape == (2, 3) and np.isfinite(single[0]).all() and not single[1]
     assert ddp[1], "device='0,1' must have gone through the torch.distributed.run re-launch"

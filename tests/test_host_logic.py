@@ -219,3 +219,16 @@ def test_importing_the_package_turns_graph_packet_capture_off():
     env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
     assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.split() == ["0", "True"]
     assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1")).stdout.split() == ["1", "False"]
+
+
+def test_label_capacity_covers_the_outlier_image_in_every_mosaic_tile():
+    """Mosaic partners are drawn with replacement from a buffer that holds the index image (data/dataset.py, reference
+    data/augment.py Mosaic._mosaic4) and MixUp's partner is an independent draw: the most-labelled image can sit in all 4 (8) tiles."""
+    from types import SimpleNamespace as NS
+    from ultralytics.engine.trainer import DetectionTrainer
+    labels = [dict(cls=np.zeros((n, 1))) for n in (3, 41, 2, 5, 1)]
+    cap = lambda mosaic, mixup: DetectionTrainer._label_capacity(NS(args=NS(mixup=mixup)), NS(dataset=NS(labels=labels, mosaic=mosaic)))  # noqa: E731
+    assert cap(0.0, 0.0) == 48          # one image: 41 rounded up to 8
+    assert cap(1.0, 0.0) == 4 * 41 + 4  # four tiles of the outlier (164 -> 168)
+    assert cap(1.0, 0.1) == 8 * 41      # MixUp of two such mosaics
+    assert DetectionTrainer._label_capacity(NS(args=NS(mixup=0.0)), NS(dataset=None)) is None

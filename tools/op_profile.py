@@ -72,3 +72,7 @@ tot = sum(r[0] for r in rows)
 print(f"total device ms/step {tot:.2f}  ({len(rows)} calls)")
 for ms, name, d, by in sorted(rows, key=lambda r: -r[0])[:int(os.environ.get('TOP', '60'))]:
     print(f"{ms*1e3:9.1f} us  {name:24s} {d:48s} {by/ms/1e6 if by else 0:8.0f} GB/s")
+if os.environ.get("ORDER"):  # the same table in EXECUTION order (forward, loss, backward), every launch
+    print("---- execution order")
+    for i, (ms, name, d, by) in enumerate(rows):
+        print(f"{i:4d} {ms*1e3:9.1f} us  {name:24s} {d:48s} {by/ms/1e6 if by else 0:8.0f} GB/s")
