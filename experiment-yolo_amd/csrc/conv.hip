@@ -13,6 +13,8 @@
 
 // measurement hook (tools/conv_bench.py DY_EPI=256): run the kernel without its output stores to price the store path
 #define DY_EPI_DEBUG_NOSTORE 256
+// add ConvArgs::res to the result after bias / activation (dy_conv_forward_res; ping-pong kernel, fast epilogue only)
+#define DY_EPI_RES 64
 
 struct ConvArgs {
   const f16* x;
@@ -34,6 +36,10 @@ struct ConvArgs {
   // RED (input-gradient launches only): y is the COMPLETE gradient w.r.t. the activated output of a Conv (conv + BatchNorm + SiLU) --
   // this launch is its only writer -- so the first pass of that layer's BatchNorm backward (sums of g = dy * act'(z) and g * xhat,
   // bn_act_bwd_reduce_kernel) runs here, in the epilogue, on the values being stored, and is added into racc
+  // DY_EPI_RES (inference, with BIAS | SILU): a tensor added to the activated result -- Bottleneck's shortcut x + cv2(cv1(x)), reference
+  // nn/modules/block.py:333-335 -- on the fp16 values about to be stored, i.e. the bits of "store, then dy_add"
+  const f16* res;      // (N, Ho, Wo, ldres)
+  int ldres;
   const f16* rraw;     // (N, Ho, Wo, ldrraw) raw conv output of that layer's forward
   const float* rcoef;  // [4][rC]: scale, shift, mean, invstd
   double* racc;        // [DY_BN_COPIES][2][rC]
@@ -903,8 +909,9 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
           //    store is 64 separate 16-byte writes per instruction (measured: 21 % of the kernel).  Each N-tile is
           //    therefore turned through a per-wave LDS scratch so that PPR consecutive lanes write one pixel's whole
           //    channel block: full-line stores, 8x fewer write requests.
-          auto fast = [&](auto acc_tag, auto stats_tag, auto bias_tag, auto silu_tag, auto red_tag) {
-            constexpr bool ACCUM = decltype(acc_tag)::value, STATS = decltype(stats_tag)::value;
+          auto fast = [&](auto acc_tag, auto stats_tag, auto bias_tag, auto silu_tag, auto red_tag, auto resv_tag) {
+            constexpr bool RESV = decltype(resv_tag)::value;   // the addend is ConvArgs::res (its own pointer / pitch), not the old output
+            constexpr bool ACCUM = decltype(acc_tag)::value || RESV, STATS = decltype(stats_tag)::value;
             constexpr bool BIAS = decltype(bias_tag)::value, SILU = decltype(silu_tag)::value, RED = decltype(red_tag)::value;
             constexpr int PPR = RB / 16;                       // 16-byte pieces per pixel row
             constexpr int PIXPASS = 64 / PPR;                  // pixels one store instruction covers
@@ -917,6 +924,10 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             const int row0 = FLAT ? 0 : oy0 + wgs * TROWS;
             const long tbase = FLAT ? (long)(pix0 + wgs * (NT * 16)) * a.ldy : ((long)(n * a.Ho + row0) * a.Wo + ox0) * a.ldy;
             char* const ybase = reinterpret_cast<char*>(a.y) + tbase * 2;
+            // RESV: where the addend of this lane's pieces lives (same pixel / channel walk over res with its own pitch)
+            const unsigned rloff = RESV ? (unsigned)((dpix * a.ldres + blockIdx.y * (16 * MT) + piece * 8) * 2) : 0u;
+            const long rtbase = !RESV ? 0 : (FLAT ? (long)(pix0 + wgs * (NT * 16)) * a.ldres : ((long)(n * a.Ho + row0) * a.Wo + ox0) * a.ldres);
+            const char* const rbase = reinterpret_cast<const char*>(a.res) + rtbase * 2;
             const int collim = FLAT ? a.npix - (pix0 + wgs * (NT * 16)) : a.Wo - ox0;  // lanes' pixels below this are real
             const bool full = FLAT ? collim >= NT * 16 : (collim >= TW && oy0 + TH <= a.Ho);
             char* const xw = xs + p * XROW + q * (NC * 2);
@@ -946,9 +957,10 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
                   lo += (f32x2){b[0], b[1]};
                   hi += (f32x2){b[2], b[3]};
                 }
-                if (SILU) {
-                  lo = (f32x2){silu_f(lo[0]), silu_f(lo[1])};
-                  hi = (f32x2){silu_f(hi[0]), silu_f(hi[1])};
+                if (SILU) {  // the division written out in packed fp32 (common.h: the quotient's bits, about half the instructions of
+                             // z / (1 + exp(-z)) -- this runs in the memory slot, beside the other group's MFMAs)
+                  lo = act_fwd2_fast<DY_ACT_SILU>(lo);
+                  hi = act_fwd2_fast<DY_ACT_SILU>(hi);
                 }
                 hv.h[m * 2] = __builtin_convertvector(lo, half2_);
                 hv.h[m * 2 + 1] = __builtin_convertvector(hi, half2_);
@@ -977,6 +989,15 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
               char* const pz = ybase + soff * 2 + loff;
               return reinterpret_cast<uint4*>(valid ? pz : reinterpret_cast<char*>(a.y));
             };
+            auto addend = [&](int t, int ps) {  // what is added to the values of (t, ps): the old output, or (RESV) the residual tensor
+              bool valid;
+              if (!RESV) return *dest(t, ps, valid);
+              const bool rowok = FLAT ? true : row0 + (t >> 1) < a.Ho;
+              const int c0 = tile_col(t) + ps * PIXPASS;
+              const long soff = FLAT ? (long)c0 * a.ldres : ((long)(t >> 1) * a.Wo + c0) * a.ldres;
+              valid = rowok && chok && dpix < 16 && c0 + dpix < collim;
+              return *reinterpret_cast<const uint4*>(valid ? rbase + soff * 2 + rloff : reinterpret_cast<const char*>(a.res));
+            };
             // software pipeline over the N-tiles: the scratch is written for tile t+1 as soon as tile t's reads have ISSUED
             // (not returned), so one LDS round trip hides behind the next tile's conversion instead of four in a row
             U4 d[2][NPASS], o[ACCUM ? NT : 1][NPASS];
@@ -985,10 +1006,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
 #pragma unroll
               for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) {
-                  bool valid;
-                  o[t][ps].u = *dest(t, ps, valid);
-                }
+                for (int ps = 0; ps < NPASS; ++ps) o[t][ps].u = addend(t, ps);
             }
             convert_write(0);
 #pragma unroll
@@ -1057,12 +1075,15 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             constexpr std::true_type Y{};
             constexpr std::false_type N_{};
             const int e = a.epi & (DY_EPI_ACCUM | DY_EPI_STATS | DY_EPI_BIAS | DY_EPI_SILU);
-            if (e == DY_EPI_ACCUM) fast(Y, N_, N_, N_, N_);
-            else if (e == DY_EPI_STATS) fast(N_, Y, N_, N_, N_);
-            else if (e == (DY_EPI_STATS | DY_EPI_BIAS)) fast(N_, Y, Y, N_, N_);
-            else if (e == (DY_EPI_BIAS | DY_EPI_SILU)) fast(N_, N_, Y, Y, N_);
-            else if (REDK) fast(N_, N_, N_, N_, std::integral_constant<bool, REDK>{});
-            else fast(N_, N_, N_, N_, N_);
+            if (e == DY_EPI_ACCUM) fast(Y, N_, N_, N_, N_, N_);
+            else if (e == DY_EPI_STATS) fast(N_, Y, N_, N_, N_, N_);
+            else if (e == (DY_EPI_STATS | DY_EPI_BIAS)) fast(N_, Y, Y, N_, N_, N_);
+            else if (e == (DY_EPI_BIAS | DY_EPI_SILU) && (a.epi & DY_EPI_RES)) {
+              // (3x3 stride-1 only -- Bottleneck.cv2 -- so that no other instantiation carries the variant's code and registers)
+              if constexpr (KS == 3 && STRIDE == 1) fast(N_, N_, Y, Y, N_, Y);
+            } else if (e == (DY_EPI_BIAS | DY_EPI_SILU)) fast(N_, N_, Y, Y, N_, N_);
+            else if (REDK) fast(N_, N_, N_, N_, std::integral_constant<bool, REDK>{}, N_);
+            else fast(N_, N_, N_, N_, N_, N_);
           }
         } else {
 #pragma unroll
@@ -1321,10 +1342,15 @@ extern "C" int dy_conv_geometry(int cin, int cout, int ks, int stride, int* cin_
   // resident; the alternative (v1 kernel, A fragments from L2) measured 150-300 TFLOP/s on them.
   // (Only up to 128x128 channels: beyond, the cout groups multiply while the 20x20 maps leave each workgroup a handful of
   // tiles per 74 KB weight load -- 256->256 @20x20 and 128->256 s2 measured 15-55 % slower this way.)
-  if (pp_trows(c, m, ks, stride, cp / c) == 0 && cp <= 128 && op <= 128) {
+  // Stride-2 3x3 over 128 input channels (yolov8n-p2's 128->256 / 128->128 down-sampling convs at 80x80): the halo tile of a stride-2
+  // kernel is four times a stride-1 tile's, so only 16-channel chunks leave room for a 32-wide cout group beside it -- without them
+  // 128->128 ran on 16-wide groups (input staged eight times, 84 TFLOP/s) and 128->256 on the v1 kernel (A fragments from L2).
+  static const bool s2cc16 = getenv("DY_CONV_S2_CC16") == nullptr || atoi(getenv("DY_CONV_S2_CC16")) != 0;
+  const bool s2wide = s2cc16 && ks == 3 && stride == 2 && cp == 128 && op <= 128;  // (128->256 on 32-wide groups measured SLOWER than v1: 227 vs 174 us)
+  if (pp_trows(c, m, ks, stride, cp / c) == 0 && cp <= 128 && (op <= 128 || s2wide)) {
     bool found = false;
     for (int mm = m; mm >= 1 && !found; mm >>= 1)
-      for (int cc2 = c; cc2 >= 32 && !found; cc2 >>= 1) {
+      for (int cc2 = c; cc2 >= (s2wide ? 16 : 32) && !found; cc2 >>= 1) {
         if (cp % cc2) continue;
         if (pp_trows(cc2, mm, ks, stride, cp / cc2)) {
           m = mm;
@@ -1779,7 +1805,7 @@ static int launch_dg2(const ConvArgs& a, int grid_y, hipStream_t s) {
   return DY_OK;
 }
 
-struct RedHost { const void* raw; int ldraw; const float* coef; double* acc; int C; };
+struct RedHost { const void* raw; int ldraw; const float* coef; double* acc; int C; const void* res; int ldres; };
 static int conv_forward_impl(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                              float* partials, int n, int h, int w, int cin, int cout, int ks, int stride, int dil,
                              int out_h, int out_w, int epi, int* num_partials, hipStream_t stream, const RedHost* red);
@@ -1804,8 +1830,23 @@ extern "C" int dy_conv_input_grad_red(const void* dy, int lddy, const void* w_pa
                                       hipStream_t stream) {
   if (!raw || !coef || !acc || C != cout || (ldraw & 7) || ((uintptr_t)raw & 15) || !dy_conv_red_supported(cin, cout, ks) || (lddx & 7))
     return DY_ERR_ARG;
-  const RedHost red{raw, ldraw, coef, acc, C};
+  const RedHost red{raw, ldraw, coef, acc, C, nullptr, 0};
   return conv_forward_impl(dy, lddy, w_packed_t, nullptr, dx, lddx, nullptr, n, h, w, cin, cout, ks, 1, 1, 0, 0, 0, nullptr, stream, &red);
+}
+// 1 when dy_conv_forward_res can take this geometry: the ping-pong kernel's transposing epilogue (whole 8-channel pieces)
+extern "C" int dy_conv_res_supported(int cin, int cout, int ks, int stride) {
+  int cp, op, cc, nch, mt, ng, kst, pe;
+  if (dy_conv_geometry(cin, cout, ks, stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return 0;
+  return (ks == 3 && stride == 1 && cin == cp && cout % 8 == 0 && pp_trows(cc, mt, ks, stride, nch) != 0) ? 1 : 0;
+}
+// Conv.forward_fuse followed by Bottleneck's shortcut add (reference nn/modules/conv.py:57-59, nn/modules/block.py:333-335) in one
+// launch: y = fp16(fp16(SiLU(conv(x) + bias)) + res) -- the bits of dy_conv_forward(BIAS | SILU) followed by dy_add.
+extern "C" int dy_conv_forward_res(const void* x, int ldx, const void* w_packed, const float* bias, const void* res, int ldres, void* y,
+                                   int ldy, int n, int h, int w, int cin, int cout, int ks, int stride, hipStream_t stream) {
+  if (!res || !bias || (ldres & 7) || ((uintptr_t)res & 15) || (ldy & 7) || !dy_conv_res_supported(cin, cout, ks, stride)) return DY_ERR_ARG;
+  const RedHost red{nullptr, 0, nullptr, nullptr, 0, res, ldres};
+  return conv_forward_impl(x, ldx, w_packed, bias, y, ldy, nullptr, n, h, w, cin, cout, ks, stride, 1, 0, 0,
+                           DY_EPI_BIAS | DY_EPI_SILU | DY_EPI_RES, nullptr, stream, &red);
 }
 static int conv_forward_impl(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                              float* partials, int n, int h, int w, int cin, int cout, int ks, int stride, int dil,
@@ -1833,6 +1874,7 @@ static int conv_forward_impl(const void* x, int ldx, const void* w_packed, const
   a.cout = cout; a.nch = nch; a.epi = epi; a.dil = dil;
   if (red) {
     a.rraw = (const f16*)red->raw; a.ldrraw = red->ldraw; a.rcoef = red->coef; a.racc = red->acc; a.rC = red->C;
+    a.res = (const f16*)red->res; a.ldres = red->ldres;
   }
   static const bool xcd_map = getenv("DY_CONV_NO_XCDMAP") == nullptr;
   a.xcd_map = xcd_map && ks == 3;  // 1x1 tiles have no halo to share

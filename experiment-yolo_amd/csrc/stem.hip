@@ -32,6 +32,8 @@ struct StemArgs {
   float* slabs;        // backward: [gridDim.x][9][16][16] fp32 (tap, cout, cin) partial weight gradients
   int N, H, W, Ho, Wo, ldraw, lddy, tiles_x, tiles_y, ntiles;
   float mul, count;
+  const float* bias;   // forward, inference form (stem_fwd_kernel<true>): per-channel bias (BatchNorm folded into the weights) or null
+  int silu;            // ... and SiLU on the way out; no statistics
 };
 
 // stage the (17 x 65) x 3 input patch of one tile as fp16, zero outside the image: one patch row per wave and trip (a coalesced
@@ -71,6 +73,9 @@ typedef uint2 __attribute__((aligned(4))) uint2_a4;
 // weight), so one lane's four K values are four CONSECUTIVE halfs of a staged input row: one 8-byte LDS read per MFMA.  Nine groups
 // = three MFMAs per 16 pixels.  A = weights (rows = cout), B = patches (columns = pixels): a lane ends up with 4 consecutive
 // channels of one pixel.
+// INFER: the eval form -- ``raw`` receives the finished activation (+ bias, SiLU: Conv.forward_fuse, reference nn/modules/conv.py:57-59)
+// or the plain conv output (un-fused eval: BatchNorm with running statistics follows as its own pass); no statistics either way.
+template <bool INFER>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
   __shared__ __attribute__((aligned(16))) f16 s_in[3][STEM_IH][STEM_IP];
   __shared__ float s_red[4][2][STEM_CO];
@@ -85,6 +90,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
     for (int kx = 0; kx < 4; ++kx) af[ks][kx] = (g < 9 && kx < 3) ? (f16)a.w[p * 27 + c * 9 + ky * 3 + kx] : (f16)0.f;
   }
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (INFER && a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
   const f16* s_flat = &s_in[0][0][0];
   // the padding slot kx = 3 of the last pixel reads column 65, which the staging never writes: its weight is zero, but 0 x (whatever
   // bits LDS holds) is NaN when those bits are a NaN -- the pad columns are zeroed once
@@ -112,13 +119,20 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
       const int oy = oy0 + ty, ox = ox0 + px;
       if (oy < a.Ho && ox < a.Wo) {
         union { half4_ h; uint2 u; } o;
+        if (INFER) {
+          acc += b4;
+          if (a.silu) acc = (f32x4){silu_f(acc[0]), silu_f(acc[1]), silu_f(acc[2]), silu_f(acc[3])};
+        }
         o.h = __builtin_convertvector(acc, half4_);
         *reinterpret_cast<uint2*>(a.raw + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.ldraw + q * 4) = o.u;
-        s1 += acc;  // statistics from the fp32 values, as the ping-pong conv epilogue takes them
-        s2 += acc * acc;
+        if (!INFER) {
+          s1 += acc;  // statistics from the fp32 values, as the ping-pong conv epilogue takes them
+          s2 += acc * acc;
+        }
       }
     }
   }
+  if (INFER) return;
   // lane (p, q) holds channels q*4 .. q*4+3: sum over the 16 pixels lanes, then over the waves, one fp64 atomic per (sum, channel)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -254,7 +268,22 @@ extern "C" int dy_stem_forward(const float* img_nchw, const float* weight, void*
   if (!img_nchw || !weight || !raw || !acc || (ldraw & 7) || ((uintptr_t)raw & 15)) return DY_ERR_ARG;
   if (stem_args(a, n, h, w) != DY_OK) return DY_ERR_ARG;
   a.img = img_nchw; a.w = weight; a.raw = (f16*)raw; a.acc = acc; a.ldraw = ldraw; a.mul = mul;
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3(stem_fwd_grid(a.ntiles)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(stem_fwd_kernel<false>, dim3(stem_fwd_grid(a.ntiles)), dim3(256), 0, stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// The same convolution in eval mode: y = act(conv(img * mul) + bias) as fp16 NHWC (bias null: none; silu 0: no activation), no
+// statistics.  With BatchNorm folded into (weight, bias) this is the whole fused stem (Conv.forward_fuse, reference
+// nn/modules/conv.py:57-59; get_FPS.py:49 fuses before timing); un-fused eval takes bias = null, silu = 0 and applies BatchNorm with
+// running statistics afterwards.
+extern "C" int dy_stem_forward_eval(const float* img_nchw, const float* weight, const float* bias, void* y, int ldy, int n, int h, int w,
+                                    float mul, int silu, hipStream_t stream) {
+  StemArgs a{};
+  if (!img_nchw || !weight || !y || (ldy & 7) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return DY_ERR_ARG;
+  if (stem_args(a, n, h, w) != DY_OK) return DY_ERR_ARG;
+  a.img = img_nchw; a.w = weight; a.raw = (f16*)y; a.ldraw = ldy; a.mul = mul; a.bias = bias; a.silu = silu;
+  hipLaunchKernelGGL(stem_fwd_kernel<true>, dim3(stem_fwd_grid(a.ntiles)), dim3(256), 0, stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

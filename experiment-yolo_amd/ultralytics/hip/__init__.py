@@ -66,6 +66,8 @@ SIGNATURES = {
     "dy_pack_desc_fill": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32]),
     "dy_pack_weights_batched": (i32, [vp, i32, i32, vp]),
     "dy_conv_forward": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, ip, vp]),
+    "dy_conv_res_supported": (i32, [i32, i32, i32, i32]),
+    "dy_conv_forward_res": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_conv_red_supported": (i32, [i32, i32, i32]),
     "dy_conv_input_grad_red": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp]),
     "dy_conv_kernel_name": (i32, [i32, i32, i32, i32, C.c_char_p, i32]),
@@ -81,6 +83,7 @@ SIGNATURES = {
     "dy_conv_wgrad": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_stem_grid": (i32, [i32, i32, i32]),
     "dy_stem_forward": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
+    "dy_stem_forward_eval": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "dy_stem_wgrad_bn": (i32, [vp, vp, i32, vp, i32, vp, vp, vp, vp, f32, vp, i32, i32, i32, f32, vp]),
     "dy_conv_wgrad_bias": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_wgrad_reduce_desc_bias": (i32, [vp, vp, vp, i32]),
@@ -144,6 +147,8 @@ SIGNATURES = {
     "dy_loss_workspace_layout": (i32, [i32, i32, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     "dy_detection_loss": (i32, [C.POINTER(DyLossArgs), vp]),
     "dy_tal_assign": (i32, [vp, ip, ip, C.POINTER(f32), i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dy_head_infer_supported": (i32, [i32, i32, i32, i32]),
+    "dy_head_infer_levels": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "dy_decode_predictions": (i32, [vp, vp, ip, ip, C.POINTER(f32), i32, i32, i32, i32, vp, vp]),
     "dy_nms_candidates": (i32, [vp, i32, i32, i32, f32, i32, vp, i32, vp, vp, vp, vp, i32, vp]),
     "dy_nms_presort_workspace": (sz, [i32, i32]),

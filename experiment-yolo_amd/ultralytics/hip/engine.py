@@ -85,6 +85,9 @@ BN_GROUP = BN_ACC and os.environ.get("DY_BN_GROUP", "1") != "0"
 # Detect's levels as BRANCHES of the recorded step (Engine.branch): the 80x80 / 40x40 levels' conv stacks -- launches that cannot fill
 # the chip -- are recorded on side streams and run beside the 160x160 level's, forward and backward (DY_HEAD_STREAMS=0: one stream).
 HEAD_STREAMS = os.environ.get("DY_HEAD_STREAMS", "0") != "0"
+# Fused (eval) models: Bottleneck's shortcut added in the epilogue of the conv in front of it (dy_conv_forward_res) instead of by a
+# dy_add launch.  DY_CONV_RES=0: the launch pair.
+CONV_RES = os.environ.get("DY_CONV_RES", "1") != "0"
 HEAD_APPLY = HEAD_DECODE and os.environ.get("DY_SILU_FAST", "1") != "0" and os.environ.get("DY_HEAD_APPLY", "1") != "0"
 BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
 BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
@@ -636,6 +639,17 @@ class Engine:
             if (self.training and STEM_DIRECT and spec.acc_f is not None and (spec.cin, spec.cout, spec.ks, spec.stride) == (3, 16, 3, 2)
                     and spec.act == DY_ACT_SILU and res is None and spec.ld is None):
                 return self._stem_direct(spec, x, out)
+            if not self.training and self.tape is None and STEM_DIRECT and self._stem_eval_ok(spec, res):
+                # eval, un-fused: the raw conv from the image batch itself, then BatchNorm with running statistics as for any Conv
+                Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+                raw = self.new_act(x.N, Ho, Wo, spec.cout)
+                y = out if out is not None else self.new_act(x.N, Ho, Wo, spec.cout)
+                bn = spec.bn
+                self.call("dy_stem_forward_eval", x.img.data_ptr(), spec.weight.data_ptr(), 0, raw.ptr, raw.ld, x.N, x.H, x.W, x.mul, 0)
+                self.call("dy_bn_eval_coef", bn["weight"].data_ptr(), bn["bias"].data_ptr(), bn["running_mean"].data_ptr(),
+                          bn["running_var"].data_ptr(), spec.coef.data_ptr(), spec.cout, spec.bn_eps)
+                self.call("dy_bn_act_apply", raw.ptr, raw.ld, 0, 0, y.ptr, y.ld, spec.coef.data_ptr(), y.npix, spec.cout, spec.act)
+                return y
             x = x.materialize()
         assert x.C == spec.cin_phys, (spec.name, x.C, spec.cin_phys)
         Ho, Wo = self.out_hw(spec, x)
@@ -677,6 +691,10 @@ class Engine:
         if self.tape is not None:
             self.tape.append(lambda: self._conv_bn_act_bwd(spec, x, raw, y, res))
         return y
+
+    @staticmethod
+    def _stem_eval_ok(spec, res):
+        return (spec.cin, spec.cout, spec.ks, spec.stride) == (3, 16, 3, 2) and res is None and spec.ld is None
 
     def _stem_direct(self, spec, x: ImageAct, out=None):
         """model.0 from the image batch itself (csrc/stem.hip): forward conv + statistics, the usual apply; backward = the usual
@@ -918,9 +936,23 @@ class Engine:
 
     def conv_fused(self, spec: ConvSpec, x: Act, out: Act | None = None, res: Act | None = None):
         """Conv.forward_fuse (reference nn/modules/conv.py:57-59): BN folded into weights + bias, SiLU in the epilogue."""
+        if isinstance(x, ImageAct):
+            if STEM_DIRECT and self._stem_eval_ok(spec, res) and spec.bias is not None:  # the fused stem from the image batch itself
+                Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+                y = out if out is not None else self.new_act(x.N, Ho, Wo, spec.cout)
+                self.call("dy_stem_forward_eval", x.img.data_ptr(), spec.weight.data_ptr(), spec.bias.data_ptr(), y.ptr, y.ld, x.N, x.H, x.W,
+                          x.mul, 1 if spec.act == DY_ACT_SILU else 0)
+                return y
+            x = x.materialize()
         Ho, Wo = self.out_hw(spec, x)
         y = out if out is not None else self.new_act(x.N, Ho, Wo, spec.cout)
         epi = DY_EPI_BIAS | (DY_EPI_SILU if spec.act == DY_ACT_SILU else 0)
+        if (res is not None and CONV_RES and spec.act == DY_ACT_SILU and spec.ld is None
+                and self.L.dy_conv_res_supported(x.C, spec.cout, spec.ks, spec.stride)):
+            # Bottleneck's shortcut rides on the conv's epilogue (same bits as the store + dy_add pair)
+            self.call("dy_conv_forward_res", x.ptr, x.ld, spec.wpack.data_ptr(), spec.bias.data_ptr(), res.ptr, res.ld, y.ptr, y.ld,
+                      x.N, x.H, x.W, x.C, spec.cout, spec.ks, spec.stride)
+            return y
         self._conv_raw(spec, x, y.ptr, y.ld, epi, 0, spec.bias)
         if res is not None:
             self.call("dy_add", y.ptr, y.ld, res.ptr, res.ld, 0, 0, y.ptr, y.ld, y.npix, y.C)
@@ -1060,6 +1092,7 @@ class Engine:
         self.pending_decode.append((spec, x, rows_level))
         self.tape.append(lambda: self._conv_bias_bwd(spec, x, dy_ptr_fn, rows_level=rows_level))
 
+    infer_head = False  # set by InferPlan around an eval forward: Detect leaves its final convs + decode to dy_head_infer_levels
     pending_decode = None
     rows_used = None   # set() while a StepPlan traces its forward: the detection levels whose box conv can take the rows form
     loss_rows = None   # (assignment pointer, anchors per image, first anchor of each level) once the plan has bound the loss

@@ -23,6 +23,8 @@ class HeadOut:
         self.box, self.cls, self.nc, self.strides = box, cls, nc, strides
         self.dbox = self.dcls = None
         self.fill_box = None  # inside a StepPlan trace the box logits are not written (dy_head_box_decode); callable that writes them
+        self.infer = None     # eval forward with the fused inference tail (Detect._infer_tail): callable -> y (B, 4+nc, A); box / cls
+                              # hold None until somebody asks for the logits (materialize)
 
     def materialize(self):
         """Write the box logits if the forward left them out (the recorded training step never reads them): an eager launch of the
@@ -93,9 +95,54 @@ class Detect(HipModule):
             a[-1].bias.data[:] = 1.0
             b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / s) ** 2)
 
+    def _infer_tail(self, xs):
+        """Eval forward asked for by an InferPlan (``eng.infer_head``): the conv stacks of every level, then NOTHING -- the two final
+        convs, the DFL decode and the sigmoid are one dy_head_infer_levels launch (``ho.infer()``) that the caller issues with a fresh
+        output tensor per call; the fp32 logits are only written when somebody asks for them (``ho.materialize()``)."""
+        import ctypes as C
+        rt, eng = self.rt, self.rt.eng
+        n, nb, ncp = len(xs), 4 * self.reg_max, (self.nc + 7) // 8 * 8
+        bsp = [rt.specs[(id(self), "cv2", l)] for l in range(n)]
+        csp = [rt.specs[(id(self), "cv3", l)] for l in range(n)]
+        if not (len({(sp.cin, sp.cout) for sp in csp}) == 1 and all(sp.ks == 1 and sp.ld is None and sp.bias is not None for sp in bsp + csp)
+                and all(eng.L.dy_head_infer_supported(sp.cin, sp.cout, csp[0].cin, self.nc) for sp in bsp)):
+            return None
+        a = [self.cv2[l][1].forward_act(self.cv2[l][0].forward_act(x)) for l, x in enumerate(xs)]
+        c = [self.cv3[l][1].forward_act(self.cv3[l][0].forward_act(x)) for l, x in enumerate(xs)]
+        ho = HeadOut([None] * n, [None] * n, self.nc, [float(s) for s in self.stride])
+        B, A, dev = xs[0].N, sum(x.H * x.W for x in xs), eng.device
+        P, I, F = C.c_void_p, C.c_int, C.c_float
+        args = (n, eng._arr(P, [t.ptr for t in a]), eng._arr(I, [t.ld for t in a]), eng._arr(P, [sp.weight.data_ptr() for sp in bsp]),
+                eng._arr(P, [sp.bias.data_ptr() for sp in bsp]), eng._arr(P, [t.ptr for t in c]), eng._arr(I, [t.ld for t in c]),
+                eng._arr(P, [sp.weight.data_ptr() for sp in csp]), eng._arr(P, [sp.bias.data_ptr() for sp in csp]),
+                eng._arr(I, [x.H for x in xs]), eng._arr(I, [x.W for x in xs]), eng._arr(F, ho.strides), B, csp[0].cin, self.nc)
+
+        def infer(y=None):
+            from ...hip import check
+            if y is None:
+                y = torch.empty((B, 4 + self.nc, A), dtype=torch.float32, device=dev)
+            check(eng.L.dy_head_infer_levels(*args, y.data_ptr(), eng.stream), "dy_head_infer_levels")
+            return y
+
+        def fill():  # the logits themselves, for callers that index the per-level feature maps (reference head.py:74 returns them too)
+            from ...hip import DY_EPI_BIAS, DY_EPI_F32OUT
+            assert eng.rec is None, "logits can only be materialised outside a trace"
+            for l, x in enumerate(xs):
+                if ho.box[l] is None:
+                    ho.box[l] = torch.empty((x.N, x.H, x.W, nb), dtype=torch.float32, device=dev)
+                    ho.cls[l] = torch.zeros((x.N, x.H, x.W, ncp), dtype=torch.float32, device=dev)
+                eng._conv_raw(bsp[l], a[l], ho.box[l].data_ptr(), nb, DY_EPI_BIAS | DY_EPI_F32OUT, 0, bsp[l].bias)
+                eng._conv_raw(csp[l], c[l], ho.cls[l].data_ptr(), ncp, DY_EPI_BIAS | DY_EPI_F32OUT, 0, csp[l].bias)
+        ho.infer, ho.fill_box = infer, fill
+        return ho
+
     def forward_act(self, xs, out=None):
         rt = self.rt
         eng = rt.eng
+        if eng.infer_head and eng.tape is None and not eng.training:
+            ho = self._infer_tail(xs)
+            if ho is not None:
+                return ho
         ncp = (self.nc + 7) // 8 * 8
         nb = 4 * self.reg_max
         boxes = [eng.transient((x.N, x.H, x.W, nb), torch.float32) for x in xs]
@@ -190,6 +237,8 @@ class Detect(HipModule):
             if self.training:
                 return y.as_reference_list()
             from ...utils.ops import decode_predictions
+            if y.infer is not None:
+                return y.infer(), LazyFeats(y)
             # (y, x) like the reference's inference return (head.py:74); the per-level (B, no, H, W) maps are re-formatted from
             # the NHWC head outputs only when somebody indexes them
             return decode_predictions(y), LazyFeats(y)

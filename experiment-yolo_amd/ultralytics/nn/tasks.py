@@ -146,6 +146,12 @@ class BaseModel(HipModule):
         return self.predict(x, *args, **kwargs)
 
     def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
+        """Reference tasks.py:67-83.  In eval mode a detection model's forward of a (B, 3, H, W) device tensor goes through the
+        inference plan of its geometry (hip/infer.py: recorded launch list / hipGraph, stem from the image batch, fused Detect tail)."""
+        if not self.training:
+            from ..hip.infer import forward_eval, wants_plan
+            if wants_plan(self, x):
+                return forward_eval(self, x)
         return HipModule.forward(self, x)
 
     def _concat_plan(self):
@@ -476,7 +482,7 @@ def reference_module_copy(model):
     reference re-registers it only when it builds the module itself."""
     stash = {}
     for m in model.modules():
-        stash[m] = {k: m.__dict__.pop(k) for k in ("rt", "_pn_i32") if k in m.__dict__}
+        stash[m] = {k: m.__dict__.pop(k) for k in ("rt", "_pn_i32", "_infer_plans", "_ag_plans", "_ag_anchor") if k in m.__dict__}
     try:
         cp = deepcopy(model)
     finally:

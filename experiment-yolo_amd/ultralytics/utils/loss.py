@@ -156,6 +156,7 @@ class v8DetectionLoss:
         from ..nn.modules.head import HeadOut
         if not isinstance(preds, HeadOut):
             preds = self._headout_from_reference(preds)
+        preds.materialize()  # a forward that left its logits out (fused decode in a recorded step / the fused inference tail) writes them now
         pub = self.__dict__.get("_pub")
         if pub is None:
             pub = object.__new__(type(self))

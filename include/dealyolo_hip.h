@@ -77,6 +77,12 @@ int dy_conv_num_partials(int n, int h, int w, int cin, int cout, int ks, int str
  * Conv's BatchNorm backward (sums of g = dx * silu'(raw*scale+shift) and g*xhat over the pixels, dy_bn_act_bwd_reduce_acc) runs in
  * the epilogue on the values being stored and is added into acc [DY_BN_COPIES][2][C].  C == cout; dy_conv_red_supported(cin, cout, ks)
  * tells whether the geometry has this form (else DY_ERR_ARG). */
+/* Conv.forward_fuse followed by Bottleneck's shortcut add (nn/modules/conv.py:57-59, nn/modules/block.py:333-335) in one launch:
+ * y = fp16(fp16(SiLU(conv(x) + bias)) + res), the bits of dy_conv_forward(DY_EPI_BIAS | DY_EPI_SILU) followed by dy_add.  3x3 stride-1
+ * convolutions the ping-pong kernel takes (dy_conv_res_supported); res: fp16 (N, Ho, Wo, ldres). */
+int dy_conv_res_supported(int cin, int cout, int ks, int stride);
+int dy_conv_forward_res(const void* x, int ldx, const void* w_packed, const float* bias, const void* res, int ldres, void* y, int ldy,
+                        int n, int h, int w, int cin, int cout, int ks, int stride, hipStream_t stream);
 int dy_conv_red_supported(int cin, int cout, int ks);
 int dy_conv_input_grad_red(const void* dy, int lddy, const void* w_packed_t, void* dx, int lddx, int n, int h, int w, int cin, int cout,
                            int ks, const void* raw, int ldraw, const float* coef, double* acc, int C, hipStream_t stream);
@@ -111,6 +117,11 @@ int dy_conv_wgrad_ld_bn(const void* x, int ldx, const void* dy, int lddy, const 
 int dy_stem_grid(int n, int h, int w);
 int dy_stem_forward(const float* img_nchw, const float* weight, void* raw, int ldraw, double* acc, int n, int h, int w, float mul,
                     hipStream_t stream);
+/* The same stem in eval mode (Conv.forward_fuse, nn/modules/conv.py:57-59; get_FPS.py:49 fuses the model before timing it):
+ * y = act(conv(img * mul) + bias) as fp16 NHWC, no statistics.  bias NULL: none (un-fused eval: BatchNorm with running statistics follows
+ * as its own pass); silu 0: no activation. */
+int dy_stem_forward_eval(const float* img_nchw, const float* weight, const float* bias, void* y, int ldy, int n, int h, int w, float mul,
+                         int silu, hipStream_t stream);
 int dy_stem_wgrad_bn(const float* img_nchw, const void* dy, int lddy, const void* raw, int ldraw, const float* coef,
                      const double* acc, float* dgamma, float* dbeta, float count, float* slabs, int n, int h, int w, float mul,
                      hipStream_t stream);
@@ -352,6 +363,15 @@ int dy_tal_assign(const float* const* scores, const int* H, const int* W, const 
 
 /* ---- Detect inference decode nn/modules/head.py:50-74 (+ DFL nn/modules/block.py:52-55, dist2bbox utils/tal.py:310-318)
  *      -> y (B, 4+nc, A) fp32 [xywh pixels, sigmoid class scores] ------------------------------------------------- */
+/* The whole inference tail of Detect in ONE launch (nn/modules/head.py:50-74 `_inference` with its two final convs head.py:38-42):
+ * per level l the box conv Conv2d(64, 64, 1) over x_box[l] and the class conv Conv2d(cin_cls, nc, 1) over x_cls[l] (fp16 NHWC, the
+ * activated outputs of cv2[l][1] / cv3[l][1]; fp32 master weights (cout, cin) + bias), DFL expectation, dist2bbox(xywh) * stride and
+ * sigmoid, written straight as y (B, 4+nc, A): no fp32 logits are written or re-read.  Same bits as dy_conv_forward (fp32 out + bias)
+ * followed by dy_decode_predictions.  dy_head_infer_supported: 64 -> 64 box conv, nc <= 80, cin_cls a multiple of 16 up to 128. */
+int dy_head_infer_supported(int cin_box, int cout_box, int cin_cls, int nc);
+int dy_head_infer_levels(int nl, const void* const* x_box, const int* ld_box, const float* const* w_box, const float* const* b_box,
+                         const void* const* x_cls, const int* ld_cls, const float* const* w_cls, const float* const* b_cls, const int* h,
+                         const int* w, const float* stride, int n, int cin_cls, int nc, float* y, hipStream_t stream);
 int dy_decode_predictions(const float* const* box, const float* const* cls, const int* H, const int* W,
                           const float* stride, int nl, int B, int nc, int ncp, float* y, hipStream_t stream);
 /* ---- ops.non_max_suppression utils/ops.py:292-427: candidate extraction (:344-392, order-preserving) ... */
