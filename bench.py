@@ -7,12 +7,16 @@ A "step" is one full training iteration of DEAL-YOLO-N (yolov8n-ASF-P2P2) at 640
 configs[1]): image import, forward, detection loss (TAL + CIoU + DFL + BCE), hand-written backward, gradient all-reduce
 (RCCL, N>1), SGD-nesterov + EMA -- all through libdealyolo_hip.so.  Inputs are synthetic and already resident in HBM.
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     the kernel with the largest total time per step among ALL launches (whatever it is): the bytes its launch cannot
-               avoid (operands read once + results written once at fp16; for a convolution that IS SURVEY.md 8(d)'s algorithmic
-               bytes) / its average launch duration, measured live with HIP events on the launch stream, against 8 TB/s HBM;
-               `traffic` = its PMC HBM bytes per launch from profiles/; `step` = the whole step priced by 8(d) alone, where
-               BatchNorm / activation passes count as fused away = 0 bytes (images/s x 367 MB / 8 TB/s);
-               `top_conv` = the most expensive convolution instantiation, for comparison with earlier rounds;
+  roofline     SURVEY.md 8(d) throughout: `achieved` / `frac` = ALGORITHMIC bytes per launch / average launch duration of the dominant
+               kernel -- the kernel group with the largest total time per step among the launches that have algorithmic bytes
+               (convolutions: forward, input gradient, weight gradient, stem) -- measured live with HIP events on the launch stream,
+               against 8 TB/s HBM; `traffic` = its PMC HBM bytes per launch from profiles/; `step` = the whole step priced the same
+               way (images/s x 367 MB / 8 TB/s; BatchNorm / activation passes count as fused away = 0 bytes);
+               `dominant_launch` = the kernel group with the largest total time among ALL launches (a BatchNorm pass: 0 algorithmic
+               bytes) priced with the bytes its launch cannot avoid (`own_frac`) -- what the top level carried in round 3;
+  config.secondary  BASELINE.json configs[3] and configs[4] timed in the same run: the LD model's training step (images/s) and
+               yolov8n-p2 fused inference at 1280x1280, batch 32 (get_FPS.py's protocol shortened: 20 + 100 forwards), each with its
+               8(d) step fraction;
   cpu_baseline the CPU oracle (a port of the reference's PyTorch CPU path) timed on the host cores in BASELINE.md section 2's protocol
                (bs=2, median of 8 steps after 2 warm-up); `bs16` = the same at bs=16 (about 25 s of CPU work: the bounded sample).
 --loss ciou|wiou|ciou+nwd|wiou+nwd selects the box loss: the default is the north-star's wiou+nwd; the reference-default ciou rate is
@@ -40,6 +44,78 @@ CFG = os.path.join(ROOT, "experiment-yolo_amd", "ultralytics", "cfg", "models", 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes per image of one TRAINING step (3 x forward conv in+out at fp16), by model YAML stem
 ALG_BYTES_PER_IMAGE = {"yolov8n-ASF-P2P2": 367.1e6, "yolov8n-LD-P2": 407.8e6, "yolov8n-ASF-P2": 392.1e6}
+P2_1280_FWD_BYTES_PER_IMAGE = 528.0e6  # yolov8n-p2 forward at 1280x1280 (conv in + out at fp16)
+
+
+def secondary_ld(dev, steps=10):
+    """BASELINE.json configs[3]: yolov8n-LD-P2 (LDConv-heavy) training step, 640x640, batch 64 -- the same StepPlan protocol as the
+    headline (hipGraph, loss-scale search settled before the timed steps)."""
+    from ultralytics.hip.train import StepPlan
+    from ultralytics.nn.tasks import DetectionModel
+    torch.manual_seed(0)
+    model = DetectionModel(os.path.join(os.path.dirname(CFG), "yolov8n-LD-P2.yaml"), verbose=False).to(dev).train()
+    with torch.no_grad():  # zero-initialised p_conv weights (reference conv.py:357) would make every offset identical
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("p_conv.weight"):
+                p_.normal_(0, 0.02)
+    for k, v in model.named_parameters():
+        v.requires_grad = ".dfl" not in k
+    plan = StepPlan(model, 64, 640, nmax=8, optimizer="SGD", use_graph=True)
+    plan.crit.bbox_loss.use_wiseiou, plan.crit.bbox_loss.nwd_loss = True, True
+    batch = {k: v.to(dev) for k, v in synth_batch(7, 64, 640, 6).items()}
+    plan.img.copy_(batch["img"])
+    batch["img"] = plan.img
+
+    def one():
+        plan.set_hyper([0.01] * 3, 0.937, [0.0, 0.0005, 0.0])
+        plan.forward_backward(batch)
+        plan.optimizer_step()
+
+    for _ in range(3):
+        one()
+    still, last, n = 0, float(plan.state[6]), 0
+    while still < 6 and n < 60:
+        one()
+        n += 1
+        now = float(plan.state[6])
+        still, last = (still + 1, last) if now == last else (0, now)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    plan.check_progress()
+    rate = 64 / dt
+    return {"workload": "yolov8n-LD-P2 train step 640x640 batch 64 (BASELINE.json configs[3]), wiou+nwd, hipGraph", "images_per_s": rate,
+            "ms_per_step": dt * 1e3, "steps": steps, "algorithmic_bytes_per_image": ALG_BYTES_PER_IMAGE["yolov8n-LD-P2"],
+            "step_frac": rate * ALG_BYTES_PER_IMAGE["yolov8n-LD-P2"] / 1e9 / HBM_PEAK_GBS}
+
+
+def secondary_p2_1280(dev, warmup=20, iters=100):
+    """BASELINE.json configs[4]: yolov8n-p2 (nc 80) fused inference at 1280x1280, batch 32, get_FPS.py's protocol (reference
+    get_FPS.py:42-87: fuse, warm-up forwards, then forwards timed one by one with a synchronisation after each) shortened from
+    200 + 1000 to 20 + 100 forwards; no NMS, as there."""
+    from ultralytics import YOLO
+    torch.manual_seed(0)
+    model = YOLO("yolov8n-p2.yaml").model.to(dev).eval()
+    model.fuse()
+    x = torch.rand(32, 3, 1280, 1280, device=dev)
+    ts = []
+    with torch.no_grad():
+        for _ in range(warmup):
+            model(x)
+        torch.cuda.synchronize()
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            model(x)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+    t = float(np.mean(ts))
+    fps = 32 / t
+    return {"workload": "yolov8n-p2 (nc 80) fused inference 1280x1280 batch 32 (BASELINE.json configs[4]), get_FPS.py protocol 20 + 100 forwards, no NMS",
+            "fps": fps, "ms_per_forward": t * 1e3, "latency_ms_per_image": t / 32 * 1e3, "algorithmic_bytes_per_image": P2_1280_FWD_BYTES_PER_IMAGE,
+            "step_frac": fps * P2_1280_FWD_BYTES_PER_IMAGE / 1e9 / HBM_PEAK_GBS}
 
 
 def synth_batch(seed, B, imgsz, nc, n_per=8):
@@ -122,6 +198,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="capture the step into hipGraphs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--probe", type=int, default=1, help="time the dominant kernel with HIP events")
+    ap.add_argument("--secondary", type=int, default=1, help="also time BASELINE configs[3] (LD train) and configs[4] (p2 1280 inference)")
     ap.add_argument("--model", default="yolov8n-ASF-P2P2", help="model YAML stem (yolov8n-LD-P2 = BASELINE.json configs[3])")
     ap.add_argument("--lr", type=float, default=0.01, help="learning rate of the three parameter groups (timing does not depend on it; "
                     "tiny test configurations pass a smaller one so that no step overflows)")
@@ -241,7 +318,8 @@ def main():
             plan.crit.sync_modes()
             plan.graph_fb = g_fb
 
-    roof = None
+    roof = breakdown = None
+    scalars_last, loss_scale, skipped_total = plan.crit.scalars.cpu(), float(plan.state[0]), float(plan.state[6])
     if rank == 0 and a.probe:
         pr = plan.probe_dominant_kernel(batch, reps=max(5, min(a.steps, 20)))
         if pr:
@@ -256,25 +334,41 @@ def main():
 
             alg = ALG_BYTES_PER_IMAGE.get(a.model)
             step_gbs = value * alg / 1e9 if alg else None
-            tc = pr["top_conv"]
-            roof = {"bound": "hbm", "achieved": pr["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pr["gbs"] / HBM_PEAK_GBS,
-                    "traffic": traffic(pr["kernel"]), "kernel": pr["kernel"], "avg_us": pr["us"], "bytes_per_launch": pr["bytes"],
-                    "bytes_definition": "each operand of the launch read once + each result written once at fp16 (for a convolution this IS "
-                                        "SURVEY.md 8(d)'s algorithmic bytes; 8(d) prices a BatchNorm/activation pass at 0 -- the step figure below does)",
-                    "algorithmic_bytes_per_launch_8d": pr["algorithmic_bytes"],
-                    "launches_per_step": pr["launches_per_step"], "ms_per_step": pr["ms_per_step"],
+            tc, ta = pr["top_conv"], pr["top_alg"]
+            roof = {"bound": "hbm", "achieved": ta["alg_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ta["alg_gbs"] / HBM_PEAK_GBS,
+                    "traffic": traffic(ta["kernel"]), "kernel": ta["kernel"], "avg_us": ta["us"], "bytes_per_launch": ta["algorithmic_bytes"],
+                    "bytes_definition": "SURVEY.md 8(d) algorithmic bytes (layer input read once + output written once at fp16) per launch of the "
+                                        "DOMINANT ALGORITHMIC KERNEL: the kernel group with the largest total time per step among the launches that "
+                                        "have algorithmic bytes (convolution forward / input gradient / weight gradient / stem); BatchNorm and "
+                                        "activation passes are priced at 0 by 8(d) -- the group that is largest among ALL launches is under "
+                                        "dominant_launch with its own least traffic, the whole step under step",
+                    "launches_per_step": ta["launches_per_step"], "ms_per_step": ta["ms_per_step"],
                     "step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS if step_gbs else None, "unit": "GB/s",
                              "algorithmic_bytes_per_image": alg, "device_ms_sum_of_launches": pr["step_device_ms"],
                              "traffic_bytes_per_step": tj.get("step_traffic_bytes")},
+                    "dominant_launch": {"kernel": pr["kernel"], "avg_us": pr["us"], "own_bytes_per_launch": pr["bytes"], "own_achieved": pr["gbs"],
+                                        "own_frac": pr["gbs"] / HBM_PEAK_GBS, "algorithmic_bytes_per_launch_8d": pr["algorithmic_bytes"],
+                                        "traffic": traffic(pr["kernel"]), "launches_per_step": pr["launches_per_step"], "ms_per_step": pr["ms_per_step"],
+                                        "own_bytes_definition": "each operand of the launch read once + each result written once at fp16"},
                     "top_conv": None if tc is None else {"kernel": tc["kernel"], "achieved": tc["gbs"], "frac": tc["gbs"] / HBM_PEAK_GBS,
                                                          "avg_us": tc["us"], "bytes_per_launch": tc["bytes"], "traffic": traffic(tc["kernel"]),
                                                          "launches_per_step": tc["launches_per_step"]},
                     "ranking": pr["ranking"]}
+            breakdown = plan.breakdown()
+    secondary = None
+    if rank == 0 and world == 1 and a.secondary and a.model == "yolov8n-ASF-P2P2" and a.batch == 64 and a.imgsz == 640:
+        secondary = {}  # (the headline plan's buffers stay resident: 288 GB hold all three workloads)
+        for key, fn in (("ld_train", secondary_ld), ("p2_1280_infer", secondary_p2_1280)):
+            try:
+                secondary[key] = fn(dev)
+            except Exception as e:  # a secondary figure must never cost the headline line
+                secondary[key] = {"error": f"{type(e).__name__}: {e}"}
+            print(f"[bench] secondary {key}: {secondary[key]}", file=sys.stderr, flush=True)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cpu = cpu_baseline(a.imgsz)
     if rank == 0:
-        s = plan.crit.scalars.cpu()
+        s = scalars_last
         out = {"metric": "images/sec (train) DEAL-YOLO-N 640x640 bs=64/GPU", "value": value, "unit": "images/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f16", "data": "synthetic",
@@ -283,9 +377,9 @@ def main():
                           "loss_mode": a.loss, f"{other.replace('+', '_')}_images_per_s": other_rate,
                           "settle_steps": settle, "skipped_in_timed_steps": skipped_timed, "timed_regions_discarded": retimed,
                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
-                          "loss_items_last": [float(x) for x in s[5:8]], "loss_scale": float(plan.state[0]),
-                          "skipped_steps": float(plan.state[6]),
-                          "device_ms_by_call": plan.breakdown() if roof else None},
+                          "loss_items_last": [float(x) for x in s[5:8]], "loss_scale": loss_scale,
+                          "skipped_steps": skipped_total,
+                          "device_ms_by_call": breakdown, "secondary": secondary},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:

@@ -11,6 +11,8 @@
 // accumulator + bias, softmax / expectation / box arithmetic in decode_pred_kernel's association (csrc/nms.hip), libm expf.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "dealyolo_hip.h"
 
@@ -234,8 +236,11 @@ extern "C" int dy_head_infer_levels(int nl, const void* const* x_box, const int*
   for (int l = 0; l < nl; ++l) {
     if (!x_box[l] || !x_cls[l] || !w_box[l] || !b_box[l] || !w_cls[l] || !b_cls[l] || h[l] < 1 || w[l] < 1) return DY_ERR_ARG;
     if ((ld_box[l] & 7) || (ld_cls[l] & 7) || ((uintptr_t)x_box[l] & 15) || ((uintptr_t)x_cls[l] & 15)) return DY_ERR_ALIGN;
+    // persistent-ish: every workgroup first stages both weight sets as fp16 (4,096 + nc x cin fp32 loads), so a few long-lived workgroups per
+    // CU beat one per 256 pixels (DY_HEAD_INFER_WGS: the cap per level)
+    static const int cap = getenv("DY_HEAD_INFER_WGS") ? atoi(getenv("DY_HEAD_INFER_WGS")) : 512;  // 4096 / 2048 / 1024 / 512 / 256: 768 / 708 / 673 / 656 / 840 us at 1280x1280, batch 32, nc 80
     long blocks = ((long)n * h[l] * w[l] + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > cap) blocks = cap;
     g.lv[l] = HeadInferLevel{(const f16*)x_box[l], (const f16*)x_cls[l], w_box[l], b_box[l], w_cls[l], b_cls[l], ld_box[l], ld_cls[l],
                              h[l], w[l], a0, (int)blocks, stride[l]};
     a0 += h[l] * w[l];

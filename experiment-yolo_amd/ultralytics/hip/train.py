@@ -732,6 +732,15 @@ class StepPlan:
         top = summary(rank[0])
         convs = [k for k in rank if k.startswith("conv_")]
         top["top_conv"] = summary(convs[0]) if convs else None
+        # the dominant kernel in SURVEY.md 8(d)'s sense: the group with the largest total time among the launches that HAVE algorithmic
+        # bytes (convolutions: forward, input gradient, weight gradient, stem); priced with those bytes alone
+        algs = [k for k in rank if sum(t[1] for t in groups[k]) > 0]
+        if algs:
+            ta = summary(algs[0])
+            ta["alg_gbs"] = ta["algorithmic_bytes"] / (ta["us"] * 1e-6) / 1e9 if ta["us"] > 0 else 0.0
+            top["top_alg"] = ta
+        else:
+            top["top_alg"] = None
         top["ranking"] = [{"kernel": k, "ms_per_step": round(sum(t[0] for t in groups[k]), 4), "launches": len(groups[k]),
                            "algorithmic_MB_per_step": round(sum(t[1] for t in groups[k]) / 1e6, 1),
                            "own_MB_per_step": round(sum(t[2] for t in groups[k]) / 1e6, 1)} for k in rank[:12]]
