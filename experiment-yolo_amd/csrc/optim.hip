@@ -77,7 +77,9 @@ struct StepArgs {
   float* ema; // may be null
   const float* hyper;
   float* state;
-  long n, g0_end, g1_end;  // group boundaries: [0,g0_end) bias, [g0_end,g1_end) decayed weights, rest norm weights
+  long n;
+  long b[5];  // ends of the first five of six segments; segment k holds optimizer group k % 3 (bias, decayed weights, norm weights):
+              // [neck + head: g0 | g1 | g2][backbone: g0 | g1 | g2] -- or, from dy_optimizer_step, [g0 | g1 | g2] and three empty ones
   const uint8_t* frozen;   // optional per-element mask (1 = requires_grad False)
   int adam;                // 0 SGD-nesterov, 1 Adam (L2 decay), 2 AdamW (decoupled), 3 RMSprop(alpha .99, momentum), 4 RAdam, 5 Adamax, 6 NAdam
 };
@@ -88,7 +90,8 @@ __global__ __launch_bounds__(256) void optim_step_kernel(StepArgs a) {
   const float mom = a.hyper[3], d = a.hyper[7];
   const bool first = a.state[5] == 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256) {
-    const int grp = i < a.g0_end ? 0 : (i < a.g1_end ? 1 : 2);
+    const int seg = (i >= a.b[0]) + (i >= a.b[1]) + (i >= a.b[2]) + (i >= a.b[3]) + (i >= a.b[4]);
+    const int grp = seg >= 3 ? seg - 3 : seg;
     float p = a.p[i];
     if (found == 0.f && !(a.frozen && a.frozen[i])) {
       const float lr = a.hyper[grp], wd = a.hyper[4 + grp];
@@ -184,15 +187,35 @@ __global__ __launch_bounds__(256) void ema_buffers_kernel(const float* s, float*
   }
 }
 
+static int optimizer_step_impl(float* params, const float* grads, float* mom, float* adam_v, float* ema, long n, const long* b5,
+                               const unsigned char* frozen, const float* buffers, float* ema_buffers, long n_buffers, const float* hyper,
+                               float* state, float* partials, int mode, hipStream_t stream);
 extern "C" int dy_optimizer_step(float* params, const float* grads, float* mom, float* adam_v, float* ema, long n,
                                  long g0_end, long g1_end, const unsigned char* frozen, const float* buffers,
                                  float* ema_buffers, long n_buffers, const float* hyper, float* state,
                                  float* partials, int mode, hipStream_t stream) {
+  const long b5[5] = {g0_end, g1_end, n, n, n};
+  return optimizer_step_impl(params, grads, mom, adam_v, ema, n, b5, frozen, buffers, ema_buffers, n_buffers, hyper, state, partials, mode, stream);
+}
+// The same step over a flat buffer laid out in SIX segments [bucket A: g0 | g1 | g2][bucket B: g0 | g1 | g2] (seg_ends: the ends of
+// the first five): the layout that makes each data-parallel gradient bucket ONE contiguous slice (hip/runtime.py; reference
+// engine/trainer.py:694-695: DDP's reducer works on contiguous buckets).
+extern "C" int dy_optimizer_step_seg(float* params, const float* grads, float* mom, float* adam_v, float* ema, long n, const long* seg_ends,
+                                     const unsigned char* frozen, const float* buffers, float* ema_buffers, long n_buffers,
+                                     const float* hyper, float* state, float* partials, int mode, hipStream_t stream) {
+  if (!seg_ends) return DY_ERR_ARG;
+  for (int k = 0; k < 5; ++k)
+    if (seg_ends[k] < (k ? seg_ends[k - 1] : 0) || seg_ends[k] > n) return DY_ERR_ARG;
+  return optimizer_step_impl(params, grads, mom, adam_v, ema, n, seg_ends, frozen, buffers, ema_buffers, n_buffers, hyper, state, partials, mode, stream);
+}
+static int optimizer_step_impl(float* params, const float* grads, float* mom, float* adam_v, float* ema, long n, const long* b5,
+                               const unsigned char* frozen, const float* buffers, float* ema_buffers, long n_buffers, const float* hyper,
+                               float* state, float* partials, int mode, hipStream_t stream) {
   if (n <= 0 || mode < 0 || mode > 6 || (mode > 0 && !adam_v)) return DY_ERR_ARG;
   int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(grad_sumsq_kernel, dim3(blocks), dim3(256), 0, stream, grads, n, partials);
   hipLaunchKernelGGL(grad_norm_final_kernel, dim3(1), dim3(256), 0, stream, partials, blocks, hyper, state);
-  StepArgs a{params, grads, mom, adam_v, ema, hyper, state, n, g0_end, g1_end, frozen, mode};
+  StepArgs a{params, grads, mom, adam_v, ema, hyper, state, n, {b5[0], b5[1], b5[2], b5[3], b5[4]}, frozen, mode};
   hipLaunchKernelGGL(optim_step_kernel, dim3(blocks), dim3(256), 0, stream, a);
   int b2 = (int)((n_buffers + 255) / 256);
   if (b2 < 1) b2 = 1;

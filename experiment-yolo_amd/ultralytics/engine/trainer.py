@@ -116,10 +116,13 @@ class DetectionTrainer:
             if self.opt_name in ("SGD", "RMSProp"):  # reference :791 ``if "momentum" in x``: only these param groups have the key;
                 mom = float(np.interp(ni, xi, [a.warmup_momentum, self.momentum]))  # Adam-family / SOAP betas are never warmed up
         p.set_hyper(lr, mom, [0.0, self.wd, 0.0])
+        # (gradient buckets: the early all-reduce sums the gradient buffer in place, so it may only start when this micro-batch is
+        # the whole optimizer step)
+        alone = not (self.accumulate > 1 or acc > 1 or p._micro) and ni - self.last_opt_step >= acc
         if a.multi_scale:
-            self._forward_backward_rescaled(batch)
+            self._forward_backward_rescaled(batch, exchange=alone)
         else:
-            self._plan_for(batch).forward_backward(batch)  # writes the shared flat gradient buffer; everything below is the main plan's
+            self._plan_for(batch).forward_backward(batch, exchange=alone)  # writes the shared flat gradient buffer; everything below is the main plan's
         if self.accumulate > 1 or acc > 1 or p._micro:
             p.accumulate()
         if ni - self.last_opt_step >= acc:
@@ -140,7 +143,7 @@ class DetectionTrainer:
         return fb
 
     # ---- multi_scale (reference models/yolo/detect/train.py:60-73) ---------------------------------------------------------------
-    def _forward_backward_rescaled(self, batch):
+    def _forward_backward_rescaled(self, batch, exchange=True):
         """``preprocess_batch`` with ``multi_scale=True``: every batch is bilinearly re-interpolated to a random multiple of the grid
         size in [0.5, 1.5] x imgsz before the step.  A recorded launch list has one input size, so each size gets its own list
         (``input_act`` plans fed through ``x_in``); they all lay their step-local buffers over ONE arena sized for the largest size --
@@ -151,7 +154,7 @@ class DetectionTrainer:
         H, W = base.imgsz
         sf = sz / max(H, W)
         if sf == 1:
-            return base.forward_backward(batch)
+            return base.forward_backward(batch, exchange=exchange)
         ns = tuple(math.ceil(x * sf / gs) * gs for x in (H, W))
         base.stage(batch)
         x = base.import_input()  # eager launch: fp16 NHWC, 8 channels (3 used)
@@ -160,7 +163,7 @@ class DetectionTrainer:
         plan = self._scaled_plan(base, ns)
         img = torch.nn.functional.interpolate(x.st.buf[..., :3].permute(0, 3, 1, 2).float(), size=ns, mode="bilinear", align_corners=False)
         plan.x_in[..., :3].copy_(img.permute(0, 2, 3, 1))
-        return plan.forward_backward(batch)
+        return plan.forward_backward(batch, exchange=exchange)
 
     def _scaled_plan(self, base, ns):
         from ..hip.engine import Arena
@@ -301,9 +304,23 @@ class DetectionTrainer:
         if not isinstance(opt, dict) or "flat" not in opt:
             raise ValueError(f"{path} carries no resumable optimizer state (written by DetectionTrainer.save_model of this package?)")
         p, rt = self.plan, self.plan.rt
-        if list(opt["param_names"]) != list(rt.param_names) or opt["mode"] != p.mode:
-            raise ValueError("the checkpoint's parameter layout / optimizer does not match this model and optimizer")
-        f = opt["flat"]
+        if sorted(opt["param_names"]) != sorted(rt.param_names) or opt["mode"] != p.mode:
+            raise ValueError("the checkpoint's parameters / optimizer do not match this model and optimizer")
+        f = dict(opt["flat"])
+        if list(opt["param_names"]) != list(rt.param_names):
+            # a checkpoint written under another ORDER of the flat parameter buffer (before round 4: [bias | decayed | norm] over the whole
+            # model; now the neck + head in front of the backbone, hip/runtime.py): move every tensor's slice to where it lives now
+            sizes = {n: prm.numel() for n, prm in self.model.named_parameters()}
+            old_off, o = {}, 0
+            for n in opt["param_names"]:
+                old_off[n] = o
+                o += (sizes[n] + 7) // 8 * 8
+            for key in ("p", "ema", "mom", "adam_v"):
+                if key in f:
+                    src, dst = f[key], torch.zeros(rt.n_params_flat, dtype=f[key].dtype)
+                    for n, k in sizes.items():
+                        dst[rt.param_off[n]:rt.param_off[n] + k] = src[old_off[n]:old_off[n] + k]
+                    f[key] = dst
         for dst, key in ((rt.flat_p, "p"), (rt.flat_b, "b"), (p.ema, "ema"), (p.ema_b, "ema_b"), (p.mom, "mom"), (p.state, "state")):
             dst.copy_(f[key])
         if p.adam_v is not None:

@@ -156,6 +156,7 @@ SIGNATURES = {
     "dy_soft_nms": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp]),
     "dy_set_hyper": (i32, [vp, vp, vp]),
     "dy_optimizer_step": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, i64, vp, vp, vp, i32, vp]),
+    "dy_optimizer_step_seg": (i32, [vp, vp, vp, vp, vp, i64, lp, vp, vp, vp, i64, vp, vp, vp, i32, vp]),
     "dy_axpy_f32": (i32, [vp, vp, f32, i64, vp]),
 }
 

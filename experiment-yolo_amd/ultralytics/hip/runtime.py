@@ -46,14 +46,28 @@ class Runtime:
                 full = f"{mname}.{pname}" if mname else pname
                 gi = 0 if "bias" in full else (2 if isinstance(mod, norm_types) else 1)
                 groups[gi].append((full, p))
-        self.param_names = [n for g in groups for n, _ in g]
+        # Six segments [neck + head: bias | decayed | norm][backbone: bias | decayed | norm]: the parameters whose gradients are final
+        # FIRST in the backward pass (everything behind the YAML's backbone) sit in front, so each data-parallel gradient bucket is one
+        # contiguous slice of the flat gradient buffer that RCCL reduces in place (StepPlan, DY_DP_BUCKETS=2; DDP's reducer works on
+        # contiguous buckets too, reference engine/trainer.py:694-695).  A root without a backbone / head split has empty first segments.
+        nb = len(self.root.yaml.get("backbone", [])) if isinstance(getattr(self.root, "yaml", None), dict) else None
+
+        def late(name):
+            parts = name.split(".")
+            return nb is not None and len(parts) > 1 and parts[0] == "model" and parts[1].isdigit() and int(parts[1]) >= nb
+
+        segs = [[(n, p) for n, p in g if late(n)] for g in groups] + [[(n, p) for n, p in g if not late(n)] for g in groups]
+        self.param_names = [n for g in segs for n, _ in g]
+        self.param_group = {n: k % 3 for k, g in enumerate(segs) for n, _ in g}  # optimizer group of every parameter
         offs, total, bounds = {}, 0, []
-        for g in groups:
+        for g in segs:
             for n, p in g:
                 offs[n] = total
                 total += _round(p.numel())
             bounds.append(total)
-        self.n_params_flat, self.group_bounds = total, bounds
+        self.n_params_flat, self.seg_bounds = total, bounds[:5]
+        self.bucket_split = bounds[2]  # [0, bucket_split): neck + head (the first gradient bucket); the rest: backbone
+        groups = segs
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self._n_params_for_gb = total  # flat_g is created with the buffers' staging tail once their size is known (below)
         self.frozen = torch.zeros(total, dtype=torch.uint8, device=dev)

@@ -89,9 +89,9 @@ class StepPlan:
         # -- the reference's DDP reducer fires its buckets inside loss.backward() the same way (engine/trainer.py:695, :810).
         self.buckets = 2 if (world_size > 1 and os.environ.get("DY_DP_BUCKETS", "1") == "2") else 1
         self.fb_cut = None          # index into rec_fb.ops between the two halves of the backward pass
-        self._bucket_idx = None     # (positions of bucket 1 in flat_gb, positions of bucket 2 + the buffer tail)
-        self._bucket_stage = None
+        self._bucket_stream = None
         self._bucket_pending = False
+        self._exchange = True
         self.graph_fb2 = None
         self.dynamic_scale = bool(dynamic_scale)  # False (amp=False): the loss scale is a constant, nothing ever halves it
         self.opt_calls = 0                        # optimizer_step() calls so far; the device counts taken + skipped (state[5], state[6])
@@ -189,8 +189,12 @@ class StepPlan:
         self.ho = ho
         return rec
 
-    def forward_backward(self, batch):
-        """Stage the batch, run fwd+loss+bwd; gradients (scaled by the loss scale) land in rt.flat_g."""
+    def forward_backward(self, batch, exchange=True):
+        """Stage the batch, run fwd+loss+bwd; gradients (scaled by the loss scale) land in rt.flat_g.  ``exchange`` (data-parallel runs
+        with gradient buckets): the optimizer step follows THIS micro-batch alone -- only then may the first bucket's all-reduce start
+        under the backbone's backward, because it sums the gradient buffer IN PLACE (a micro-batch that is going to be accumulated must
+        keep its local gradients: pass False)."""
+        self._exchange = bool(exchange)
         if not self.input_act:
             self.stage(batch)
         n = self.crit.set_targets(batch, cap=self.B * self.nmax)
@@ -232,33 +236,19 @@ class StepPlan:
         return self.crit.scalars
 
     # ---- gradient buckets ------------------------------------------------------------------------------------------------------
-    def _bucket_positions(self):
-        if self._bucket_idx is None:
-            rt, dev = self.rt, self.rt.flat_p.device
-            nb = len(self.model.yaml.get("backbone", []))
-            in1 = torch.zeros(rt.flat_gb.numel(), dtype=torch.bool)
-            for name, p in self.model.named_parameters():
-                parts = name.split(".")
-                if parts[0] == "model" and parts[1].isdigit() and int(parts[1]) >= nb:
-                    o = rt.param_off[name]
-                    in1[o:o + (p.numel() + 7) // 8 * 8] = True
-            self._bucket_idx = (in1.nonzero().flatten().to(dev), (~in1).nonzero().flatten().to(dev))
-            self._bucket_stage = [torch.zeros(i.numel(), dtype=torch.float32, device=dev) for i in self._bucket_idx]
-            self._bucket_stream = torch.cuda.Stream(dev)
-        return self._bucket_idx
-
+    # The flat gradient buffer is laid out [neck + head | backbone | buffer tail] (hip/runtime.py), so a bucket is a VIEW of it: no
+    # gather / scatter launches and no staging copies between the two graphs -- RCCL reduces the slices in place.
     def _start_bucket1(self):
-        """Neck + head gradients are final: gather them and start their all-reduce on the side stream."""
-        if self._micro:  # gradient accumulation exchanges the accumulated buffer once, at the optimizer step
+        """Neck + head gradients are final: start their all-reduce on the side stream."""
+        if self._micro or not self._exchange:  # gradient accumulation exchanges the accumulated buffer once, at the optimizer step
             return
-        idx1, _ = self._bucket_positions()
-        st = self._bucket_stage[0]
-        torch.index_select(self.rt.flat_gb, 0, idx1, out=st)
+        if self._bucket_stream is None:
+            self._bucket_stream = torch.cuda.Stream(self.rt.flat_p.device)
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(self._bucket_stream):
             self._bucket_stream.wait_event(ready)
-            all_reduce_flat(st, self.world_size)
+            all_reduce_flat(self.rt.flat_gb[:self.rt.bucket_split], self.world_size)
         self._bucket_pending = True
 
     # ---- the two halves on their own: ``loss = model(batch); loss.backward()`` (nn/tasks.py, BaseModel.loss) -----------------------
@@ -414,14 +404,9 @@ class StepPlan:
             else:
                 t[n:].zero_()
             if self._bucket_pending and not self._micro:
-                # bucket 1 is (being) reduced on the side stream; bucket 2 = the backbone's gradients + the buffer tail goes now
-                idx1, idx2 = self._bucket_positions()
-                st2 = self._bucket_stage[1]
-                torch.index_select(t, 0, idx2, out=st2)
-                all_reduce_flat(st2, self.world_size)
+                # bucket 1 is (being) reduced on the side stream; bucket 2 = the backbone's gradients + the buffer tail goes now, in place
+                all_reduce_flat(t[rt.bucket_split:], self.world_size)
                 torch.cuda.current_stream().wait_stream(self._bucket_stream)
-                t.index_copy_(0, idx1, self._bucket_stage[0])
-                t.index_copy_(0, idx2, st2)
                 self._bucket_pending = False
             else:
                 if self._bucket_pending:  # an accumulating step: the early bucket is not used
@@ -459,12 +444,10 @@ class StepPlan:
         rt = self.rt
         if getattr(self, "_soap", None) is None:
             from .soap import Soap
-            b0, b1 = rt.group_bounds[0], rt.group_bounds[1]
             views = []
             for n, p in self.model.named_parameters():
                 if p.requires_grad:
-                    o = rt.param_off[n]
-                    views.append((n, o, p.numel(), tuple(p.shape), 0 if o < b0 else (1 if o < b1 else 2)))
+                    views.append((n, rt.param_off[n], p.numel(), tuple(p.shape), rt.param_group[n]))
             self._soap_views = views
             self._soap = Soap([(rt.flat_p[o:o + k].view(sh), g) for _, o, k, sh, g in views], beta1=self._hyp["momentum"], beta2=0.95)
             self._soap_apply_pending()
@@ -513,9 +496,9 @@ class StepPlan:
         if key not in self.rec_opt:
             eng.rec = Recorder()
             try:
-                b = rt.group_bounds
-                eng.call("dy_optimizer_step", rt.flat_p.data_ptr(), grads.data_ptr(), self.mom.data_ptr(),
-                         0 if self.adam_v is None else self.adam_v.data_ptr(), self.ema.data_ptr(), rt.n_params_flat, b[0], b[1],
+                b = (C.c_long * 5)(*rt.seg_bounds)  # (read at enqueue time: travels as kernel arguments)
+                eng.call("dy_optimizer_step_seg", rt.flat_p.data_ptr(), grads.data_ptr(), self.mom.data_ptr(),
+                         0 if self.adam_v is None else self.adam_v.data_ptr(), self.ema.data_ptr(), rt.n_params_flat, b,
                          rt.frozen.data_ptr(), rt.flat_b.data_ptr(), self.ema_b.data_ptr(), rt.n_buffers_flat,
                          self.hyper.data_ptr(), self.state.data_ptr(), self.partials.data_ptr(), self.mode)
             finally:

@@ -396,6 +396,12 @@ int dy_soft_nms(const float* boxes, float* scores, const float* cls, const int* 
 int dy_optimizer_step(float* params, const float* grads, float* mom, float* adam_v, float* ema, long n, long g0_end,
                       long g1_end, const unsigned char* frozen, const float* buffers, float* ema_buffers,
                       long n_buffers, const float* hyper, float* state, float* partials, int mode, hipStream_t stream);
+/* The same step over a flat buffer of SIX segments [bucket A: bias | decayed | norm][bucket B: bias | decayed | norm] (seg_ends: the ends
+ * of the first five, host array): each data-parallel gradient bucket is then ONE contiguous slice that RCCL reduces in place -- DDP's
+ * reducer works on contiguous buckets too (engine/trainer.py:694-695).  Segment k takes the hyper-parameters of group k % 3. */
+int dy_optimizer_step_seg(float* params, const float* grads, float* mom, float* adam_v, float* ema, long n, const long* seg_ends,
+                          const unsigned char* frozen, const float* buffers, float* ema_buffers, long n_buffers, const float* hyper,
+                          float* state, float* partials, int mode, hipStream_t stream);
 /* hyper (16 device floats read by dy_optimizer_step: lr per group, momentum, weight decay per group, EMA decay, max grad norm,
  * beta2, eps) set from 16 HOST floats that are copied at enqueue time (kernel arguments): safe however far the host runs ahead. */
 int dy_set_hyper(float* hyper_dev, const float* host_values16, hipStream_t stream);

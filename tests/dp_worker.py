@@ -31,7 +31,7 @@ def main(out_dir):
     for it, accumulate in enumerate(STEPS):
         for micro in range(accumulate):
             plan.set_hyper(*hyper(it))
-            plan.forward_backward(shard_batch(global_batch(it, micro, b * world), rank, world))
+            plan.forward_backward(shard_batch(global_batch(it, micro, b * world), rank, world), exchange=accumulate == 1)
             if accumulate > 1:
                 plan.accumulate()
         plan.all_reduce()

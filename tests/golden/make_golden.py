@@ -587,7 +587,7 @@ def gen_ckpt():
 MAP_PROTOCOL = dict(name="yolov8n-ASF-P2P2", nc=4, imgsz=320, batch=16, nb=8, epochs=30, nval=2, init_seed=5)
 
 
-def gen_map():
+def gen_map(perm_seed=None, save=True):
     """mAP parity protocol (north-star: 'mAP50 on a held-out synthetic set within +-0.2 of the reference'): the REFERENCE
     model / loss / build_optimizer / optimizer_step / ModelEMA train DEAL-YOLO-N for 30 epochs x 8 batches of 16 planted-
     rectangle images (320x320, 4 classes, no augmentation), driven as engine/trainer.py:780-815 does, from the shared
@@ -623,7 +623,11 @@ def gen_map():
     train = [{k: torch.from_numpy(v) for k, v in b.items()} for b in planted_batches(1, nb, bs, P["imgsz"], P["nc"])]
     hist = []
     t0 = time.time()
+    order_rng = None if perm_seed is None else np.random.default_rng(1000 + perm_seed)  # gen_map_dist: a neutral perturbation
+    base_train = train
     for epoch in range(epochs):
+        if order_rng is not None:  # the same eight batches in another order every epoch (what a shuffling loader does)
+            train = [base_train[j] for j in order_rng.permutation(nb)]
         m.train()
         for j, x in enumerate(fake.optimizer.param_groups):  # scheduler.step() value of this epoch (LambdaLR on initial_lr)
             x["lr"] = x["initial_lr"] * lf(epoch)
@@ -662,9 +666,27 @@ def gen_map():
     st = {k: torch.cat(v, 0).numpy() for k, v in stats.items()}
     dm = DetMetrics(names={i: str(i) for i in range(P["nc"])})
     dm.process(st["tp"], st["conf"], st["pred_cls"], st["target_cls"])
-    print("reference mean_results (P, R, mAP50, mAP50-95):", dm.mean_results())
+    print("reference mean_results (P, R, mAP50, mAP50-95):", dm.mean_results(), "perm_seed", perm_seed, flush=True)
+    if not save:
+        return np.stack(hist), np.asarray(dm.mean_results(), np.float64)
     npz("map_parity", loss_hist=np.stack(hist), mean_results=np.asarray(dm.mean_results(), np.float64), n_det=np.asarray(len(st["conf"])),
         protocol=np.asarray([P["nc"], P["imgsz"], P["batch"], P["nb"], P["epochs"], P["nval"], P["init_seed"]]))
+
+def gen_map_dist(k=6):
+    """The reference's DISTRIBUTION under the protocol of gen_map: the same run repeated with k neutral perturbations -- the eight
+    training batches visited in another (seeded) order every epoch, nothing else changed -- so that the parity test compares means
+    with a known spread instead of one trajectory of a chaotic system with another (map_parity_dist.npz: mean_results (k, 4),
+    final-epoch loss items (k, 3), the order seeds)."""
+    torch.set_num_threads(int(os.environ.get("DY_GOLDEN_THREADS", "4")))
+    res, last = [], []
+    for s in range(1, k + 1):
+        hist, mr = gen_map(perm_seed=s, save=False)
+        res.append(mr)
+        last.append(hist[-1])
+    res = np.stack(res)
+    print("reference mAP50 over", k, "batch orders:", res[:, 2].round(4), "mean", res[:, 2].mean().round(4), "std", res[:, 2].std(ddof=1).round(4))
+    npz("map_parity_dist", mean_results=res, last_loss=np.stack(last), order_seeds=np.arange(1, k + 1))
+
 
 def gen_data():
     """Data pipeline: the REFERENCE YOLODataset + build_dataloader over the fixture dataset of

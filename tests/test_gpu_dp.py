@@ -95,3 +95,34 @@ def test_rccl_runs_the_collective_path_on_the_gpu(tmp_path, buckets):
         res[backend] = torch.load(os.path.join(out, "rank0.pt"))
     for k in ("p", "b", "ema"):
         assert torch.equal(res["nccl"][k], res["gloo"][k]), k
+
+
+def test_gradient_buckets_are_contiguous_views_of_the_flat_buffer():
+    """The flat parameter / gradient buffers are laid out [neck + head: bias | decayed | norm][backbone: bias | decayed | norm] (hip/runtime.py),
+    so that each gradient bucket of the bucketed all-reduce is ONE slice reduced in place (DDP's reducer works on contiguous buckets:
+    reference engine/trainer.py:694-695) -- no index gathers, no staging copies between the two graphs -- and the optimizer kernel
+    takes the six segment bounds."""
+    from conftest import CFG_DIR
+    from ultralytics.hip.train import StepPlan
+    from ultralytics.nn.tasks import DetectionModel
+    torch.manual_seed(0)
+    m = DetectionModel(os.path.join(CFG_DIR, "yolov8n-ASF-P2P2.yaml"), verbose=False).cuda().train()
+    plan = StepPlan(m, 2, 64, nmax=8)
+    rt = plan.rt
+    nb = len(m.yaml["backbone"])
+    b = [0] + list(rt.seg_bounds) + [rt.n_params_flat]
+    assert b == sorted(b) and rt.bucket_split == b[3] and 0 < rt.bucket_split < rt.n_params_flat
+    norm = tuple(v for k, v in torch.nn.__dict__.items() if "Norm" in k and isinstance(v, type))
+    mods = dict(m.named_modules())
+    for name, p in m.named_parameters():
+        o, late = rt.param_off[name], int(name.split(".")[1]) >= nb
+        grp = 0 if "bias" in name else (2 if isinstance(mods[name.rsplit(".", 1)[0]], norm) else 1)
+        seg = next(k for k in range(6) if b[k] <= o < b[k + 1])
+        assert seg == (0 if late else 3) + grp and rt.param_group[name] == grp, name
+        assert (o < rt.bucket_split) == late
+        assert p.data.data_ptr() == rt.flat_p.data_ptr() + 4 * o and p.grad.data_ptr() == rt.flat_gb.data_ptr() + 4 * o
+    assert not hasattr(plan, "_bucket_stage") and not hasattr(plan, "_bucket_positions")
+    # the two buckets tile the exchange buffer [gradients | buffer tail] exactly
+    b1, b2 = rt.flat_gb[:rt.bucket_split], rt.flat_gb[rt.bucket_split:]
+    assert b1.is_contiguous() and b2.is_contiguous() and b1.numel() + b2.numel() == rt.flat_gb.numel()
+    assert b2.data_ptr() == rt.flat_gb.data_ptr() + 4 * rt.bucket_split
