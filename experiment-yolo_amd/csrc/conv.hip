@@ -40,6 +40,10 @@ struct ConvArgs {
   // nn/modules/block.py:333-335 -- on the fp16 values about to be stored, i.e. the bits of "store, then dy_add"
   const f16* res;      // (N, Ho, Wo, ldres)
   int ldres;
+  // 1x1 (FLAT) launches of the ping-pong kernel only: the input / the output is a never-materialised channel concatenation (DySegs,
+  // include/dealyolo_hip.h).  xs.nseg > 0: chunk h of the input comes from the segment that holds channels [h*CC, (h+1)*CC) (the host
+  // picked CC so that no chunk straddles two segments).  ys.nseg > 0: every 8-channel piece of the output goes to its segment.
+  DySegs xs, ys;
   const f16* rraw;     // (N, Ho, Wo, ldrraw) raw conv output of that layer's forward
   const float* rcoef;  // [4][rC]: scale, shift, mean, invstd
   double* racc;        // [DY_BN_COPIES][2][rC]
@@ -749,6 +753,24 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
   auto prefetch = [&](const TileCur& tc, int h) {
     if (FLAT) {
       const int tile = tc.bx;
+      if (a.xs.nseg > 0) {
+        // segmented input: the chunk's segment (scalar search), its own base pointer and pixel stride
+        int sg = 0;
+#pragma unroll 1
+        while (sg + 1 < a.xs.nseg && h * CC >= a.xs.c_end[sg]) ++sg;
+        const int cb = sg ? a.xs.c_end[sg - 1] : 0, ld = a.xs.ld[sg];
+        const f16* base = reinterpret_cast<const f16*>(a.xs.ptr[sg]) + (h * CC - cb);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(base), 0, (int)((unsigned)a.npix * (unsigned)ld * 2u - (unsigned)(h * CC - cb) * 2u), 0x00020000);
+        const unsigned org = (unsigned)tile * HW_ * ld * 2u;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+          const int id = gtid + i * GTHR;
+          const unsigned off = id < NCHUNK16 ? (unsigned)(((id / CPP) * ld + (id % CPP) * 8) * 2) + org : NEVER;
+          const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
+          pf[i] = *reinterpret_cast<const uint4*>(&v);
+        }
+        return;
+      }
       const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x), 0, (int)((unsigned)a.npix * (unsigned)a.ldx * 2u), 0x00020000);
       const unsigned org = ((unsigned)tile * HW_ * a.ldx + h * CC) * 2u;
 #pragma unroll
@@ -909,8 +931,9 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
           //    store is 64 separate 16-byte writes per instruction (measured: 21 % of the kernel).  Each N-tile is
           //    therefore turned through a per-wave LDS scratch so that PPR consecutive lanes write one pixel's whole
           //    channel block: full-line stores, 8x fewer write requests.
-          auto fast = [&](auto acc_tag, auto stats_tag, auto bias_tag, auto silu_tag, auto red_tag, auto resv_tag) {
+          auto fast = [&](auto acc_tag, auto stats_tag, auto bias_tag, auto silu_tag, auto red_tag, auto resv_tag, auto segy_tag) {
             constexpr bool RESV = decltype(resv_tag)::value;   // the addend is ConvArgs::res (its own pointer / pitch), not the old output
+            constexpr bool SEGY = decltype(segy_tag)::value;   // 1x1 only: the output is a segmented concatenation (ConvArgs::ys)
             constexpr bool ACCUM = decltype(acc_tag)::value || RESV, STATS = decltype(stats_tag)::value;
             constexpr bool BIAS = decltype(bias_tag)::value, SILU = decltype(silu_tag)::value, RED = decltype(red_tag)::value;
             constexpr int PPR = RB / 16;                       // 16-byte pieces per pixel row
@@ -930,6 +953,20 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             const char* const rbase = reinterpret_cast<const char*>(a.res) + rtbase * 2;
             const int collim = FLAT ? a.npix - (pix0 + wgs * (NT * 16)) : a.Wo - ox0;  // lanes' pixels below this are real
             const bool full = FLAT ? collim >= NT * 16 : (collim >= TW && oy0 + TH <= a.Ho);
+            // SEGY: this lane's 8-channel piece lives in ONE segment for the whole launch: its base (at the piece's channel), its pixel
+            // stride and whether the segment accumulates
+            char* sbase = nullptr;
+            int sld = 0;
+            bool sacc = false;
+            if (SEGY) {
+              const int chn = (int)(blockIdx.y * (16 * MT) + piece * 8);
+              int sg = 0;
+              while (sg + 1 < a.ys.nseg && chn >= a.ys.c_end[sg]) ++sg;
+              const int cb = sg ? a.ys.c_end[sg - 1] : 0;
+              sbase = reinterpret_cast<char*>(const_cast<void*>(a.ys.ptr[sg])) + (chn - cb) * 2;
+              sld = a.ys.ld[sg];
+              sacc = a.ys.acc[sg] != 0;
+            }
             char* const xw = xs + p * XROW + q * (NC * 2);
             const char* const xr = xs + dpix * XROW + piece * 16;
             typedef uint2 __attribute__((may_alias)) uint2_a;  // (the 8-byte write and the 16-byte read are different C++ types)
@@ -984,6 +1021,10 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
               const int c0 = tile_col(t) + ps * PIXPASS;              // compile-time column of lane group 0
               const long soff = FLAT ? (long)c0 * a.ldy : ((long)(t >> 1) * a.Wo + c0) * a.ldy;  // scalar
               valid = rowok && chok && dpix < 16 && c0 + dpix < collim;
+              if (SEGY) {  // (FLAT) pixel pix0 + wgs * 64 + c0 + dpix of the lane's segment
+                char* const pzs = sbase + (long)(pix0 + wgs * (NT * 16) + c0 + dpix) * sld * 2;
+                return reinterpret_cast<uint4*>(valid ? pzs : reinterpret_cast<char*>(const_cast<void*>(a.ys.ptr[0])));
+              }
               // lanes without a destination get the tensor base: the accumulate variant LOADS through this pointer before
               // it tests `valid`, and rows of a partial tile past the last image lie outside the allocation
               char* const pz = ybase + soff * 2 + loff;
@@ -991,6 +1032,10 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             };
             auto addend = [&](int t, int ps) {  // what is added to the values of (t, ps): the old output, or (RESV) the residual tensor
               bool valid;
+              if (SEGY) {  // only the segments that accumulate have an old value
+                uint4* const pd = dest(t, ps, valid);
+                return (valid && sacc) ? *pd : make_uint4(0, 0, 0, 0);
+              }
               if (!RESV) return *dest(t, ps, valid);
               const bool rowok = FLAT ? true : row0 + (t >> 1) < a.Ho;
               const int c0 = tile_col(t) + ps * PIXPASS;
@@ -1075,15 +1120,18 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             constexpr std::true_type Y{};
             constexpr std::false_type N_{};
             const int e = a.epi & (DY_EPI_ACCUM | DY_EPI_STATS | DY_EPI_BIAS | DY_EPI_SILU);
-            if (e == DY_EPI_ACCUM) fast(Y, N_, N_, N_, N_, N_);
-            else if (e == DY_EPI_STATS) fast(N_, Y, N_, N_, N_, N_);
-            else if (e == (DY_EPI_STATS | DY_EPI_BIAS)) fast(N_, Y, Y, N_, N_, N_);
+            if (FLAT && a.ys.nseg > 0) {
+              // input gradient of a 1x1 conv over a segmented concatenation: every piece to its segment, stored or added per segment
+              if constexpr (FLAT && !REDK) fast(Y, N_, N_, N_, N_, N_, Y);
+            } else if (e == DY_EPI_ACCUM) fast(Y, N_, N_, N_, N_, N_, N_);
+            else if (e == DY_EPI_STATS) fast(N_, Y, N_, N_, N_, N_, N_);
+            else if (e == (DY_EPI_STATS | DY_EPI_BIAS)) fast(N_, Y, Y, N_, N_, N_, N_);
             else if (e == (DY_EPI_BIAS | DY_EPI_SILU) && (a.epi & DY_EPI_RES)) {
               // (3x3 stride-1 only -- Bottleneck.cv2 -- so that no other instantiation carries the variant's code and registers)
-              if constexpr (KS == 3 && STRIDE == 1) fast(N_, N_, Y, Y, N_, Y);
-            } else if (e == (DY_EPI_BIAS | DY_EPI_SILU)) fast(N_, N_, Y, Y, N_, N_);
-            else if (REDK) fast(N_, N_, N_, N_, std::integral_constant<bool, REDK>{}, N_);
-            else fast(N_, N_, N_, N_, N_, N_);
+              if constexpr (KS == 3 && STRIDE == 1) fast(N_, N_, Y, Y, N_, Y, N_);
+            } else if (e == (DY_EPI_BIAS | DY_EPI_SILU)) fast(N_, N_, Y, Y, N_, N_, N_);
+            else if (REDK) fast(N_, N_, N_, N_, std::integral_constant<bool, REDK>{}, N_, N_);
+            else fast(N_, N_, N_, N_, N_, N_, N_);
           }
         } else {
 #pragma unroll
@@ -1805,7 +1853,8 @@ static int launch_dg2(const ConvArgs& a, int grid_y, hipStream_t s) {
   return DY_OK;
 }
 
-struct RedHost { const void* raw; int ldraw; const float* coef; double* acc; int C; const void* res; int ldres; };
+struct RedHost { const void* raw; int ldraw; const float* coef; double* acc; int C; const void* res; int ldres;
+                 const DySegs* xs; const DySegs* ys; int cc_override; };
 static int conv_forward_impl(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                              float* partials, int n, int h, int w, int cin, int cout, int ks, int stride, int dil,
                              int out_h, int out_w, int epi, int* num_partials, hipStream_t stream, const RedHost* red);
@@ -1830,7 +1879,7 @@ extern "C" int dy_conv_input_grad_red(const void* dy, int lddy, const void* w_pa
                                       hipStream_t stream) {
   if (!raw || !coef || !acc || C != cout || (ldraw & 7) || ((uintptr_t)raw & 15) || !dy_conv_red_supported(cin, cout, ks) || (lddx & 7))
     return DY_ERR_ARG;
-  const RedHost red{raw, ldraw, coef, acc, C, nullptr, 0};
+  const RedHost red{raw, ldraw, coef, acc, C, nullptr, 0, nullptr, nullptr, 0};
   return conv_forward_impl(dy, lddy, w_packed_t, nullptr, dx, lddx, nullptr, n, h, w, cin, cout, ks, 1, 1, 0, 0, 0, nullptr, stream, &red);
 }
 // 1 when dy_conv_forward_res can take this geometry: the ping-pong kernel's transposing epilogue (whole 8-channel pieces)
@@ -1844,15 +1893,75 @@ extern "C" int dy_conv_res_supported(int cin, int cout, int ks, int stride) {
 extern "C" int dy_conv_forward_res(const void* x, int ldx, const void* w_packed, const float* bias, const void* res, int ldres, void* y,
                                    int ldy, int n, int h, int w, int cin, int cout, int ks, int stride, hipStream_t stream) {
   if (!res || !bias || (ldres & 7) || ((uintptr_t)res & 15) || (ldy & 7) || !dy_conv_res_supported(cin, cout, ks, stride)) return DY_ERR_ARG;
-  const RedHost red{nullptr, 0, nullptr, nullptr, 0, res, ldres};
+  const RedHost red{nullptr, 0, nullptr, nullptr, 0, res, ldres, nullptr, nullptr, 0};
   return conv_forward_impl(x, ldx, w_packed, bias, y, ldy, nullptr, n, h, w, cin, cout, ks, stride, 1, 0, 0,
                            DY_EPI_BIAS | DY_EPI_SILU | DY_EPI_RES, nullptr, stream, &red);
+}
+// ---- 1x1 convolutions over a never-materialised concatenation (DySegs)
+extern "C" int dy_segs_bytes(void) { return (int)sizeof(DySegs); }
+static bool segs_valid(const DySegs* s, int total) {
+  if (!s || s->nseg < 1 || s->nseg > DY_MAX_SEGS || s->c_end[s->nseg - 1] != total) return false;
+  for (int k = 0; k < s->nseg; ++k) {
+    const int cb = k ? s->c_end[k - 1] : 0;
+    if (s->c_end[k] <= cb || (s->c_end[k] & 7) || (s->ld[k] & 7) || s->ld[k] < s->c_end[k] - cb || !s->ptr[k] || ((uintptr_t)s->ptr[k] & 15)) return false;
+  }
+  return true;
+}
+// the Cin chunk a forward launch over these segments stages per step: dy_conv_geometry's own, or 32 where that one (64) would straddle
+// a boundary -- the packed weights are the same for both; 0: no such chunk (16-channel chunks of 48- / 80-channel inputs only work
+// when they are the geometry's own)
+static int segs_chunk(int cin, int cout, const DySegs* s) {
+  int cp, op, cc, nch, mt, ng, kst, pe;
+  if (dy_conv_geometry(cin, cout, 1, 1, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK || cin != cp) return 0;
+  for (int c = cc; c >= 32 || c == cc; c >>= 1) {
+    bool ok = cin % c == 0 && pp_trows(c, mt, 1, 1, cin / c) != 0;
+    for (int k = 0; ok && k < s->nseg; ++k) ok = s->c_end[k] % c == 0;
+    if (ok) return c;
+    if (c <= 32) break;
+  }
+  return 0;
+}
+extern "C" int dy_conv1x1_segs_supported(int cin, int cout, const DySegs* xs) {
+  return (segs_valid(xs, cin) && segs_chunk(cin, cout, xs) != 0) ? 1 : 0;
+}
+// dy_conv_forward for a 1x1 convolution whose INPUT is the concatenation xs (n, h, w, cin = xs->c_end[last]): Conv.forward over
+// torch.cat(...) (reference nn/modules/block.py:222-226 C2f, :166-171 SPPF, nn/modules/conv.py:338-348 Concat) without the cat.
+extern "C" int dy_conv1x1_forward_segs(const DySegs* xs, const void* w_packed, const float* bias, void* y, int ldy, float* partials, int n,
+                                       int h, int w, int cin, int cout, int epi, hipStream_t stream) {
+  if (!segs_valid(xs, cin)) return DY_ERR_ARG;
+  const int c = segs_chunk(cin, cout, xs);
+  if (!c) return DY_ERR_ARG;
+  const RedHost red{nullptr, 0, nullptr, nullptr, 0, nullptr, 0, xs, nullptr, c};
+  return conv_forward_impl(nullptr, 0, w_packed, bias, y, ldy, partials, n, h, w, cin, cout, 1, 1, 1, 0, 0, epi, nullptr, stream, &red);
+}
+// ... and its input gradient: dx_s (+)= (W^T dy)[channels of segment s] for every segment of dxs (total channels = cout here),
+// stored or added per segment (dxs->acc): the dgrad of the same layer writing straight into the concat members' gradient tensors.
+extern "C" int dy_conv1x1_input_grad_segs(const void* dy, int lddy, const void* w_packed_t, const DySegs* dxs, int n, int h, int w, int cin,
+                                          int cout, hipStream_t stream) {
+  if (!segs_valid(dxs, cout)) return DY_ERR_ARG;
+  const RedHost red{nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, dxs, 0};
+  return conv_forward_impl(dy, lddy, w_packed_t, nullptr, nullptr, 0, nullptr, n, h, w, cin, cout, 1, 1, 1, 0, 0, 0, nullptr, stream, &red);
 }
 static int conv_forward_impl(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                              float* partials, int n, int h, int w, int cin, int cout, int ks, int stride, int dil,
                              int out_h, int out_w, int epi, int* num_partials, hipStream_t stream, const RedHost* red) {
   int cp, op, cc, nch, mt, ng, kst, pe;
   if (dy_conv_geometry(cin, cout, ks, stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return DY_ERR_ARG;
+  const bool segx = red && red->xs, segy = red && red->ys;
+  if (segx) {  // segmented input (1x1): the chunk size the caller chose so that no chunk straddles two segments; same packed layout
+    if (ks != 1 || !red->cc_override || cin % red->cc_override || (red->cc_override != cc && (red->cc_override < 32 || cc < 32))) return DY_ERR_ARG;
+    cc = red->cc_override;
+    nch = cin / cc;
+    x = red->xs->ptr[0];
+    ldx = 8;
+    for (int k = 0; k < red->xs->nseg; ++k)  // every segment is addressed through 32-bit buffer offsets
+      if ((double)n * h * w * red->xs->ld[k] * 2.0 >= 2147483648.0) return DY_ERR_ARG;
+  }
+  if (segy) {
+    if (ks != 1 || y || epi) return DY_ERR_ARG;
+    ldy = 8;
+  }
+  if ((segx || segy) && pp_trows(cc, mt, ks, stride, nch) == 0) return DY_ERR_ARG;
   if (cin != cp || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return DY_ERR_ALIGN;
   if (!(epi & DY_EPI_F32OUT) && (((uintptr_t)y & 15) || (ldy & 3))) return DY_ERR_ALIGN;
   if (dil != 1 && !(dil == 2 && ks == 3 && stride == 1)) return DY_ERR_ARG;
@@ -1875,6 +1984,8 @@ static int conv_forward_impl(const void* x, int ldx, const void* w_packed, const
   if (red) {
     a.rraw = (const f16*)red->raw; a.ldrraw = red->ldraw; a.rcoef = red->coef; a.racc = red->acc; a.rC = red->C;
     a.res = (const f16*)red->res; a.ldres = red->ldres;
+    if (red->xs) a.xs = *red->xs;
+    if (red->ys) a.ys = *red->ys;
   }
   static const bool xcd_map = getenv("DY_CONV_NO_XCDMAP") == nullptr;
   a.xcd_map = xcd_map && ks == 3;  // 1x1 tiles have no halo to share

@@ -33,6 +33,9 @@ struct WgArgs {
   float* dbeta;
   int ldraw, cout;
   float count;
+  // BNF 3 (1x1 only): x is a never-materialised concatenation (DySegs, include/dealyolo_hip.h): every staged granule comes from the
+  // segment that holds its channels, through the thread's own pointer (a workgroup's Cin chunk may straddle segments)
+  DySegs xs;
 };
 
 static __device__ __forceinline__ half8 tr_frag(const char* base0, const char* base1) {
@@ -61,6 +64,8 @@ template <int KS, int STRIDE, int NCI, int MTC, int BNF>
 // channels over two workgroups to fit was measured slower, 258 vs 224 us.)
 __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void conv_wgrad_kernel(const WgArgs a) {
   constexpr bool FLAT = (KS == 1);
+  constexpr bool BN1 = (BNF == 1 || BNF == 3);   // BatchNorm + SiLU backward formed while staging dY
+  constexpr bool XSEG = (BNF == 3);              // ... and X is a segmented concatenation
   constexpr int TAPS = KS * KS;
   constexpr int NCOL = NCI * TAPS;          // (ci tile, tap) columns of this workgroup
   constexpr int CPW = (NCOL + 3) / 4;       // columns per wave (round-robin)
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
   __shared__ __attribute__((aligned(16))) char smem[XBYTES + YBYTES];
   char* const sx = smem;
   char* const sy = smem + XBYTES;
-  __shared__ __attribute__((aligned(16))) float sbn[BNF == 1 ? 4 * COUT_C : (BNF == 2 ? 256 * 8 : 4)];  // BNF 1: [sc | sh | kb | kc] of this cout chunk; 2: bias-sum scratch
+  __shared__ __attribute__((aligned(16))) float sbn[BN1 ? 4 * COUT_C : (BNF == 2 ? 256 * 8 : 4)];  // BNF 1: [sc | sh | kb | kc] of this cout chunk; 2: bias-sum scratch
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // BNF 2: sum over pixels of this thread's dY granule (its channel part is fixed)
   (void)bsum;
 
@@ -100,8 +105,8 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
   constexpr int NGX = HHX * HWX * (CIN_C / 8), NGY = TH * TW * (COUT_C / 8);
   constexpr int NPX = (NGX + 255) / 256, NPY = (NGY + 255) / 256;
   uint4 pfx[NPX], pfy[NPY];
-  uint4 pfr[BNF == 1 ? NPY : 1];     // BNF: raw conv output granules beside the dy granules
-  unsigned roff[BNF == 1 ? NPY : 1]; // their byte offsets in the (raw / draw) geometry
+  uint4 pfr[BN1 ? NPY : 1];     // BNF: raw conv output granules beside the dy granules
+  unsigned roff[BN1 ? NPY : 1]; // their byte offsets in the (raw / draw) geometry
   int ncur = 0, nnext = 0;  // BNF, 3x3: image index of the staged / prefetched tile (the draw store needs its descriptor)
   (void)ncur; (void)nnext;
   unsigned vnext = 0, vcur = 0, ornext = 0, orcur = 0;  // BNF: validity bits + (raw / draw) tile-origin offset of the prefetched / staged tile
@@ -119,6 +124,22 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
     const int hy = FLAT ? 0 : pixel / HWX, hx = FLAT ? pixel : pixel - hy * HWX;
     xoff[i] = ok ? (unsigned)(((hy * a.W + hx) * a.ldx + ci0 + part * 8) * 2) : NEVER;
   }
+  const char* xb[XSEG ? NPX : 1];  // XSEG: where this thread's granule i lives (its segment's base at the granule's channel) ...
+  int xl[XSEG ? NPX : 1];          // ... and that segment's pixel stride in bytes
+  (void)xb; (void)xl;
+  if (XSEG) {
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int id = tid + i * 256;
+      const int part = id % CPGX, ch = ci0 + part * 8;
+      int sg = 0;
+      while (sg + 1 < a.xs.nseg && ch >= a.xs.c_end[sg]) ++sg;
+      const int cb = sg ? a.xs.c_end[sg - 1] : 0;
+      const bool ok = id < NGX && ch < a.cin_r8;
+      xb[XSEG ? i : 0] = ok ? reinterpret_cast<const char*>(a.xs.ptr[sg]) + (ch - cb) * 2 : nullptr;
+      xl[XSEG ? i : 0] = a.xs.ld[sg] * 2;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NPY; ++i) {
     const int id = tid + i * 256;
@@ -126,9 +147,9 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
     const bool ok = id < NGY && co0 + part * 8 < a.cout_r8;
     const int ty = FLAT ? 0 : pixel / TW, tx = FLAT ? pixel : pixel - ty * TW;
     yoff[i] = ok ? (unsigned)(((ty * a.Wo + tx) * a.lddy + co0 + part * 8) * 2) : NEVER;
-    if (BNF == 1) roff[i] = ok ? (unsigned)(((ty * a.Wo + tx) * a.ldraw + co0 + part * 8) * 2) : NEVER;
+    if (BN1) roff[i] = ok ? (unsigned)(((ty * a.Wo + tx) * a.ldraw + co0 + part * 8) * 2) : NEVER;
   }
-  if (BNF == 1) {
+  if (BN1) {
     // BatchNorm backward coefficients of this cout chunk from the reduce pass's fp64 sums (what bn_act_bwd_apply_kernel<.., true>
     // does in its prologue): dx = sc*g - (kb*x + kc), kb = sc*invstd*mean(g*xhat), kc = sc*mean(g) - kb*mean
     for (int c = tid; c < COUT_C; c += 256) {
@@ -168,11 +189,21 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
       const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x), 0, (int)((unsigned)a.npix * (unsigned)a.ldx * 2u), 0x00020000);
       const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.dy), 0, (int)((unsigned)a.npix * (unsigned)a.lddy * 2u), 0x00020000);
       const unsigned ox = (unsigned)tile * (TH * TW) * a.ldx * 2u, oy = (unsigned)tile * (TH * TW) * a.lddy * 2u;
+      if (XSEG) {
+        const long p0 = (long)tile * (TH * TW);
 #pragma unroll
-      for (int i = 0; i < NPX; ++i) pfx[i] = ld16(rx, xoff[i] + ox);
+        for (int i = 0; i < NPX; ++i) {
+          const long gp = p0 + (tid + i * 256) / CPGX;
+          const char* src = xb[XSEG ? i : 0];
+          pfx[i] = (src && gp < a.npix) ? *reinterpret_cast<const uint4*>(src + gp * xl[XSEG ? i : 0]) : make_uint4(0, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) pfx[i] = ld16(rx, xoff[i] + ox);
+      }
 #pragma unroll
       for (int i = 0; i < NPY; ++i) pfy[i] = ld16(ry, yoff[i] + oy);
-      if (BNF == 1) {
+      if (BN1) {
         const unsigned nbytes = (unsigned)a.npix * (unsigned)a.ldraw * 2u;
         const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.raw), 0, (int)nbytes, 0x00020000);
         ornext = (unsigned)tile * (TH * TW) * a.ldraw * 2u;
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
           pfy[i] = ld16(ry, ox0 + tx < a.Wo ? yoff[i] + oy : NEVER);
         }
       }
-      if (BNF == 1) {
+      if (BN1) {
         const unsigned nbytes = (unsigned)(a.Ho * a.Wo * a.ldraw * 2);
         const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.raw) + (size_t)n * a.Ho * a.Wo * a.ldraw, 0, (int)nbytes, 0x00020000);
         ornext = (unsigned)((oy0 * a.Wo + ox0) * a.ldraw * 2);
@@ -247,7 +278,7 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
       const int id = tid + i * 256;
       if (id < NGX) *reinterpret_cast<uint4*>(sx + (id / (CIN_C / 8)) * PSX + (id % (CIN_C / 8)) * 16) = pfx[i];
     }
-    if (BNF == 1) {
+    if (BN1) {
       vcur = vnext; orcur = ornext; ncur = nnext;
       // d(raw) = BatchNorm + SiLU backward of (dy, raw), formed here in registers: it becomes the A operand in LDS and -- from the
       // workgroups of Cin chunk 0 -- the tensor the input-gradient pass reads.  Granules the range check zeroed (outside the image,
@@ -468,7 +499,10 @@ extern "C" int dy_wgrad_reduce_batched(const void* descs_device, int n, int tota
 
 template <int KS, int STRIDE, int NCI, int MTC>
 static int launch_wgrad(const WgArgs& a, int gx, int gy, hipStream_t s) {
-  if (a.raw) hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC, 1>), dim3(gx, gy), dim3(256), 0, s, a);
+  if (a.raw && a.xs.nseg > 0) {
+    if constexpr (KS == 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC, 3>), dim3(gx, gy), dim3(256), 0, s, a);
+    else return DY_ERR_ARG;
+  } else if (a.raw) hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC, 1>), dim3(gx, gy), dim3(256), 0, s, a);
   else if (a.acc && MTC != 3) hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC, 2>), dim3(gx, gy), dim3(256), 0, s, a);
   else if (a.acc) return DY_ERR_ARG;
   else hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, NCI, MTC, 0>), dim3(gx, gy), dim3(256), 0, s, a);
@@ -553,6 +587,7 @@ extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks
 
 struct WgBnHost {  // BatchNorm + SiLU backward folded into the staging of dY (dy_conv_wgrad_bn)
   const void* raw; void* draw; const float* coef; const double* acc; float* dgamma; float* dbeta; int ldraw; float count;
+  const DySegs* xs = nullptr;  // dy_conv1x1_wgrad_bn_segs: the X operand is a segmented concatenation
 };
 static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
                            int cin, int cout, int ks, int stride, int accumulate, int ld_taps, int ld_cphys, int ld_cin,
@@ -609,6 +644,19 @@ extern "C" int dy_conv_wgrad_bias(const void* x, int ldx, const void* dy, int ld
   const WgBnHost bn{nullptr, nullptr, nullptr, bias_acc, nullptr, nullptr, 0, 1.f};
   return conv_wgrad_impl(x, ldx, dy, lddy, slabs, dw, n, h, w, cin, cout, ks, stride, accumulate, 0, 0, 0, stream, &bn);
 }
+// dy_conv_wgrad_bn for a 1x1 Conv whose input is the never-materialised concatenation xs (cin = xs->c_end[last]): C2f.cv2 / SPPF.cv2 /
+// the Conv behind a Concat layer (reference nn/modules/block.py:222-226, :166-171, nn/modules/conv.py:338-348).
+extern "C" int dy_conv1x1_wgrad_bn_segs(const DySegs* xs, const void* dy, int lddy, const void* raw, int ldraw, void* draw, const float* coef,
+                                        const double* acc, float* dgamma, float* dbeta, float count, float* slabs, float* dw, int n, int h,
+                                        int w, int cin, int cout, int accumulate, hipStream_t stream) {
+  if (!raw || !coef || !acc || (ldraw & 7) || ((uintptr_t)raw & 15) || ((uintptr_t)draw & 15) || (cout & 15)) return DY_ERR_ARG;
+  if (!xs || xs->nseg < 1 || xs->nseg > DY_MAX_SEGS || xs->c_end[xs->nseg - 1] != cin) return DY_ERR_ARG;
+  for (int k = 0; k < xs->nseg; ++k)
+    if ((xs->c_end[k] & 7) || (xs->ld[k] & 7) || !xs->ptr[k] || ((uintptr_t)xs->ptr[k] & 15) || xs->c_end[k] <= (k ? xs->c_end[k - 1] : 0)) return DY_ERR_ARG;
+  WgBnHost bn{raw, draw, coef, acc, dgamma, dbeta, ldraw, count};
+  bn.xs = xs;
+  return conv_wgrad_impl(xs->ptr[0], 8, dy, lddy, slabs, dw, n, h, w, cin, cout, 1, 1, accumulate, 0, 0, 0, stream, &bn);
+}
 extern "C" int dy_conv_wgrad_ld_bn(const void* x, int ldx, const void* dy, int lddy, const void* raw, int ldraw, void* draw,
                                    const float* coef, const double* acc, float* dgamma, float* dbeta, float count, float* slabs,
                                    float* dw, int n, int h, int w, int cout, int ld_cin, int ld_taps, int ld_cphys, int accumulate,
@@ -642,6 +690,7 @@ static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, flo
     a.raw = (const f16*)bn->raw; a.draw = (f16*)bn->draw; a.coef = bn->coef; a.acc = bn->acc;
     a.dgamma = bn->dgamma; a.dbeta = bn->dbeta; a.ldraw = bn->ldraw; a.count = bn->count;
     a.cout = bn->raw ? cout : (cout + 7) / 8 * 8;  // bias sums: one slot per physical channel of dY
+    if (bn->xs) a.xs = *bn->xs;
   }
   a.nci_chunks = cp / (16 * nci);
   const int nco_chunks = op / (16 * mtc);

@@ -56,6 +56,11 @@ class DyLossArgs(C.Structure):
                 ("box_w", vp * 4), ("box_b", vp * 4), ("box_in_coef", vp * 4)]
 
 
+class DySegs(C.Structure):
+    """include/dealyolo_hip.h DySegs: a channel concatenation that is never materialised (hip/engine.py, SegAct)."""
+    _fields_ = [("nseg", i32), ("c_end", i32 * 8), ("ld", i32 * 8), ("acc", i32 * 8), ("ptr", vp * 8)]
+
+
 # name -> (restype, argtypes); every exported symbol of include/dealyolo_hip.h appears here (tests/test_abi.py)
 SIGNATURES = {
     "dy_abi_version": (i32, []),
@@ -66,6 +71,11 @@ SIGNATURES = {
     "dy_pack_desc_fill": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32]),
     "dy_pack_weights_batched": (i32, [vp, i32, i32, vp]),
     "dy_conv_forward": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, ip, vp]),
+    "dy_segs_bytes": (i32, []),
+    "dy_conv1x1_segs_supported": (i32, [i32, i32, C.POINTER(DySegs)]),
+    "dy_conv1x1_forward_segs": (i32, [C.POINTER(DySegs), vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "dy_conv1x1_input_grad_segs": (i32, [vp, i32, vp, C.POINTER(DySegs), i32, i32, i32, i32, i32, vp]),
+    "dy_conv1x1_wgrad_bn_segs": (i32, [C.POINTER(DySegs), vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dy_conv_res_supported": (i32, [i32, i32, i32, i32]),
     "dy_conv_forward_res": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dy_conv_red_supported": (i32, [i32, i32, i32]),
@@ -175,6 +185,8 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        if L.dy_segs_bytes() != C.sizeof(DySegs):
+            raise RuntimeError(f"{LIB_PATH} lays DySegs out in {L.dy_segs_bytes()} bytes, this binding in {C.sizeof(DySegs)}: rebuild the library")
         if L.dy_loss_args_bytes() != C.sizeof(DyLossArgs):  # a stale .so (or a stale binding) would read garbage pointers
             raise RuntimeError(f"{LIB_PATH} was built with a DyLossArgs of {L.dy_loss_args_bytes()} bytes, this binding lays out "
                                f"{C.sizeof(DyLossArgs)}: rebuild the library (make -C experiment-yolo_amd/csrc)")

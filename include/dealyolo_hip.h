@@ -32,6 +32,21 @@ typedef struct ihipStream_t* hipStream_t;
 #define DY_ERR_LAUNCH (-2)
 #define DY_ERR_ALIGN (-3)
 
+/* A channel CONCATENATION that is never materialised: the tensor's channels [c_end[s-1], c_end[s]) live in segment s, an fp16 NHWC
+ * tensor (or channel slice) of its own pixel stride.  C2f's ``torch.cat(y, 1)`` (nn/modules/block.py:222-226), SPPF's and the model's
+ * Concat layers (nn/modules/conv.py:338-348) feed 1x1 convolutions only; those read their input, write their input gradient and read
+ * their weight-gradient operand through this table, so every concat member stays a contiguous tensor for the kernels that touch it
+ * alone (BatchNorm apply / backward reduce, the 3x3 convs of a Bottleneck) instead of a strided slice of a wide buffer. */
+#define DY_MAX_SEGS 8
+typedef struct DySegs {
+  int nseg;                      /* 1..DY_MAX_SEGS */
+  int c_end[DY_MAX_SEGS];        /* exclusive end channel of segment s in the concatenated tensor (multiples of 8, increasing) */
+  int ld[DY_MAX_SEGS];           /* pixel stride of segment s in elements */
+  int acc[DY_MAX_SEGS];          /* as an OUTPUT: 1 = add to what the segment holds (gradient fan-in), 0 = store */
+  const void* ptr[DY_MAX_SEGS];  /* first channel of segment s */
+} DySegs;
+int dy_segs_bytes(void); /* sizeof(DySegs) in the library (bindings check their layout) */
+
 /* conv epilogue flags */
 #define DY_EPI_STATS 1   /* write per-workgroup sum / sum-of-squares partials of the (fp16-rounded) output */
 #define DY_EPI_BIAS 2    /* add bias[cout] */
@@ -108,6 +123,18 @@ int dy_conv_wgrad_bn(const void* x, int ldx, const void* dy, int lddy, const voi
 int dy_conv_wgrad_ld_bn(const void* x, int ldx, const void* dy, int lddy, const void* raw, int ldraw, void* draw,
                         const float* coef, const double* acc, float* dgamma, float* dbeta, float count, float* slabs, float* dw,
                         int n, int h, int w, int cout, int ld_cin, int ld_taps, int ld_cphys, int accumulate, hipStream_t stream);
+/* 1x1 convolutions over a never-materialised concatenation (DySegs above): forward (dy_conv_forward with xs in place of (x, ldx); epi as
+ * there), input gradient (every 8-channel piece of W^T dy stored in / added to its segment) and weight gradient with the BatchNorm backward
+ * apply inside (dy_conv_wgrad_bn with xs in place of (x, ldx)).  dy_conv1x1_segs_supported: a Cin chunk exists that no segment boundary
+ * cuts (the geometry's own, or 32 where that is 64: same packed weights) and the ping-pong kernel takes the shape. */
+int dy_conv1x1_segs_supported(int cin, int cout, const DySegs* xs);
+int dy_conv1x1_forward_segs(const DySegs* xs, const void* w_packed, const float* bias, void* y, int ldy, float* partials, int n, int h,
+                            int w, int cin, int cout, int epi, hipStream_t stream);
+int dy_conv1x1_input_grad_segs(const void* dy, int lddy, const void* w_packed_t, const DySegs* dxs, int n, int h, int w, int cin, int cout,
+                               hipStream_t stream);
+int dy_conv1x1_wgrad_bn_segs(const DySegs* xs, const void* dy, int lddy, const void* raw, int ldraw, void* draw, const float* coef,
+                             const double* acc, float* dgamma, float* dbeta, float count, float* slabs, float* dw, int n, int h, int w,
+                             int cin, int cout, int accumulate, hipStream_t stream);
 /* The stem Conv(3 -> 16, k 3, s 2, p 1) of the model YAMLs (nn/modules/conv.py:41-55 as model.0) read straight from the image
  * batch the trainer hands the model (models/yolo/detect/train.py:57-59: fp32 NCHW, img * mul): no import pass, no padded copy.
  * dy_stem_forward writes the raw conv output (N,Ho,Wo,ldraw) fp16 and ADDS the BatchNorm sums into acc [DY_BN_COPIES][2][16]
