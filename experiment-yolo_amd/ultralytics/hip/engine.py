@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import (DY_ACT_LEAKY, DY_ACT_NONE, DY_ACT_SILU, DY_BN_COPIES, DY_EPI_ACCUM, DY_EPI_BIAS, DY_EPI_F32OUT, DY_EPI_SILU,
-               DY_EPI_STATS, DY_EPI_STATS_ACC, check, lib)
+               DY_EPI_STATS, DY_EPI_STATS_ACC, DySegs, check, lib)
 
 BN2D_EPS, BN2D_MOM = 1e-3, 0.03  # reference utils/torch_utils.py:347-349
 BN3D_EPS, BN3D_MOM = 1e-5, 0.1  # nn.BatchNorm3d defaults (ScalSeq), untouched by initialize_weights
@@ -88,6 +88,12 @@ HEAD_STREAMS = os.environ.get("DY_HEAD_STREAMS", "0") != "0"
 # Fused (eval) models: Bottleneck's shortcut added in the epilogue of the conv in front of it (dy_conv_forward_res) instead of by a
 # dy_add launch.  DY_CONV_RES=0: the launch pair.
 CONV_RES = os.environ.get("DY_CONV_RES", "1") != "0"
+# Concatenations that are never materialised (SegAct): every member of a C2f / Concat stays a contiguous tensor of its own and the 1x1
+# conv behind the concat reads its input, writes its input gradient and reads its weight-gradient operand through a segment table
+# (dy_conv1x1_*_segs).  Round 3 wrote the members into channel slices of one wide buffer: free to concatenate, but every kernel that
+# touches ONE member (BatchNorm apply / backward reduce, the Bottleneck's 3x3 convs) then walked a strided slice and moved up to
+# three times its bytes.  DY_PLANAR=0: the slices.
+PLANAR = os.environ.get("DY_PLANAR", "1") != "0"
 HEAD_APPLY = HEAD_DECODE and os.environ.get("DY_SILU_FAST", "1") != "0" and os.environ.get("DY_HEAD_APPLY", "1") != "0"
 BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
 BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
@@ -248,6 +254,25 @@ class ImageAct:
         if self._act is None:
             self._act = self.eng.import_image(self.img, 8, self.mul)
         return self._act
+
+
+class SegAct:
+    """A channel concatenation that is never materialised: ``parts`` are Acts (tensors or slices) of one (N, H, W), in channel order.
+    Consumed by 1x1 convolutions through a segment table (``Engine._segs``); anything else asks ``Engine.dense`` for a copy."""
+
+    def __init__(self, parts):
+        flat = []
+        for p in parts:
+            flat.extend(p.parts if isinstance(p, SegAct) else [p])
+        assert all((q.N, q.H, q.W) == (flat[0].N, flat[0].H, flat[0].W) for q in flat), "concatenation of different map sizes"
+        self.parts = flat
+        self.C = sum(q.C for q in flat)
+
+    N = property(lambda s: s.parts[0].N)
+    H = property(lambda s: s.parts[0].H)
+    W = property(lambda s: s.parts[0].W)
+    npix = property(lambda s: s.parts[0].npix)
+    needs_grad = property(lambda s: any(q.needs_grad for q in s.parts))
 
 
 class Recorder:
@@ -433,7 +458,9 @@ class Engine:
         if self.tape is None:
             return
         for x in xs:
-            if isinstance(x, Act) and x.needs_grad:
+            if isinstance(x, SegAct):
+                self._use(*x.parts)
+            elif isinstance(x, Act) and x.needs_grad:
                 d = self._uses.setdefault(id(x.st), {})
                 d[(x.c0, x.C)] = d.get((x.c0, x.C), 0) + 1
 
@@ -621,7 +648,38 @@ class Engine:
         self.call("dy_warp_import_u8", pool.data_ptr(), slots.data_ptr(), out.ptr, N, S, cp)
         return out
 
+    # ---- segmented concatenations -------------------------------------------------------------------------------------------------
+    def _segs(self, x: SegAct, grad=False, acc=None):
+        """The DySegs table of ``x`` (``grad``: of the members' gradient tensors, with their store / accumulate flags)."""
+        t = DySegs()
+        assert len(x.parts) <= 8
+        t.nseg, end = len(x.parts), 0
+        for i, q in enumerate(x.parts):
+            end += q.C
+            t.c_end[i], t.ld[i], t.ptr[i] = end, q.ld, (q.gptr if grad else q.ptr)
+            t.acc[i] = int(acc[i]) if acc is not None else 0
+        return t
+
+    def seg_conv_ok(self, spec, x):
+        """A 1x1 Conv can read the concatenation ``x`` without a copy: forward through dy_conv1x1_forward_segs and -- when a backward
+        pass will follow -- weight / input gradients through their segmented forms (the BatchNorm-in-the-weight-gradient path)."""
+        if not (PLANAR and isinstance(x, SegAct) and spec.ks == 1 and spec.stride == 1 and spec.ld is None and len(x.parts) <= 8
+                and x.C == spec.cin_phys and all(q.st.buf.dtype == torch.float16 for q in x.parts)):
+            return False
+        if self.tape is not None and not (self.training and BN_ACC and BN_WGRAD and spec.acc_b is not None and spec.act == DY_ACT_SILU
+                                          and not self.side_wgrad and spec.bn is not None):
+            return False
+        return bool(self.L.dy_conv1x1_segs_supported(x.C, spec.cout, C.byref(self._segs(x))))
+
+    def dense(self, x):
+        """``x`` as ONE tensor: a SegAct is copied together (and its gradient split again in the backward pass); Acts pass through."""
+        return self._concat_copy(x.parts) if isinstance(x, SegAct) else x
+
     def _conv_raw(self, spec, x, y_ptr, ldy, epi, partials_ptr=0, bias=None):
+        if isinstance(x, SegAct):
+            self.call("dy_conv1x1_forward_segs", C.byref(self._segs(x)), spec.wpack.data_ptr(), _ptr(bias), y_ptr, ldy, partials_ptr, x.N, x.H,
+                      x.W, x.C, spec.cout, epi)
+            return
         self.call("dy_conv_forward", x.ptr, x.ld, spec.wpack.data_ptr(), _ptr(bias), y_ptr, ldy, partials_ptr, x.N, x.H, x.W,
                   x.C, spec.cout, spec.ks, spec.stride, 1, 0, 0, epi, None)
 
@@ -651,6 +709,8 @@ class Engine:
                 self.call("dy_bn_act_apply", raw.ptr, raw.ld, 0, 0, y.ptr, y.ld, spec.coef.data_ptr(), y.npix, spec.cout, spec.act)
                 return y
             x = x.materialize()
+        if isinstance(x, SegAct) and not self.seg_conv_ok(spec, x):
+            x = self.dense(x)
         assert x.C == spec.cin_phys, (spec.name, x.C, spec.cin_phys)
         Ho, Wo = self.out_hw(spec, x)
         raw = self.new_act(x.N, Ho, Wo, spec.cout)
@@ -868,7 +928,12 @@ class Engine:
         side = deferred and self.side_wgrad
         if side:
             self.fork()
-        if bn is not None:  # dy_ptr is the gradient w.r.t. the ACTIVATED output: BatchNorm + SiLU backward inside the kernel
+        if bn is not None and isinstance(x, SegAct):  # (seg_conv_ok checked at forward time that this path is the one taken)
+            raw, draw, coef, accb, gw, gb, cnt = bn
+            self.call("dy_conv1x1_wgrad_bn_segs", C.byref(self._segs(x)), dy_ptr, lddy, raw.ptr, raw.ld, draw.data_ptr() if x.needs_grad else 0,
+                      coef, accb, gw, gb, cnt, slabs.data_ptr(), dw, x.N, x.H, x.W, spec.cin, spec.cout, accumulate_w)
+            dy_ptr, lddy = draw.data_ptr(), spec.cout
+        elif bn is not None:  # dy_ptr is the gradient w.r.t. the ACTIVATED output: BatchNorm + SiLU backward inside the kernel
             raw, draw, coef, accb, gw, gb, cnt = bn
             head = (x.ptr, x.ld, dy_ptr, lddy, raw.ptr, raw.ld, draw.data_ptr() if x.needs_grad else 0, coef, accb, gw, gb, cnt,
                     slabs.data_ptr(), dw, x.N, x.H, x.W)
@@ -889,6 +954,15 @@ class Engine:
         else:
             self.call("dy_conv_wgrad", x.ptr, x.ld, dy_ptr, lddy, slabs.data_ptr(), dw, x.N, x.H, x.W,
                       spec.cin, spec.cout, spec.ks, spec.stride, accumulate_w, side=side)
+        if isinstance(x, SegAct):
+            assert bn is not None, f"{spec.name}: a segmented input needs the BatchNorm-in-the-weight-gradient path"
+            if x.needs_grad:  # every 8-channel piece of W^T d(raw) goes to its member's gradient tensor, stored or added per member
+                accs = [q.grad_target() if q.needs_grad else 0 for q in x.parts]
+                if not all(q.needs_grad for q in x.parts):  # a member without a gradient still receives its pieces: give it a sink
+                    raise NotImplementedError("a concatenation member that needs no gradient beside members that do")
+                self.call("dy_conv1x1_input_grad_segs", dy_ptr, lddy, spec.wpack_t.data_ptr(), C.byref(self._segs(x, grad=True, acc=accs)),
+                          x.N, Ho, Wo, spec.cout_phys, spec.cin)
+            return
         if x.needs_grad:
             acc = x.grad_target()
             prod = self._sole_consumer_of_conv(x) if (BN_DGRED and not acc and spec.stride == 1 and spec.ld is None) else None
@@ -944,6 +1018,8 @@ class Engine:
                           x.mul, 1 if spec.act == DY_ACT_SILU else 0)
                 return y
             x = x.materialize()
+        if isinstance(x, SegAct) and not self.seg_conv_ok(spec, x):
+            x = self.dense(x)
         Ho, Wo = self.out_hw(spec, x)
         y = out if out is not None else self.new_act(x.N, Ho, Wo, spec.cout)
         epi = DY_EPI_BIAS | (DY_EPI_SILU if spec.act == DY_ACT_SILU else 0)
@@ -962,6 +1038,7 @@ class Engine:
         """Plain conv + bias (Detect's final nn.Conv2d 1x1, reference nn/modules/head.py:38-42).  ``dy_ptr_fn`` returns
         (ptr, ld) of the fp16 gradient w.r.t. the output at backward time.  ``rows_level``: this is the box branch of detection
         level ``rows_level`` -- its output gradient is non-zero at foreground anchors only (see HEAD_ROWS)."""
+        x = self.dense(x)
         self._use(x)
         self._conv_raw(spec, x, y_ptr, ldy, DY_EPI_BIAS | (DY_EPI_F32OUT if f32out else 0), 0, spec.bias)
         if self.tape is not None:
@@ -1135,6 +1212,7 @@ class Engine:
         self._conv_bwd(spec, x, dyp, ld, Ho, Wo, accumulate, defer=defer)
 
     def upsample2x(self, x: Act, out: Act | None = None):
+        x = self.dense(x)
         y = out if out is not None else self.new_act(x.N, 2 * x.H, 2 * x.W, x.C)
         self._use(x)
         self.call("dy_upsample2x", x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, 0, 0)
@@ -1146,6 +1224,7 @@ class Engine:
         return y
 
     def maxpool5(self, x: Act, out: Act):
+        x = self.dense(x)
         arg = self.transient((x.npix * x.C,), torch.uint8)
         self.hold(arg)
         self._use(x)
@@ -1185,6 +1264,7 @@ class Engine:
             self.tape.append(bwd)
 
     def add(self, xs, out: Act | None = None):
+        xs = [self.dense(t) for t in xs]
         a = xs[0]
         y = out if out is not None else self.new_act(a.N, a.H, a.W, a.C)
         b = xs[1]
@@ -1219,6 +1299,8 @@ class Engine:
     def concat(self, xs, out_storage=None):
         """Concat (reference nn/modules/conv.py:338-348).  Inputs already living in consecutive slices of one Storage
         are returned as a view; anything else is copied."""
+        if any(isinstance(t, SegAct) for t in xs):
+            xs = SegAct(xs).parts
         st = xs[0].st
         pos = xs[0].c0
         inplace = True
@@ -1229,6 +1311,11 @@ class Engine:
             pos += t.C
         if inplace:
             return Act(st, xs[0].c0, pos - xs[0].c0)
+        if PLANAR and len(xs) <= 8:
+            return SegAct(xs)  # never materialised: the 1x1 conv behind it reads the members where they are
+        return self._concat_copy(xs)
+
+    def _concat_copy(self, xs):
         a = xs[0]
         y = self.new_act(a.N, a.H, a.W, sum(t.C for t in xs))
         self._use(*xs)
@@ -1255,7 +1342,7 @@ class Engine:
     def zoom_cat(self, xs, out: Act | None = None):
         """Zoom_cat (reference nn/extra_modules/block.py:3402-3412): [maxpool+avgpool of the fine map | middle map | 2x
         nearest of the coarse map] written into one buffer (exact 2x pyramids only)."""
-        l, m, s = xs
+        l, m, s = (self.dense(t) for t in xs)
         assert l.H == 2 * m.H and l.W == 2 * m.W and m.H == 2 * s.H and m.W == 2 * s.W, "Zoom_cat needs exact 2x pyramids"
         y = out if out is not None else self.new_act(m.N, m.H, m.W, l.C + m.C + s.C)
         self._use(l, m, s)
@@ -1286,6 +1373,7 @@ class Engine:
         every scale at its native resolution (a 1x1 conv commutes with nearest up-sampling); BatchNorm3d statistics
         are those of the up-sampled (B,3,H,W) volume, i.e. level l weighs 4**l.  ``res``: a tensor added to the result (the ``Add`` that
         follows ScalSeq in the ASF models, reference nn/extra_modules/block.py:3479-3484, folded into the tail kernel)."""
+        ps = [self.dense(t) for t in ps]
         p3 = ps[0]
         N, H, W, Cc = p3.N, p3.H, p3.W, conv3d.cout
         assert ps[1].H * 2 == H and ps[2].H * 4 == H and ps[1].W * 2 == W and ps[2].W * 4 == W, "ScalSeq needs exact 2x/4x pyramids"
@@ -1354,6 +1442,7 @@ class Engine:
 
     # ---- LDConv (reference nn/modules/conv.py:366-410) -----------------------------------------------------------
     def ldconv(self, sp_p: ConvSpec, sp_c: ConvSpec, pn_i32, Np, stride, x: Act, out: Act | None = None):
+        x = self.dense(x)
         h, w = self.out_hw(sp_p, x)
         off = self.transient((x.N, h, w, 2 * Np), torch.float32)
         self.hold(off)

@@ -252,6 +252,9 @@ class HipModule(nn.Module):
         return self._export(rt, y)
 
     def _export(self, rt, y):
+        from .engine import SegAct
+        if isinstance(y, SegAct):
+            y = rt.eng.dense(y)
         if isinstance(y, Act):
             return rt.to_tensor(y)
         if isinstance(y, (list, tuple)):

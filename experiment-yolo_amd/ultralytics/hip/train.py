@@ -128,6 +128,7 @@ class StepPlan:
             # (the rows / fused-decode / class-kernel forms of the head need their weight gradients on the main stream: with weight
             # gradients on the side stream the trace takes the dense head kernels from the start -- decided HERE, before the forward
             # is traced, so that the loss is never told to leave rows unwritten which a dense backward would then read)
+            eng.side_wgrad = self.side_wgrad  # (known while the forward is traced: segmented concatenations need the main-stream weight gradients too)
             head_forms = HEAD_ROWS and not self.side_wgrad
             eng.rows_used, eng.loss_rows = (set() if head_forms else None), None
             eng.pending_decode = [] if head_forms else None

@@ -50,6 +50,18 @@ class C2f(HipModule):
 
     def forward_act(self, x, out=None):
         eng, c, n = self.rt.eng, self.c, len(self.m)
+        from ...hip.engine import PLANAR, SegAct
+        if PLANAR and out is None:
+            # the concatenation is never built: cv1's output (both halves) and every Bottleneck's output are tensors of their own -- the
+            # kernels that touch one member alone (BatchNorm apply / backward reduce, the 3x3 convs) walk contiguous memory -- and cv2,
+            # a 1x1 conv, reads / back-propagates through a segment table (reference block.py:222-226: y = list(cv1(x).chunk(2, 1)) ...);
+            # a shape the segmented kernels do not take is copied together by conv_bn_act (Engine.dense)
+            y01 = self.cv1.forward_act(x)
+            parts, prev = [y01], y01.sub(c, c)
+            for b in self.m:
+                prev = b.forward_act(prev)
+                parts.append(prev)
+            return self.cv2.forward_act(SegAct(parts))
         cat = eng.new_storage(x.N, x.H, x.W, (2 + n) * c)
         self.cv1.forward_act(x, cat.act(0, 2 * c))
         prev = cat.act(c, c)
