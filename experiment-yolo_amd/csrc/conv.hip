@@ -681,6 +681,39 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
       rcf[16 * MT + tid] = c < a.rC ? a.rcoef[a.rC + c] : 0.f;
     }
   }
+  // Segmented input (1x1): where chunk h lives -- {base pointer of the chunk's first channel (lo, hi), pixel stride, bytes to the end
+  // of the segment} -- found once per workgroup by thread h and parked in LDS: the staging loop reads its chunk's entry instead of
+  // searching the table in the kernel arguments (a dependent scalar-load chain per chunk: the first version, +10 us on a 160x160 launch)
+  unsigned* const xtab = reinterpret_cast<unsigned*>(rcf + 2 * 16 * MT);
+  if (FLAT && a.xs.nseg > 0 && tid < a.nch && tid < 16) {
+    const int ch0 = tid * CC;
+    int sg = 0;
+    while (sg + 1 < a.xs.nseg && ch0 >= a.xs.c_end[sg]) ++sg;
+    const int cb = sg ? a.xs.c_end[sg - 1] : 0;
+    const unsigned long long base = (unsigned long long)(reinterpret_cast<const f16*>(a.xs.ptr[sg]) + (ch0 - cb));
+    xtab[tid * 4 + 0] = (unsigned)base;
+    xtab[tid * 4 + 1] = (unsigned)(base >> 32);
+    xtab[tid * 4 + 2] = (unsigned)a.xs.ld[sg];
+    xtab[tid * 4 + 3] = (unsigned)a.npix * (unsigned)a.xs.ld[sg] * 2u - (unsigned)(ch0 - cb) * 2u;
+  }
+  // Segmented output (1x1 input gradient): this lane's 8-channel piece lives in ONE segment for the whole launch -- its base at the
+  // piece's channel, its pixel stride in bytes, whether that segment accumulates
+  char* sbase = nullptr;
+  unsigned sld2 = 0;
+  bool sacc = false;
+  if (FLAT && a.ys.nseg > 0) {
+    const int chn = (int)(blockIdx.y * (16 * MT)) + (lane % ((4 * NC * 2) / 16)) * 8;
+    int sg = 0;
+    while (sg + 1 < a.ys.nseg && chn >= a.ys.c_end[sg]) ++sg;
+    const int cb = sg ? a.ys.c_end[sg - 1] : 0;
+    sbase = reinterpret_cast<char*>(const_cast<void*>(a.ys.ptr[sg])) + (chn - cb) * 2;
+    sld2 = (unsigned)a.ys.ld[sg] * 2u;
+    sacc = a.ys.acc[sg] != 0;
+  }
+  bool seg_any_acc = false;  // (wave-uniform) some output segment accumulates: the epilogue variant that loads old values
+  if (FLAT)
+    for (int k = 0; k < a.ys.nseg; ++k) seg_any_acc = seg_any_acc || a.ys.acc[k] != 0;
+  if (FLAT && a.xs.nseg > 0) __syncthreads();
   f32x2 rsg[4], rsgx[4];  // RED: this lane's running sums over its 8-channel piece (dead registers in every other variant)
 #pragma unroll
   for (int j = 0; j < 4; ++j) rsg[j] = rsgx[j] = (f32x2){0.f, 0.f};
@@ -754,13 +787,12 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
     if (FLAT) {
       const int tile = tc.bx;
       if (a.xs.nseg > 0) {
-        // segmented input: the chunk's segment (scalar search), its own base pointer and pixel stride
-        int sg = 0;
-#pragma unroll 1
-        while (sg + 1 < a.xs.nseg && h * CC >= a.xs.c_end[sg]) ++sg;
-        const int cb = sg ? a.xs.c_end[sg - 1] : 0, ld = a.xs.ld[sg];
-        const f16* base = reinterpret_cast<const f16*>(a.xs.ptr[sg]) + (h * CC - cb);
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(base), 0, (int)((unsigned)a.npix * (unsigned)ld * 2u - (unsigned)(h * CC - cb) * 2u), 0x00020000);
+        // segmented input: the chunk's own base pointer and pixel stride from the table the prologue left in LDS
+        const uint4 e = *reinterpret_cast<const uint4*>(xtab + (h < 16 ? h : 15) * 4);
+        const unsigned blo = __builtin_amdgcn_readfirstlane(e.x), bhi = __builtin_amdgcn_readfirstlane(e.y);
+        const int ld = __builtin_amdgcn_readfirstlane(e.z);
+        const f16* base = reinterpret_cast<const f16*>(((unsigned long long)bhi << 32) | blo);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(base), 0, (int)__builtin_amdgcn_readfirstlane(e.w), 0x00020000);
         const unsigned org = (unsigned)tile * HW_ * ld * 2u;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -953,20 +985,6 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             const char* const rbase = reinterpret_cast<const char*>(a.res) + rtbase * 2;
             const int collim = FLAT ? a.npix - (pix0 + wgs * (NT * 16)) : a.Wo - ox0;  // lanes' pixels below this are real
             const bool full = FLAT ? collim >= NT * 16 : (collim >= TW && oy0 + TH <= a.Ho);
-            // SEGY: this lane's 8-channel piece lives in ONE segment for the whole launch: its base (at the piece's channel), its pixel
-            // stride and whether the segment accumulates
-            char* sbase = nullptr;
-            int sld = 0;
-            bool sacc = false;
-            if (SEGY) {
-              const int chn = (int)(blockIdx.y * (16 * MT) + piece * 8);
-              int sg = 0;
-              while (sg + 1 < a.ys.nseg && chn >= a.ys.c_end[sg]) ++sg;
-              const int cb = sg ? a.ys.c_end[sg - 1] : 0;
-              sbase = reinterpret_cast<char*>(const_cast<void*>(a.ys.ptr[sg])) + (chn - cb) * 2;
-              sld = a.ys.ld[sg];
-              sacc = a.ys.acc[sg] != 0;
-            }
             char* const xw = xs + p * XROW + q * (NC * 2);
             const char* const xr = xs + dpix * XROW + piece * 16;
             typedef uint2 __attribute__((may_alias)) uint2_a;  // (the 8-byte write and the 16-byte read are different C++ types)
@@ -1021,8 +1039,8 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
               const int c0 = tile_col(t) + ps * PIXPASS;              // compile-time column of lane group 0
               const long soff = FLAT ? (long)c0 * a.ldy : ((long)(t >> 1) * a.Wo + c0) * a.ldy;  // scalar
               valid = rowok && chok && dpix < 16 && c0 + dpix < collim;
-              if (SEGY) {  // (FLAT) pixel pix0 + wgs * 64 + c0 + dpix of the lane's segment
-                char* const pzs = sbase + (long)(pix0 + wgs * (NT * 16) + c0 + dpix) * sld * 2;
+              if (SEGY) {  // (FLAT) pixel pix0 + wgs * 64 + c0 + dpix of the lane's segment (a segment stays below 4 GB: 32-bit offset)
+                char* const pzs = sbase + (size_t)((unsigned)(pix0 + wgs * (NT * 16) + c0 + dpix) * sld2);
                 return reinterpret_cast<uint4*>(valid ? pzs : reinterpret_cast<char*>(const_cast<void*>(a.ys.ptr[0])));
               }
               // lanes without a destination get the tensor base: the accumulate variant LOADS through this pointer before
@@ -1122,7 +1140,10 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             const int e = a.epi & (DY_EPI_ACCUM | DY_EPI_STATS | DY_EPI_BIAS | DY_EPI_SILU);
             if (FLAT && a.ys.nseg > 0) {
               // input gradient of a 1x1 conv over a segmented concatenation: every piece to its segment, stored or added per segment
-              if constexpr (FLAT && !REDK) fast(Y, N_, N_, N_, N_, N_, Y);
+              if constexpr (FLAT && !REDK) {
+                if (seg_any_acc) fast(Y, N_, N_, N_, N_, N_, Y);   // per-lane: the segments that accumulate load their old values
+                else fast(N_, N_, N_, N_, N_, N_, Y);
+              }
             } else if (e == DY_EPI_ACCUM) fast(Y, N_, N_, N_, N_, N_, N_);
             else if (e == DY_EPI_STATS) fast(N_, Y, N_, N_, N_, N_, N_);
             else if (e == (DY_EPI_STATS | DY_EPI_BIAS)) fast(N_, Y, Y, N_, N_, N_, N_);
@@ -1753,7 +1774,8 @@ static size_t pp_lds_bytes(int cc, int mt, int ks, int stride, int nch, int trow
   if (tile < red) tile = red;
   const size_t wts = (size_t)nch * ((ks * ks * cc + 31) / 32) * 16 * mt * 64;
   const size_t xpose = 8 * 16 * (size_t)(32 * mt + 16);  // per-wave store-transpose scratch
-  return 2 * tile + wts + xpose + 3 * 16 * mt * 4;      // + this cout group's bias + the RED coefficient table (scale | shift)
+  return 2 * tile + wts + xpose + 3 * 16 * mt * 4 + (flat ? 256 : 0);  // + this cout group's bias + the RED coefficient table (scale | shift)
+                                                                        // + (1x1) the per-chunk table of a segmented input
 }
 // rows per wave of the ping-pong kernel for a geometry (0 = does not fit: v3/v1 take it)
 static int pp_trows(int cc, int mt, int ks, int stride, int nch) {
@@ -1914,7 +1936,7 @@ static int segs_chunk(int cin, int cout, const DySegs* s) {
   int cp, op, cc, nch, mt, ng, kst, pe;
   if (dy_conv_geometry(cin, cout, 1, 1, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK || cin != cp) return 0;
   for (int c = cc; c >= 32 || c == cc; c >>= 1) {
-    bool ok = cin % c == 0 && pp_trows(c, mt, 1, 1, cin / c) != 0;
+    bool ok = cin % c == 0 && cin / c <= 16 && pp_trows(c, mt, 1, 1, cin / c) != 0;
     for (int k = 0; ok && k < s->nseg; ++k) ok = s->c_end[k] % c == 0;
     if (ok) return c;
     if (c <= 32) break;
@@ -1952,6 +1974,7 @@ static int conv_forward_impl(const void* x, int ldx, const void* w_packed, const
     if (ks != 1 || !red->cc_override || cin % red->cc_override || (red->cc_override != cc && (red->cc_override < 32 || cc < 32))) return DY_ERR_ARG;
     cc = red->cc_override;
     nch = cin / cc;
+    if (nch > 16) return DY_ERR_ARG;  // the kernel's per-chunk table
     x = red->xs->ptr[0];
     ldx = 8;
     for (int k = 0; k < red->xs->nseg; ++k)  // every segment is addressed through 32-bit buffer offsets
