@@ -532,9 +532,17 @@ static int dispatch_wgrad(int nci, int mtc, const WgArgs& a, int gx, int gy, hip
 // re-reads x).  DY_WGRAD_SPLIT=0 restores one block per layer; DY_WGRAD_SPLIT_F scales the threshold: measured per step (one box,
 // alternating runs) off 12.810 / 12.740 ms, F=0.5 13.330 / 13.217 (re-reads dominate), F=1 12.787 / 12.745, F=2 12.708 / 12.676
 // (the default: 64->64 3x3 @40x40 takes (32, 32) blocks, 128 columns), F=4 12.778 / 12.701.
+// resident workgroups per CU the grid is sized for: 1 where the accumulators leave room for one (64x64 3x3), 2 otherwise -- and, for the
+// lightest blocks (one or two 16x16 tiles: the 16-channel Bottlenecks at 160x160), DY_WGRAD_LIGHT_WGS (their slabs are a few KB, their
+// LDS tiles ~36 KB and their registers < 128, so more of them fit and hide each other's staging latency)
+static int wgrad_per_cu(int ks, int nci, int mtc) {
+  static const int light = getenv("DY_WGRAD_LIGHT_WGS") ? atoi(getenv("DY_WGRAD_LIGHT_WGS")) : 2;
+  if (ks == 3 && nci * mtc >= 16) return 1;
+  return nci * mtc <= 2 ? light : 2;
+}
 static long wgrad_columns(int ks, int nci, int mtc, int cp, int op) {
   const int gy = (cp / (16 * nci)) * (op / (16 * mtc));
-  const int per_cu = (ks == 3 && nci * mtc >= 16) ? 1 : 2;
+  const int per_cu = wgrad_per_cu(ks, nci, mtc);
   int gx = (256 * per_cu) / gy;
   return gx < 32 ? 32 : gx;
 }
@@ -572,7 +580,7 @@ extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks
   // bounds) over the (ci chunk, co chunk) grid rows.  More workgroups than that only add slab traffic (147 KB each for
   // 64x64 3x3) and a ragged second round; fewer leave CUs idle.
   const int gy = (cp / (16 * nci)) * (op / (16 * mtc));
-  const int per_cu = (ks == 3 && nci * mtc >= 16) ? 1 : 2;
+  const int per_cu = wgrad_per_cu(ks, nci, mtc);
   int gx = (256 * per_cu) / gy;
   if (gx < 32) gx = 32;
   // every workgroup ends by writing a full fp32 weight slab (147 KB for 64x64x3x3) that the reduce kernel reads back: on small

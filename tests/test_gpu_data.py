@@ -107,9 +107,12 @@ def test_plan_recorded_for_u8_batches_equals_the_float_plan():
         finally:
             E.STEM_DIRECT = direct
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
-    assert float((out[2][0][5:9] - out[0][0][5:9]).abs().max() / out[0][0][5:9].abs().max()) < 2e-3       # loss items
-    assert float((out[2][1] - out[0][1]).norm() / out[0][1].norm()) < 0.15  # gradients at random init (BatchNorm over 4 small images, task-aligned
-                                                                            # assignment): 5.4e-2 measured for that last-bit noise
+    assert float((out[2][0][5:9] - out[0][0][5:9]).abs().max() / out[0][0][5:9].abs().max()) < 2e-4       # loss items: 2.0e-5 measured
+    # gradients: 4.3e-2 (relative L2) measured here, and the SAME at full size (round 4, scratch measurement: 3.5e-2 at 640x640 batch 2,
+    # 5.1e-2 at batch 8) -- so not BatchNorm over a few small images, as round 3 guessed: at random init the task-aligned top-10
+    # choice is full of near-ties, and the last-bit noise the other summation order puts on ~2 % of the stem outputs flips a few
+    # assignments; each flip re-routes a whole anchor's gradient while the loss VALUES barely move.  Bound: twice the measured value.
+    assert float((out[2][1] - out[0][1]).norm() / out[0][1].norm()) < 9e-2
     with pytest.raises(TypeError):  # the recorded launch list reads ONE input format (this plan: float NCHW -> fine; u8 plan: not)
         plan_u8 = StepPlan(m, B, S, nmax=8, optimizer="SGD", use_graph=False)
         lab_d = {k: v.cuda() for k, v in lab.items()}

@@ -107,3 +107,17 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_mfma_lds_pmc.csv"), "w") as fo:
         fo.write(f"\"{k}\",{n},{busy[0] / n:.0f},{gui[0] / 8.0 / max(gui[1], 1):.0f},{frac:.4f},{c[0] / max(c[1], 1):.0f},{a[0] / max(a[1], 1):.0f},"
                  f"{(c[0] / a[0]) if a[0] else 0.0:.4f}\n")
 print("wrote", f"profiles/{tag}_mfma_lds_pmc.csv")
+# BASELINE.json configs[3] / configs[4]: the kernel stats of the LD training bench and of get_FPS.py (yolov8n-p2, 1280x1280, batch 32)
+for sub, name in (("prof_ld", "ld"), ("prof_p2", "p2_1280")):
+    src = os.path.join(G, sub, "st_kernel_stats.csv")
+    if not os.path.exists(src):
+        hits = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(G, sub)) for f in fs if f.endswith("kernel_stats.csv")]
+        src = hits[0] if hits else None
+    if src:
+        shutil.copy(src, os.path.join(ROOT, "profiles", f"{tag}_{name}_kernel_stats.csv"))
+        log = os.path.join(G, sub + ".log")
+        if os.path.exists(log):
+            keep = [l for l in open(log) if l.startswith("{") or l.startswith("model ")]
+            if keep:
+                open(os.path.join(ROOT, "profiles", f"{tag}_{name}_line.txt"), "w").write(keep[-1])
+        print("wrote", f"profiles/{tag}_{name}_kernel_stats.csv")
