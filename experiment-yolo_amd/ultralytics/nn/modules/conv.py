@@ -15,6 +15,8 @@ from ...hip import DY_ACT_NONE, DY_ACT_SILU
 from ...hip.runtime import HipModule
 
 __all__ = ("Conv", "LDConv", "Concat", "autopad")
+# DY_SPLIT_COUT=0: one launch per fused conv whatever its output width (the last 64-wide cout group zero-padded)
+SPLIT_COUT = __import__("os").environ.get("DY_SPLIT_COUT", "1") != "0"
 
 
 def autopad(k, p=None, d=1):
@@ -46,6 +48,18 @@ class Conv(HipModule):
     def _build_specs(self, rt):
         rt.make_spec(id(self), self.conv, getattr(self, "bn", None), self._act_code(), self.conv.kernel_size[0],
                      self.conv.stride[0], name="Conv")
+        self.__dict__["_split"] = None
+        c2, k = self.conv.out_channels, self.conv.kernel_size[0]
+        if SPLIT_COUT and not hasattr(self, "bn") and self.conv.bias is not None and k == 3 and self.conv.stride[0] == 1 and c2 > 64 and c2 % 64 in (16, 32):
+            # fused (eval) 3x3 conv whose output width is 64 m + 16 / 32 (Detect's class branch for nc = 80: 80 = 64 + 16 channels): the conv
+            # kernel's cout groups are 64 wide, so the last group would multiply 48 / 32 rows of zero weights -- as much matrix work for
+            # 16 outputs as for 64.  The tail runs as a launch of its own on a 16- / 32-row group: two parameter views, two packs.
+            from types import SimpleNamespace as NS
+            lo = c2 // 64 * 64
+            w, b = self.conv.weight.data, self.conv.bias.data
+            parts = [NS(weight=NS(data=w[:lo]), bias=NS(data=b[:lo])), NS(weight=NS(data=w[lo:]), bias=NS(data=b[lo:]))]
+            self.__dict__["_split"] = (lo, [rt.make_spec((id(self), "cout", i), pc, None, self._act_code(), k, 1, name=f"Conv.cout{i}")
+                                            for i, pc in enumerate(parts)])
 
     def out_hw(self, h, w):
         k, s = self.conv.kernel_size[0], self.conv.stride[0]
@@ -57,6 +71,16 @@ class Conv(HipModule):
         spec = self.rt.spec(self)
         if hasattr(self, "bn"):
             return eng.conv_bn_act(spec, x, out, res, defer_apply=defer_apply)
+        split = self.__dict__.get("_split")
+        if split is not None and res is None and eng.tape is None:
+            lo, (sa, sb) = split
+            from ...hip.engine import Act
+            x = eng.dense(x)
+            Ho, Wo = eng.out_hw(spec, x)
+            y = out if out is not None else eng.new_act(x.N, Ho, Wo, spec.cout)
+            eng.conv_fused(sa, x, Act(y.st, y.c0, lo, y.needs_grad))
+            eng.conv_fused(sb, x, Act(y.st, y.c0 + lo, spec.cout - lo, y.needs_grad))
+            return y
         return eng.conv_fused(spec, x, out, res)
 
     forward_fuse = HipModule.forward

@@ -143,3 +143,24 @@ def test_plans_follow_geometry_weights_and_parameter_storage():
     m.train()
     out = m(xa)
     assert isinstance(out, list) and out[0].shape[1] == 70
+
+
+def test_split_tail_cout_group_is_the_same_convolution(monkeypatch):
+    """Fused 3x3 convs with 64 m + 16 outputs (Detect's class branch at nc = 80) run their last 16 channels as a launch of their own
+    (nn/modules/conv.py, DY_SPLIT_COUT) instead of a zero-padded 64-wide group: every output channel is the same dot product, summed
+    in the chunk order the 16-row geometry takes (64-channel chunks where the 64-row group takes 32-channel ones): fp32 rounding
+    order: 1e-8 of the largest output measured, 1e-5 the bound."""
+    from ultralytics.hip import infer as I
+    from ultralytics.nn.modules import conv as conv_mod
+    x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(9)).cuda()
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(conv_mod, "SPLIT_COUT", on)
+        m = _model("yolov8n-p2", fuse=True)
+        with torch.no_grad():
+            outs.append(m(x)[0])
+        n_split = sum(1 for mod in m.modules() if mod.__dict__.get("_split") is not None)
+        assert (n_split == 8) == on, n_split  # cv3[l][0] and cv3[l][1] of the four levels
+    e = relerr(outs[0], outs[1])
+    print(f"split vs padded tail group: {e:.2e}")
+    assert e < 1e-5
