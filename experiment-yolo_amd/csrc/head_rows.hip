@@ -289,8 +289,9 @@ static int box_decode_fill(BoxDecArgs& a, const void* x, int ldx, const float* x
                            int A, int a0, int n, int h, int w, int cin, int cout) {
   if (cin != 64 || cout != 64 || !x || !weight || !bias || !pred_box || n < 1 || h < 1 || w < 1 || a0 < 0 || a0 + h * w > A) return DY_ERR_ARG;
   if ((ldx & 7) || ((uintptr_t)x & 15)) return DY_ERR_ALIGN;
+  static const int cap = getenv("DY_HEAD_DECODE_WGS") ? atoi(getenv("DY_HEAD_DECODE_WGS")) : 2048;  // measurement knob (workgroups per level)
   long blocks = ((long)n * h * w + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > cap) blocks = cap;
   a = BoxDecArgs{(const f16*)x, weight, bias, pred_box, ldx, A, a0, h * w, w, n, x_coef, (int)blocks};
   return DY_OK;
 }

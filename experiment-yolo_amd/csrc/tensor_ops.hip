@@ -1119,9 +1119,8 @@ extern "C" int dy_scalseq_tail_backward_all(const void* r0, int ld0, const void*
   if (blocks > 2048) blocks = 2048;
   if (mode == 0 && blocks > max_partials) blocks = max_partials;
   if (blocks < 1) blocks = 1;
-  static const bool cols_ok = !(getenv("DY_SCALSEQ_COLS") && atoi(getenv("DY_SCALSEQ_COLS")) == 0);
   const int cpp = C >> 3;
-  if (cols_ok && cpp <= 16 && 64 % cpp == 0 && w % (64 / cpp) == 0) {
+  if (cpp <= 16 && 64 % cpp == 0 && w % (64 / cpp) == 0) {
     long wblocks = ((long)n * (h >> 2) * (w / (64 / cpp)) + 3) / 4;
     if (wblocks > 2048) wblocks = 2048;
     if (mode == 0 && wblocks > max_partials) wblocks = max_partials;

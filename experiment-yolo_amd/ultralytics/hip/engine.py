@@ -57,8 +57,8 @@ BIAS_WGRAD = BN_ACC and os.environ.get("DY_BIAS_WGRAD", "1") != "0"
 # slot, not the MFMA slot, set the pace (a fused 32->32 3x3 dgrad at 160x160: 90-107 us against ~50 us + ~50 us for the two launches).
 # Off by default; DY_BN_DGRED=1 enables it, DY_BN_DGRED_MAXC bounds the output width it is used for.
 # SPPF's three chained 5x5 pools (and their backward chain) as one launch each with the map resident in LDS, when it fits
-# (Engine.sppf_pools; =0: three dy_maxpool5 / dy_maxpool5_backward launches).
-SPPF_FUSED = os.environ.get("DY_SPPF_FUSED", "1") != "0"
+# (Engine.sppf_pools); maps that do not fit take three dy_maxpool5 / dy_maxpool5_backward launches (the form a test flips this to).
+SPPF_FUSED = True
 # Add's backward hands the sum's gradient buffer to an operand that has no other consumer instead of copying it (Engine.add).
 ADD_ALIAS = os.environ.get("DY_ADD_ALIAS", "1") != "0"
 # The Add that follows ScalSeq (ASF models) folded into ScalSeq's tail kernel as a residual operand (nn/tasks.py, forward_act).
@@ -1238,7 +1238,7 @@ class Engine:
 
     def sppf_pools(self, cat, c_):
         """SPPF's y1 = m(x), y2 = m(y1), y3 = m(y2) into slices 1..3 of ``cat`` (slice 0 = x): one launch with the map resident in LDS
-        when it fits (DY_SPPF_FUSED=0: never), three dy_maxpool5 launches otherwise.  Reference nn/modules/block.py:166-171."""
+        when it fits, three dy_maxpool5 launches otherwise.  Reference nn/modules/block.py:166-171."""
         x = cat.act(0, c_)
         if not (SPPF_FUSED and cat.buf.dtype == torch.float16 and self.L.dy_sppf_pool3_supported(x.H, x.W, c_)):
             for j in range(3):
