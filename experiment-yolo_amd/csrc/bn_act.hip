@@ -124,6 +124,10 @@ struct ApplyArgs {
   int ldx, ldr, ldy, C, act;
   long npix;
   int rev;  // walk the pixels from the far end (DY_EW_REVERSE bit 0)
+  // two output PLANES (C2f.cv1: reference nn/modules/block.py:223 ``cv1(x).chunk(2, 1)``): channels [csplit, C) go to y2 (its own pixel
+  // stride) instead of y + csplit -- each half of the chunk is then a contiguous tensor for the kernels that read it alone
+  f16* y2 = nullptr;
+  int ldy2 = 0, csplit = 1 << 30;
 };
 
 // Statistics that arrive in an fp64 accumulator instead of a finished coefficient table (the *_acc entry points): the conv
@@ -186,6 +190,8 @@ static __device__ __forceinline__ void bn_act_apply_body(const ApplyArgs& a, con
     sh[j] = ACC ? s_coef[a.C + c0 + j] : a.coef[a.C + c0 + j];
   }
   auto at = [&](long p) { return a.rev ? a.npix - 1 - p : p; };
+  f16* const yb = c0 < a.csplit ? a.y + c0 : a.y2 + (c0 - a.csplit);  // this thread's granule of the output (its plane)
+  const int ly = c0 < a.csplit ? a.ldy : a.ldy2;
   auto one = [&](long pix, const half8& xv) {
     pix = at(pix);
     half8 rv;
@@ -209,7 +215,7 @@ static __device__ __forceinline__ void bn_act_apply_body(const ApplyArgs& a, con
         out[j] = (f16)z;
       }
     }
-    *reinterpret_cast<half8*>(a.y + pix * a.ldy + c0) = out;
+    *reinterpret_cast<half8*>(yb + pix * ly) = out;
   };
   const long step = (long)nb * rows;
   long pix = (long)bx * rows + row;
@@ -317,6 +323,26 @@ extern "C" int dy_bn_act_apply_acc(const void* x, int ldx, const void* res, int 
   return DY_OK;
 }
 
+// dy_bn_act_apply_acc (no residual) whose output lives in TWO planes: channels [0, csplit) to y, the rest to y2 (reference
+// nn/modules/block.py:223: C2f's cv1(x).chunk(2, 1) -- each half is then a tensor of its own)
+extern "C" int dy_bn_act_apply_acc_split(const void* x, int ldx, void* y, int ldy, void* y2, int ldy2, int csplit, const double* acc,
+                                         const float* gamma, const float* beta, float* running_mean, float* running_var, float* coef,
+                                         long npix, int C, int act, float count, float eps, float momentum, hipStream_t stream) {
+  if ((C & 7) || (ldx & 7) || (ldy & 7) || (ldy2 & 7) || (csplit & 7) || csplit <= 0 || csplit >= C || !y2) return DY_ERR_ALIGN;
+  if ((C >> 3) > 256 || !acc || !gamma || !beta || !running_mean || !running_var || !coef) return DY_ERR_ARG;
+  const int rev = ew_reverse();
+  ApplyArgs a{(const f16*)x, nullptr, (f16*)y, nullptr, ldx, 0, ldy, C, act, npix, rev & 1};
+  a.y2 = (f16*)y2; a.ldy2 = ldy2; a.csplit = csplit;
+  const BnAccFwd b{acc, gamma, beta, running_mean, running_var, coef, count, eps, momentum};
+  const dim3 grid(ew_blocks(npix, C, "DY_EW_BLOCKS_APPLY_ACC", 8192));
+  const size_t lds = 2 * (size_t)C * sizeof(float);
+  if (act == DY_ACT_SILU) hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_SILU, true, true>), grid, dim3(256), lds, stream, a, b);
+  else if (act == DY_ACT_LEAKY) hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_LEAKY, true>), grid, dim3(256), lds, stream, a, b);
+  else hipLaunchKernelGGL((bn_act_apply_kernel<DY_ACT_NONE, true>), grid, dim3(256), lds, stream, a, b);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
 extern "C" int dy_bn_group_max(void) { return DY_BN_GROUP_MAX; }
 // dy_bn_act_apply_acc (SiLU, no residual) for n <= dy_bn_group_max() tensors in one launch; array arguments have n entries
 extern "C" int dy_bn_act_apply_acc_group(int n, const void* const* x, const int* ldx, void* const* y, const int* ldy, const double* const* acc,
@@ -355,6 +381,8 @@ struct BwdRedArgs {
   double* acc;      // non-null: add the block's sums into acc[blockIdx.x % DY_BN_COPIES][2][C] instead (see BnAccFwd)
   f16* rg;          // RES: gradient of the residual operand (Bottleneck shortcut, y = act(bn(conv)) + res): rg (+)= dy on the way
   int ldrg, rg_acc;
+  const f16* dy2 = nullptr;  // two gradient PLANES (see ApplyArgs): channels [csplit, C) of dy come from dy2
+  int lddy2 = 0, csplit = 1 << 30;
 };
 
 template <int ACT, bool RES = false>
@@ -376,6 +404,8 @@ static __device__ __forceinline__ void bn_act_bwd_reduce_body(const BwdRedArgs& 
     const long step = (long)nb * rows;
     long pix = (long)bx * rows + row;
     auto at = [&](long p) { return a.rev ? a.npix - 1 - p : p; };
+    const f16* const dyb = c0 < a.csplit ? a.dy + c0 : a.dy2 + (c0 - a.csplit);  // this thread's granule of the gradient (its plane)
+    const int ldd = c0 < a.csplit ? a.lddy : a.lddy2;
     auto pair = [](const half8& v, int j) { return (f32x2){(float)v[2 * j], (float)v[2 * j + 1]}; };
     // the shortcut's gradient is dy itself: written (first writer) or added (fan-in) here instead of by a launch of its own
     auto pass_on = [&](long p, const half8& dv) {
@@ -389,9 +419,9 @@ static __device__ __forceinline__ void bn_act_bwd_reduce_body(const BwdRedArgs& 
       *reinterpret_cast<half8*>(dst) = o;
     };
     for (; pix + step < a.npix; pix += 2 * step) {
-      const half8 dv0 = *reinterpret_cast<const half8*>(a.dy + at(pix) * a.lddy + c0);
+      const half8 dv0 = *reinterpret_cast<const half8*>(dyb + at(pix) * ldd);
       const half8 xv0 = *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0);
-      const half8 dv1 = *reinterpret_cast<const half8*>(a.dy + at(pix + step) * a.lddy + c0);
+      const half8 dv1 = *reinterpret_cast<const half8*>(dyb + at(pix + step) * ldd);
       const half8 xv1 = *reinterpret_cast<const half8*>(a.x + at(pix + step) * a.ldx + c0);
       if (RES) {
         pass_on(pix, dv0);
@@ -407,7 +437,7 @@ static __device__ __forceinline__ void bn_act_bwd_reduce_body(const BwdRedArgs& 
       }
     }
     if (pix < a.npix) {
-      const half8 dv = *reinterpret_cast<const half8*>(a.dy + at(pix) * a.lddy + c0);
+      const half8 dv = *reinterpret_cast<const half8*>(dyb + at(pix) * ldd);
       const half8 xv = *reinterpret_cast<const half8*>(a.x + at(pix) * a.ldx + c0);
       if (RES) pass_on(pix, dv);
 #pragma unroll
@@ -493,6 +523,25 @@ extern "C" int dy_bn_act_bwd_reduce_acc(const void* dy, int lddy, const void* x,
   else if (res_grad && act == DY_ACT_LEAKY) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DY_ACT_LEAKY, true>), dim3((int)blocks), dim3(256), 0, stream, a);
   else if (res_grad) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DY_ACT_NONE, true>), dim3((int)blocks), dim3(256), 0, stream, a);
   else DY_ACT_DISPATCH(bn_act_bwd_reduce_kernel, dim3((int)blocks), stream, a);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+
+// dy_bn_act_bwd_reduce_acc (no shortcut gradient) for a gradient that lives in TWO planes: channels [0, csplit) in dy, the rest in dy2
+extern "C" int dy_bn_act_bwd_reduce_acc_split(const void* dy, int lddy, const void* dy2, int lddy2, int csplit, const void* x, int ldx,
+                                              const float* coef, double* acc, long npix, int C, int act, hipStream_t stream) {
+  if ((C & 7) || C > 2048 || (ldx & 7) || (lddy & 7) || (lddy2 & 7) || (csplit & 7) || csplit <= 0 || csplit >= C || !dy2) return DY_ERR_ALIGN;
+  const int cpp = C >> 3;
+  if (cpp > 256 || !acc) return DY_ERR_ARG;
+  const int rows = 256 / cpp;
+  long blocks = (npix + (long)rows * 8 - 1) / ((long)rows * 8);
+  static const long bcap = getenv("DY_EW_BLOCKS_BRED") ? atol(getenv("DY_EW_BLOCKS_BRED")) : 1024;
+  if (blocks > bcap) blocks = bcap;
+  if (blocks < 1) blocks = 1;
+  const int rev = ew_reverse();
+  BwdRedArgs a{(const f16*)dy, (const f16*)x, coef, nullptr, lddy, ldx, C, act, npix, (rev >> 2) & 1, acc, nullptr, 0, 0};
+  a.dy2 = (const f16*)dy2; a.lddy2 = lddy2; a.csplit = csplit;
+  DY_ACT_DISPATCH(bn_act_bwd_reduce_kernel, dim3((int)blocks), stream, a);
   DY_CHECK_LAUNCH();
   return DY_OK;
 }

@@ -36,6 +36,11 @@ struct WgArgs {
   // BNF 3 (1x1 only): x is a never-materialised concatenation (DySegs, include/dealyolo_hip.h): every staged granule comes from the
   // segment that holds its channels, through the thread's own pointer (a workgroup's Cin chunk may straddle segments)
   DySegs xs;
+  // BNF 1 / 3, 1x1 only: dy lives in TWO planes of one allocation (C2f.cv1's chunk halves: bn_act.hip, ApplyArgs): channels
+  // [dy_csplit, cout) start dy_plane bytes behind dy, both planes have pixel stride lddy.  0 = one tensor.  (Pixels past the end of
+  // plane 0 would read plane 1 -- the BN forms zero such granules by the RAW tensor's range check, which is why only they take planes.)
+  int dy_csplit;
+  unsigned dy_plane;
 };
 
 static __device__ __forceinline__ half8 tr_frag(const char* base0, const char* base1) {
@@ -147,6 +152,10 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
     const bool ok = id < NGY && co0 + part * 8 < a.cout_r8;
     const int ty = FLAT ? 0 : pixel / TW, tx = FLAT ? pixel : pixel - ty * TW;
     yoff[i] = ok ? (unsigned)(((ty * a.Wo + tx) * a.lddy + co0 + part * 8) * 2) : NEVER;
+    if (FLAT && BN1 && a.dy_csplit && ok) {
+      const int ch = co0 + part * 8;
+      yoff[i] = (unsigned)((tx * a.lddy + (ch < a.dy_csplit ? ch : ch - a.dy_csplit)) * 2) + (ch < a.dy_csplit ? 0u : a.dy_plane);
+    }
     if (BN1) roff[i] = ok ? (unsigned)(((ty * a.Wo + tx) * a.ldraw + co0 + part * 8) * 2) : NEVER;
   }
   if (BN1) {
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
   auto prefetch = [&](int tile) {
     if (FLAT) {
       const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x), 0, (int)((unsigned)a.npix * (unsigned)a.ldx * 2u), 0x00020000);
-      const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.dy), 0, (int)((unsigned)a.npix * (unsigned)a.lddy * 2u), 0x00020000);
+      const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.dy), 0, (int)((unsigned)a.npix * (unsigned)a.lddy * 2u + (a.dy_csplit ? a.dy_plane : 0u)), 0x00020000);
       const unsigned ox = (unsigned)tile * (TH * TW) * a.ldx * 2u, oy = (unsigned)tile * (TH * TW) * a.lddy * 2u;
       if (XSEG) {
         const long p0 = (long)tile * (TH * TW);
@@ -596,6 +605,8 @@ extern "C" int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks
 struct WgBnHost {  // BatchNorm + SiLU backward folded into the staging of dY (dy_conv_wgrad_bn)
   const void* raw; void* draw; const float* coef; const double* acc; float* dgamma; float* dbeta; int ldraw; float count;
   const DySegs* xs = nullptr;  // dy_conv1x1_wgrad_bn_segs: the X operand is a segmented concatenation
+  int dy_csplit = 0;           // dy_conv1x1_wgrad_bn_planes: dY in two planes (WgArgs)
+  unsigned dy_plane = 0;
 };
 static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, float* slabs, float* dw, int n, int h, int w,
                            int cin, int cout, int ks, int stride, int accumulate, int ld_taps, int ld_cphys, int ld_cin,
@@ -665,6 +676,27 @@ extern "C" int dy_conv1x1_wgrad_bn_segs(const DySegs* xs, const void* dy, int ld
   bn.xs = xs;
   return conv_wgrad_impl(xs->ptr[0], 8, dy, lddy, slabs, dw, n, h, w, cin, cout, 1, 1, accumulate, 0, 0, 0, stream, &bn);
 }
+// dy_conv_wgrad_bn / dy_conv1x1_wgrad_bn_segs (xs may be NULL: then (x, ldx) is the input) for a 1x1 Conv whose OUTPUT gradient lives in
+// two planes of one allocation -- channels [0, csplit) at dy, [csplit, cout) at dy2 > dy, both with pixel stride lddy (C2f.cv1, whose
+// halves are tensors of their own: reference nn/modules/block.py:223)
+extern "C" int dy_conv1x1_wgrad_bn_planes(const DySegs* xs, const void* x, int ldx, const void* dy, const void* dy2, int lddy, int csplit,
+                                          const void* raw, int ldraw, void* draw, const float* coef, const double* acc, float* dgamma,
+                                          float* dbeta, float count, float* slabs, float* dw, int n, int h, int w, int cin, int cout,
+                                          int accumulate, hipStream_t stream) {
+  if (!raw || !coef || !acc || (ldraw & 7) || ((uintptr_t)raw & 15) || ((uintptr_t)draw & 15) || (cout & 15)) return DY_ERR_ARG;
+  if (!dy || !dy2 || (csplit & 7) || csplit <= 0 || csplit >= cout || ((uintptr_t)dy2 & 15)) return DY_ERR_ARG;
+  const long plane = (const char*)dy2 - (const char*)dy;
+  if (plane < (long)n * h * w * lddy * 2 || plane + (double)n * h * w * lddy * 2.0 >= 2147483648.0) return DY_ERR_ARG;
+  if (xs) {
+    if (xs->nseg < 1 || xs->nseg > DY_MAX_SEGS || xs->c_end[xs->nseg - 1] != cin) return DY_ERR_ARG;
+    for (int k = 0; k < xs->nseg; ++k)
+      if ((xs->c_end[k] & 7) || (xs->ld[k] & 7) || !xs->ptr[k] || ((uintptr_t)xs->ptr[k] & 15) || xs->c_end[k] <= (k ? xs->c_end[k - 1] : 0)) return DY_ERR_ARG;
+  }
+  WgBnHost bn{raw, draw, coef, acc, dgamma, dbeta, ldraw, count};
+  bn.xs = xs;
+  bn.dy_csplit = csplit; bn.dy_plane = (unsigned)plane;
+  return conv_wgrad_impl(xs ? xs->ptr[0] : x, xs ? 8 : ldx, dy, lddy, slabs, dw, n, h, w, cin, cout, 1, 1, accumulate, 0, 0, 0, stream, &bn);
+}
 extern "C" int dy_conv_wgrad_ld_bn(const void* x, int ldx, const void* dy, int lddy, const void* raw, int ldraw, void* draw,
                                    const float* coef, const double* acc, float* dgamma, float* dbeta, float count, float* slabs,
                                    float* dw, int n, int h, int w, int cout, int ld_cin, int ld_taps, int ld_cphys, int accumulate,
@@ -699,6 +731,7 @@ static int conv_wgrad_impl(const void* x, int ldx, const void* dy, int lddy, flo
     a.dgamma = bn->dgamma; a.dbeta = bn->dbeta; a.ldraw = bn->ldraw; a.count = bn->count;
     a.cout = bn->raw ? cout : (cout + 7) / 8 * 8;  // bias sums: one slot per physical channel of dY
     if (bn->xs) a.xs = *bn->xs;
+    a.dy_csplit = bn->dy_csplit; a.dy_plane = bn->dy_plane;
   }
   a.nci_chunks = cp / (16 * nci);
   const int nco_chunks = op / (16 * mtc);

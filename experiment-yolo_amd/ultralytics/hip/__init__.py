@@ -126,6 +126,10 @@ SIGNATURES = {
     "dy_maxpool5": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "dy_maxpool5_backward": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dy_bn_group_max": (i32, []),
+    "dy_bn_act_apply_acc_split": (i32, [vp, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, vp]),
+    "dy_bn_act_bwd_reduce_acc_split": (i32, [vp, i32, vp, i32, i32, vp, i32, vp, vp, i64, i32, i32, vp]),
+    "dy_conv1x1_wgrad_bn_planes": (i32, [C.POINTER(DySegs), vp, i32, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32,
+                                         i32, i32, i32, vp]),
     "dy_bn_act_apply_acc_group": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dy_bn_act_bwd_reduce_acc_group": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dy_bn_act_bwd_reduce_rows": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),

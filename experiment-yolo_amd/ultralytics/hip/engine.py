@@ -59,6 +59,11 @@ BIAS_WGRAD = BN_ACC and os.environ.get("DY_BIAS_WGRAD", "1") != "0"
 # SPPF's three chained 5x5 pools (and their backward chain) as one launch each with the map resident in LDS, when it fits
 # (Engine.sppf_pools); maps that do not fit take three dy_maxpool5 / dy_maxpool5_backward launches (the form a test flips this to).
 SPPF_FUSED = True
+# C2f.cv1's two halves (reference block.py:223, ``cv1(x).chunk(2, 1)``) as tensors of their own -- what planar concatenations left
+# sliced: the second half is what the first Bottleneck reads, adds (shortcut) and back-propagates into.  The apply pass writes both
+# planes, the backward reduce and the weight-gradient kernel read the gradient from both (dy_*_split / dy_conv1x1_wgrad_bn_planes).
+# DY_PLANAR_CV1=0: cv1 writes one 2c-wide tensor, the second half is a channel slice of it.
+PLANAR_CV1 = os.environ.get("DY_PLANAR_CV1", "1") != "0"
 # Add's backward hands the sum's gradient buffer to an operand that has no other consumer instead of copying it (Engine.add).
 ADD_ALIAS = os.environ.get("DY_ADD_ALIAS", "1") != "0"
 # The Add that follows ScalSeq (ASF models) folded into ScalSeq's tail kernel as a residual operand (nn/tasks.py, forward_act).
@@ -671,6 +676,26 @@ class Engine:
             return False
         return bool(self.L.dy_conv1x1_segs_supported(x.C, spec.cout, C.byref(self._segs(x))))
 
+    def planes_ok(self, spec, x):
+        """``spec`` (a 1x1 Conv + BatchNorm + SiLU) may write its output as two planes: the training forms that take them are the
+        accumulator-statistics apply, the split backward reduce and the BatchNorm-in-the-weight-gradient kernel."""
+        if not (PLANAR and PLANAR_CV1 and self.training and BN_ACC and BN_WGRAD and spec.acc_f is not None and spec.acc_b is not None
+                and spec.ks == 1 and spec.stride == 1 and spec.ld is None and spec.act == DY_ACT_SILU and spec.bn is not None
+                and not self.side_wgrad and spec.cout % 16 == 0):
+            return False
+        return not isinstance(x, SegAct) or self.seg_conv_ok(spec, x)
+
+    def new_planes(self, N, H, W, c):
+        """Two (N, H, W, c) tensors in ONE allocation (and so their gradient twins): the halves of a C2f.cv1 output."""
+        buf = self.transient((2, N, H, W, c), torch.float16)
+        sts = [Storage.over(self, buf[0]), Storage.over(self, buf[1])]
+        if self.tape is not None:
+            g = self.transient((2, N, H, W, c), torch.float16)
+            self.hold(g)
+            sts[0].gbuf, sts[1].gbuf = g[0], g[1]
+        self.hold(buf)
+        return sts[0].act(), sts[1].act()
+
     def dense(self, x):
         """``x`` as ONE tensor: a SegAct is copied together (and its gradient split again in the backward pass); Acts pass through."""
         return self._concat_copy(x.parts) if isinstance(x, SegAct) else x
@@ -716,12 +741,23 @@ class Engine:
         raw = self.new_act(x.N, Ho, Wo, spec.cout)
         y = out if out is not None else self.new_act(x.N, Ho, Wo, spec.cout)
         self._use(x, res)
-        if self.tape is not None:
+        planes = isinstance(y, SegAct)  # the output as two planes (new_planes; the caller asked planes_ok)
+        if self.tape is not None and not planes:
             self._prod[(id(y.st), y.c0, y.C)] = (spec, raw)
         assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, spec.cout), (spec.name, (y.N, y.H, y.W, y.C), (x.N, Ho, Wo, spec.cout))
         npix = x.N * Ho * Wo
         bn = spec.bn
         acc = self.training and BN_ACC and spec.acc_f is not None
+        if planes:
+            assert acc and res is None and not defer_apply and len(y.parts) == 2 and self.planes_ok(spec, x), spec.name
+            y0, y1 = y.parts
+            self._conv_raw(spec, x, raw.ptr, raw.ld, DY_EPI_STATS | DY_EPI_STATS_ACC, self._acc_ready(spec.acc_f))
+            self.call("dy_bn_act_apply_acc_split", raw.ptr, raw.ld, y0.ptr, y0.ld, y1.ptr, y1.ld, y0.C, spec.acc_f.data_ptr(),
+                      bn["weight"].data_ptr(), bn["bias"].data_ptr(), bn["running_mean"].data_ptr(), bn["running_var"].data_ptr(),
+                      spec.coef.data_ptr(), npix, spec.cout, spec.act, float(npix), spec.bn_eps, spec.bn_mom)
+            if self.tape is not None:
+                self.tape.append(lambda: self._conv_bn_act_bwd(spec, x, raw, y, None))
+            return y
         if acc:
             # statistics through the fp64 accumulator: conv adds, the apply kernel below finishes them in its prologue
             self._conv_raw(spec, x, raw.ptr, raw.ld, DY_EPI_STATS | DY_EPI_STATS_ACC, self._acc_ready(spec.acc_f))
@@ -851,6 +887,21 @@ class Engine:
         return [y for _, _, _, y, _ in outs]
 
     def _conv_bn_act_bwd(self, spec, x, raw, y, res, reduced=False):
+        if isinstance(y, SegAct):  # two output planes (conv_bn_act): the split reduce, then the weight gradient with dY in planes
+            y0, y1 = y.parts
+            assert y0.grad_ready() and y1.grad_ready(), f"gradient of {spec.name} output incomplete"
+            assert y1.gptr - y0.gptr == y0.npix * y0.ld * 2 and y0.ld == y1.ld == y0.C, "the planes' gradients are not one allocation"
+            npix = y0.npix
+            self.call("dy_bn_act_bwd_reduce_acc_split", y0.gptr, y0.ld, y1.gptr, y1.ld, y0.C, raw.ptr, raw.ld, spec.coef.data_ptr(),
+                      self._acc_ready(spec.acc_b), npix, spec.cout, spec.act)
+            if self.cur_sid:
+                draw = self.transient((npix * spec.cout,), torch.float16)
+                self.hold(draw)
+            else:
+                draw = self.scratch("draw", npix * spec.cout * 2)
+            bn = (raw, draw, spec.coef.data_ptr(), spec.acc_b.data_ptr(), spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(), float(npix))
+            self._conv_bwd(spec, x, y0.gptr, y0.ld, y0.H, y0.W, bn=bn, planes=(y1.gptr, y0.C))
+            return
         assert y.grad_ready(), f"gradient of {spec.name} output incomplete"
         npix = y.npix
         acc = BN_ACC and spec.acc_b is not None
@@ -907,7 +958,7 @@ class Engine:
                       spec.bwdcoef.data_ptr(), npix, spec.cout, spec.act, 0)
         self._conv_bwd(spec, x, draw.data_ptr(), spec.cout, y.H, y.W)
 
-    def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0, defer=True, bn=None, bias_acc=None):
+    def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0, defer=True, bn=None, bias_acc=None, planes=None):
         """weight gradient + input gradient of one convolution given d(raw output) (fp16, (N,Ho,Wo,lddy)).
         When the engine is collecting (``self.deferred_wgrad`` is a list: StepPlan's backward trace) the per-workgroup slabs of
         this layer are kept and reduced together with every other layer's by ONE ``dy_wgrad_reduce_batched`` launch at the end
@@ -928,7 +979,14 @@ class Engine:
         side = deferred and self.side_wgrad
         if side:
             self.fork()
-        if bn is not None and isinstance(x, SegAct):  # (seg_conv_ok checked at forward time that this path is the one taken)
+        if planes is not None:  # dY in two planes (dy_ptr, planes[0]), split at channel planes[1]; x a tensor or a concatenation
+            raw, draw, coef, accb, gw, gb, cnt = bn
+            seg = isinstance(x, SegAct)
+            self.call("dy_conv1x1_wgrad_bn_planes", C.byref(self._segs(x)) if seg else None, 0 if seg else x.ptr, 0 if seg else x.ld, dy_ptr,
+                      planes[0], lddy, planes[1], raw.ptr, raw.ld, draw.data_ptr() if x.needs_grad else 0, coef, accb, gw, gb, cnt,
+                      slabs.data_ptr(), dw, x.N, x.H, x.W, spec.cin, spec.cout, accumulate_w)
+            dy_ptr, lddy = draw.data_ptr(), spec.cout
+        elif bn is not None and isinstance(x, SegAct):  # (seg_conv_ok checked at forward time that this path is the one taken)
             raw, draw, coef, accb, gw, gb, cnt = bn
             self.call("dy_conv1x1_wgrad_bn_segs", C.byref(self._segs(x)), dy_ptr, lddy, raw.ptr, raw.ld, draw.data_ptr() if x.needs_grad else 0,
                       coef, accb, gw, gb, cnt, slabs.data_ptr(), dw, x.N, x.H, x.W, spec.cin, spec.cout, accumulate_w)

@@ -56,8 +56,14 @@ class C2f(HipModule):
             # kernels that touch one member alone (BatchNorm apply / backward reduce, the 3x3 convs) walk contiguous memory -- and cv2,
             # a 1x1 conv, reads / back-propagates through a segment table (reference block.py:222-226: y = list(cv1(x).chunk(2, 1)) ...);
             # a shape the segmented kernels do not take is copied together by conv_bn_act (Engine.dense)
-            y01 = self.cv1.forward_act(x)
-            parts, prev = [y01], y01.sub(c, c)
+            spec = self.rt.spec(self.cv1)
+            if eng.planes_ok(spec, x):  # both halves of the chunk as tensors of their own
+                y0, prev = eng.new_planes(x.N, x.H, x.W, c)
+                self.cv1.forward_act(x, SegAct([y0, prev]))
+                parts = [y0, prev]
+            else:
+                y01 = self.cv1.forward_act(x)
+                parts, prev = [y01], y01.sub(c, c)
             for b in self.m:
                 prev = b.forward_act(prev)
                 parts.append(prev)

@@ -135,6 +135,20 @@ int dy_conv1x1_input_grad_segs(const void* dy, int lddy, const void* w_packed_t,
 int dy_conv1x1_wgrad_bn_segs(const DySegs* xs, const void* dy, int lddy, const void* raw, int ldraw, void* draw, const float* coef,
                              const double* acc, float* dgamma, float* dbeta, float count, float* slabs, float* dw, int n, int h, int w,
                              int cin, int cout, int accumulate, hipStream_t stream);
+/* C2f's ``cv1(x).chunk(2, 1)`` (nn/modules/block.py:223) with each half a tensor of its own ("two planes": channels [0, csplit) at one
+ * base, [csplit, C) at another): the BatchNorm apply that writes them (dy_bn_act_apply_acc, no residual), the backward reduce that
+ * reads their gradients (dy_bn_act_bwd_reduce_acc, no shortcut gradient) and the 1x1 weight gradient with the BatchNorm backward
+ * inside whose dY operand they are (dy_conv_wgrad_bn; xs != NULL: dy_conv1x1_wgrad_bn_segs).  The weight gradient wants both planes
+ * in one allocation, dy2 >= dy + n*h*w*lddy, same pixel stride. */
+int dy_bn_act_apply_acc_split(const void* x, int ldx, void* y, int ldy, void* y2, int ldy2, int csplit, const double* acc,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var, float* coef, long npix,
+                              int C, int act, float count, float eps, float momentum, hipStream_t stream);
+int dy_bn_act_bwd_reduce_acc_split(const void* dy, int lddy, const void* dy2, int lddy2, int csplit, const void* x, int ldx,
+                                   const float* coef, double* acc, long npix, int C, int act, hipStream_t stream);
+int dy_conv1x1_wgrad_bn_planes(const DySegs* xs, const void* x, int ldx, const void* dy, const void* dy2, int lddy, int csplit,
+                               const void* raw, int ldraw, void* draw, const float* coef, const double* acc, float* dgamma,
+                               float* dbeta, float count, float* slabs, float* dw, int n, int h, int w, int cin, int cout,
+                               int accumulate, hipStream_t stream);
 /* The stem Conv(3 -> 16, k 3, s 2, p 1) of the model YAMLs (nn/modules/conv.py:41-55 as model.0) read straight from the image
  * batch the trainer hands the model (models/yolo/detect/train.py:57-59: fp32 NCHW, img * mul): no import pass, no padded copy.
  * dy_stem_forward writes the raw conv output (N,Ho,Wo,ldraw) fp16 and ADDS the BatchNorm sums into acc [DY_BN_COPIES][2][16]

@@ -135,6 +135,37 @@ def test_stream_variants_of_the_step_give_the_same_gradients(golden, variant, mo
     assert torch.isfinite(plan.rt.flat_g).all() and e < 1e-3
 
 
+@pytest.mark.parametrize("name", [MODELS[0], "yolov8n-LD-P2"])
+def test_cv1_halves_as_planes_are_the_same_step_bit_for_bit(golden, name, monkeypatch):
+    """C2f.cv1's two halves as tensors of their own (Engine.new_planes, DY_PLANAR_CV1; reference nn/modules/block.py:223) against the
+    2c-wide tensor with a sliced second half: the apply / reduce / weight-gradient kernels compute every element and every sum in
+    the same order from another base pointer, so loss items and ALL gradients must be EQUAL -- and the two-plane launches must be
+    the ones recorded."""
+    from ultralytics.hip import engine as E
+    from ultralytics.hip.train import StepPlan
+    G = golden("models")
+    batch = {k: G.t(f"{name}/{k}") for k in ("img", "batch_idx", "cls", "bboxes")}
+    outs = []
+    for on in (False, True):
+        monkeypatch.setattr(E, "PLANAR_CV1", on)
+        m, _ = _build(name, MODELS.index(name))
+        plan = StepPlan(m, 2, 64, nmax=8, init_scale=1024.0)
+        plan.forward_backward(batch)
+        plan.forward_backward(batch)
+        torch.cuda.synchronize()
+        names = [o[2] for o in plan.rec_fb.ops if o[0] is not None]
+        n_c2f = sum(1 for mod in m.modules() if type(mod).__name__ == "C2f")
+        for k in ("dy_bn_act_apply_acc_split", "dy_bn_act_bwd_reduce_acc_split", "dy_conv1x1_wgrad_bn_planes"):
+            assert names.count(k) == (n_c2f if on else 0), (k, names.count(k), n_c2f)
+        outs.append((plan.rt.flat_g.clone(), plan.crit.scalars.clone()))
+    assert torch.isfinite(outs[0][0]).all() and float(outs[0][0].abs().max()) > 0
+    if "LD" in name:  # LDConv's far-sample scatter adds with fp32 atomics: the order of those sums differs from run to run
+        assert relerr(outs[0][1][5:9], outs[1][1][5:9]) < 1e-6 and relerr(outs[0][0], outs[1][0]) < 1e-4
+        return
+    assert torch.equal(outs[0][1][5:9], outs[1][1][5:9])
+    assert torch.equal(outs[0][0], outs[1][0]), f"max diff {float((outs[0][0] - outs[1][0]).abs().max()):.3e}"
+
+
 def test_optimizer_trace_vs_golden(golden):
     """5 SGD-nesterov steps (warm-up lr/momentum, clip 10, EMA) against the reference's own optimizer_step trace."""
     from golden.cases import synth_batch
