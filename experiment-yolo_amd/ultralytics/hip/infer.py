@@ -14,10 +14,12 @@ import os
 
 import torch
 
+from . import check
 from .engine import ImageAct, Recorder
 
 # DY_INFER_PLAN=0: eval ``model(x)`` walks the modules eagerly on every call (import pass, generic final convs, dy_decode_predictions)
 INFER_PLAN = os.environ.get("DY_INFER_PLAN", "1") != "0"
+NO_INPUT_COPY = os.environ.get("DY_INFER_INPUT_COPY", "0") != "1"
 MAX_PLANS = int(os.environ.get("DY_INFER_PLANS", "4"))  # input geometries kept recorded per model (least recently used goes first)
 
 
@@ -33,6 +35,7 @@ class InferPlan:
         self.rec = self.graph = self.ho = None
         self.keep = []      # this plan's buffers: released with the plan, not parked on the engine for ever
         self.calls = 0
+        self.head = 0       # the leading launches that read the image batch: issued per call on the CALLER's tensor (no input copy)
 
     def _trace(self):
         eng = self.eng
@@ -42,17 +45,32 @@ class InferPlan:
             self.ho = self.model.forward_act(ImageAct(eng, self.img))
         finally:
             self.rec, eng.rec, eng.infer_head, eng.keep = eng.rec, None, False, keep
+        # The launches that read the image batch (the stem) stay OUT of the replayed list when they lead it: each call issues them
+        # with the caller's own tensor in place of the static input, and a 629 MB device copy per forward (1280x1280 batch 32: 0.25 of
+        # 7.6 ms) never happens.  DY_INFER_INPUT_COPY=1, or a list in which something else comes first: copy into ``img`` as before.
+        ip = self.img.data_ptr()
+        reads = [i for i, (fn, args, _, sid) in enumerate(self.rec.ops) if fn is not None and any(isinstance(v, int) and v == ip for v in args)]
+        if NO_INPUT_COPY and reads and reads == list(range(len(reads))) and all(self.rec.ops[i][3] == 0 for i in reads):
+            self.head = len(reads)
         if self.use_graph:
             want = self._finish().clone()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                eng.replay(self.rec)
+                eng.replay(self.rec, self.head, None)
+            self._head(ip)
             g.replay()
             if not torch.equal(self._finish(), want):  # same safety net as StepPlan._verify_capture: a broken capture must not go unnoticed
                 raise RuntimeError("the captured inference graph does not reproduce the traced forward (device work from another host "
                                    "thread during capture, or DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 not in effect: see ultralytics/hip/__init__.py)")
             self.graph = g
+
+    def _head(self, ptr):
+        """The leading launches with ``ptr`` where the trace had the static input."""
+        eng, ip = self.eng, self.img.data_ptr()
+        s = eng.stream
+        for fn, args, name, _ in self.rec.ops[:self.head]:
+            check(fn(*[ptr if (isinstance(v, int) and v == ip) else v for v in args], s), name)
 
     def _finish(self):
         """Detect's tail into a fresh tensor (or, for heads the fused kernel does not take, the decode of the logits the list wrote)."""
@@ -64,17 +82,21 @@ class InferPlan:
     def __call__(self, x):
         if tuple(x.shape) != self.shape:
             raise ValueError(f"this plan was recorded for inputs of shape {self.shape}, got {tuple(x.shape)}")
-        if x.data_ptr() != self.img.data_ptr():
+        direct = self.rec is not None and self.head and x.dtype == torch.float32 and x.is_contiguous() and x.device == self.img.device
+        if not direct and x.data_ptr() != self.img.data_ptr():
             self.img.copy_(x, non_blocking=True)
         self.rt.ensure_packed()
         self.eng.training = False
         self.calls += 1
         if self.rec is None:
             self._trace()
-        elif self.graph is not None:
+            return self._finish()
+        if self.head:
+            self._head(x.data_ptr() if direct else self.img.data_ptr())
+        if self.graph is not None:
             self.graph.replay()
         else:
-            self.eng.replay(self.rec)
+            self.eng.replay(self.rec, self.head, None)
         return self._finish()
 
 

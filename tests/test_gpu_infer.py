@@ -90,6 +90,14 @@ def test_plan_replays_the_walked_forward_bit_for_bit(name, fuse, size):
         y5, _ = m(x)
     torch.cuda.synchronize()
     assert plan.calls == 4 and (plan.graph is not None) == plan.use_graph
+    # the stem is launched on the caller's tensor: the forward of x * 0.5 never touched the plan's static input ...
+    assert plan.head >= 1 and torch.equal(plan.img, x)
+    with torch.no_grad():  # ... while an input the stem cannot read as it is (fp16, or a strided view) goes through it
+        y6, _ = m(x.half())
+        assert torch.equal(plan.img, x.half().float())
+        y7, _ = m(torch.stack([x, x], -1)[..., 0])
+        assert torch.equal(plan.img, x)
+    assert torch.equal(y7, y1) and relerr(y6, y1) < 2e-2
     assert torch.equal(y1, y2) and torch.equal(y1, y3) and torch.equal(y1, y5) and not torch.equal(y1, y4)
     assert len({t.data_ptr() for t in (y1, y2, y3, y4, y5)}) == 5, "every forward returns a tensor of its own"
     # the per-level (B, no, H, W) maps of the reference's inference return (head.py:74), materialised on demand
