@@ -639,16 +639,33 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_wlds_kernel(ConvArgs a, int
 // slot and the vector/memory work runs beside it.
 //   slot s:  group g computes chunk j = (s-g)/2 when s-g is even, and runs MEM(j) with j = (s-g-1)/2 when it is odd.
 //   MEM(j):  epilogue of j's tile if j was its last chunk; LDS write of chunk j+1; global prefetch of chunk j+2.
-template <int CC, int MT, int KS, int STRIDE, int TROWS, bool REDK = false>
+// FW (0 / 40 / 80): "full-width" tiles for maps that are exactly FW pixels wide (3x3 stride-1, 32-channel chunks).  The usual tile is 32
+// columns wide, so a 40-wide map pays for 64 columns (37.5 % of its MFMAs and staged bytes on pixels that do not exist) and an 80-wide
+// one for 96.  With FW a wave owns an 80-pixel STRIP -- two rows of 40 or one of 80, contiguous in memory because the tile spans the
+// whole width -- as five 16-pixel N-tiles: the epilogue addresses it like the 1x1 kernel's flat pixels, the k-loop like any 3x3 tile
+// except that N-tile 2 of a 40-wide strip straddles the row end (its lanes 8-15 sit one LDS row further: one more base register).
+// Columns 0 and FW+1 of the halo never exist; the descriptor's range check answers them.  Fits beside 73.7 KB of resident weights
+// only with the 64-byte swizzled pixels (SWZ below): 10 x 48 x 64 B = 30.7 KB per group.
+template <int CC, int MT, int KS, int STRIDE, int TROWS, bool REDK = false, int FW = 0>
 __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntiles) {
 #ifdef DY_CONV_TIMING
   unsigned long long tacc[8] = {}, tlast = clock64();
 #endif
   constexpr bool FLAT = (KS == 1);
   constexpr int GW = 4, GTHR = GW * 64;                 // waves / threads per group
-  constexpr int NT = 2 * TROWS;                         // 16-pixel N-tiles per wave
-  constexpr int TH = GW * TROWS, TW = 32;
-  constexpr int HW_ = FLAT ? GW * NT * 16 : (TW - 1) * STRIDE + KS;
+  static_assert(FW == 0 || (KS == 3 && STRIDE == 1 && CC == 32 && !REDK && TROWS * FW == 80), "full-width tiles: 3x3 s1, 32-channel chunks");
+  constexpr bool LIN = FLAT || FW != 0;                 // a wave's N-tiles are consecutive runs of 16 pixels of ONE contiguous strip
+  constexpr int NT = FW ? 5 : 2 * TROWS;                // 16-pixel N-tiles per wave
+  constexpr int TH = GW * TROWS, TW = FW ? FW : 32;
+  // 3x3 stride-1 tiles of 32-channel chunks: 64-byte pixels WITHOUT padding.  A B-fragment read (ds_read_b128, lanes = 16 consecutive
+  // pixels x 4 channel quarters) is conflict-free on that pitch when the 16-byte slot of a pixel is XORed with 2 for pixels whose index
+  // has bit 2 set (enumerated over the instruction's four 16-lane groups and every alignment of the 16 pixels; the 96-byte padded pitch
+  // it replaces is the only padding <= 112 B that is conflict-free).  Rows are 40 pixels long in LDS (34 real), so that a tap's row
+  // offset never changes a pixel's index mod 8 and the XOR term depends on (lane pixel + dx) only: three base registers, immediates
+  // as before.  A tile takes 25.6 KB instead of 32.6: the 32-wide cout groups fit two workgroups per CU.
+  constexpr bool SWZ = (KS == 3 && STRIDE == 1 && CC == 32);
+  constexpr int HWR = FLAT ? GW * NT * 16 : (TW - 1) * STRIDE + KS;   // halo columns that exist
+  constexpr int HW_ = SWZ ? ((HWR + 7) & ~7) : HWR;                   // pixels per tile row in LDS
   constexpr int HH_ = FLAT ? 1 : (TH - 1) * STRIDE + KS;
   constexpr int KSTEPS = (KS * KS * CC + 31) / 32;
   constexpr int CPP = CC / 8;
@@ -656,7 +673,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
   constexpr int NCHUNK16 = HH_ * HW_ * CPP;
   constexpr int NPF = (NCHUNK16 + GTHR - 1) / GTHR;
   constexpr int NC = 4 * MT;
-  constexpr int PS = ps_bytes(CC, STRIDE);
+  constexpr int PS = SWZ ? 64 : ps_bytes(CC, STRIDE);
   constexpr int RED_BYTES = 8 * 2 * 16 * MT * 4;
   constexpr int TILE_BYTES = HH_ * HW_ * PS > RED_BYTES ? HH_ * HW_ * PS : RED_BYTES;
   constexpr unsigned NEVER = 0x80000000u;               // byte offset no image reaches: the buffer range check returns 0
@@ -745,8 +762,19 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
   };
   // LDS byte offset of this lane's pixel in N-tile 0; N-tile t lies a compile-time distance further (bdelta)
   const int boff0 = FLAT ? (wg * (NT * 16) + p) * PS : ((wg * TROWS * STRIDE) * HW_ + p * STRIDE) * PS;
-  auto bdelta = [](int t) { return FLAT ? t * 16 * PS : (((t >> 1) * STRIDE) * HW_ + (t & 1) * 16 * STRIDE) * PS; };
+  auto bdelta = [](int t) {
+    constexpr int FWD = FW ? FW : 1;
+    if (FW) return (((t * 16) / FWD) * HW_ + (t * 16) % FWD) * PS;  // strip pixel 16 t -> (row, column) of the wave's rows
+    return FLAT ? t * 16 * PS : (((t >> 1) * STRIDE) * HW_ + (t & 1) * 16 * STRIDE) * PS;
+  };
+  // FW = 40: N-tile 2 covers columns 32-39 of the strip's first row and 0-7 of its second: lanes 8-15 lie HW_ - FW pixels further
+  const int fwadj = (FW == 40 && p >= 8) ? (HW_ - FW) * PS : 0;
+  auto straddles = [](int t) { return FW == 40 && t == 2; };
   const char* const stb = st + boff0;
+  const char* stbx[3];  // SWZ: the lane's base for taps of column dx, with its channel quarter and that pixel's slot XOR folded in
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) stbx[dx] = stb + ((q * 16) ^ (((p + dx) & 4) << 3));
+  (void)stbx;
   const int aoff = p * 64 + ((q ^ ((0 - (p >> 2)) & 3)) << 4);
   const int co0 = blockIdx.y * (16 * MT) + q * NC;
   f32x2 s1[NC / 2], s2[NC / 2];
@@ -770,7 +798,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
       const int hy = pixel / HW_, hx = pixel - hy * HW_;
       int ry = hy;
       rx = hx;
-      bool ok = id < NCHUNK16;
+      bool ok = id < NCHUNK16 && hx < HWR && !(FW && (hx == 0 || hx == FW + 1));
       if (a.dil == 2) {
         ok = ok && !(((hy - PAD) | (hx - PAD)) & 1);
         ry = (hy - PAD) >> 1;
@@ -818,7 +846,7 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
       const int img = a.Hr * a.Wr * a.ldx * 2;
       const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x) + (size_t)n * a.Hr * a.Wr * a.ldx, 0, img, 0x00020000);
       const unsigned org = (unsigned)(((ty0 * a.Wr + tx0) * a.ldx + h * CC) * 2);
-      const bool xedge = tx0 < 0 || tx0 + (a.dil == 2 ? (HW_ + 1) / 2 : HW_) > a.Wr;   // wave-uniform
+      const bool xedge = !FW && (tx0 < 0 || tx0 + (a.dil == 2 ? (HWR + 1) / 2 : HWR) > a.Wr);   // wave-uniform (FW: goff holds the border)
       if (!xedge) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -910,17 +938,19 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
           int tap = kk / CC;
           const int c = kk - tap * CC;
           if (tap > KS * KS - 1) tap = KS * KS - 1;
-          return ((tap / KS) * HW_ + (tap % KS)) * PS + c * 2;
+          return ((tap / KS) * HW_ + (tap % KS)) * PS + (SWZ ? 0 : c * 2);  // (SWZ: one tap per k-step, c = q * 8 lives in stbx)
         };
+        auto bbase = [&](int ks) { return SWZ ? stbx[ks % KS] : stb; };
+        auto bptr = [&](int ks, int t) { return bbase(ks) + (bdelta(t) + frag_off(ks)) + (straddles(t) ? fwadj : 0); };
 #pragma unroll
         for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const half8*>(wh + (m * 16) * 64 + aoff);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bf[0][t] = *reinterpret_cast<const half8*>(stb + (bdelta(t) + frag_off(0)));
+        for (int t = 0; t < NT; ++t) bf[0][t] = *reinterpret_cast<const half8*>(bptr(0, t));
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
           if (ks + 1 < KSTEPS) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bf[(ks + 1) & 1][t] = *reinterpret_cast<const half8*>(stb + (bdelta(t) + frag_off(ks + 1)));
+            for (int t = 0; t < NT; ++t) bf[(ks + 1) & 1][t] = *reinterpret_cast<const half8*>(bptr(ks + 1, t));
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -944,7 +974,8 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
       __builtin_amdgcn_s_setprio(3);
       const int j = (r - 1) >> 1;  // chunk whose k-loop this group finished in the previous slot (-1: none yet)
       if (j + 1 < J) {  // pf holds chunk j+1: its k-loop runs in the next slot
-        char* const wb = st + swz<CC, STRIDE>(gtid / CPP, gtid % CPP);  // granule i lies GTHR/CPP pixels further: immediates
+        char* const wb = st + (SWZ ? (gtid / CPP) * 64 + (((gtid % CPP) << 4) ^ (((gtid / CPP) & 4) << 3))
+                                   : swz<CC, STRIDE>(gtid / CPP, gtid % CPP));  // granule i lies GTHR/CPP pixels further: immediates
 #pragma unroll
         for (int i = 0; i < NPF; ++i)
           if (gtid + i * GTHR < NCHUNK16) *reinterpret_cast<uint4*>(wb + i * (GTHR / CPP) * PS) = pf[i];
@@ -983,8 +1014,9 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             const unsigned rloff = RESV ? (unsigned)((dpix * a.ldres + blockIdx.y * (16 * MT) + piece * 8) * 2) : 0u;
             const long rtbase = !RESV ? 0 : (FLAT ? (long)(pix0 + wgs * (NT * 16)) * a.ldres : ((long)(n * a.Ho + row0) * a.Wo + ox0) * a.ldres);
             const char* const rbase = reinterpret_cast<const char*>(a.res) + rtbase * 2;
-            const int collim = FLAT ? a.npix - (pix0 + wgs * (NT * 16)) : a.Wo - ox0;  // lanes' pixels below this are real
-            const bool full = FLAT ? collim >= NT * 16 : (collim >= TW && oy0 + TH <= a.Ho);
+            const int fwrows = a.Ho - row0 < 0 ? 0 : (a.Ho - row0 < TROWS ? a.Ho - row0 : TROWS);  // FW: rows of the strip inside the image
+            const int collim = FLAT ? a.npix - (pix0 + wgs * (NT * 16)) : (FW ? fwrows * FW : a.Wo - ox0);  // lanes' pixels below this are real
+            const bool full = LIN ? collim >= NT * 16 : (collim >= TW && oy0 + TH <= a.Ho);
             char* const xw = xs + p * XROW + q * (NC * 2);
             const char* const xr = xs + dpix * XROW + piece * 16;
             typedef uint2 __attribute__((may_alias)) uint2_a;  // (the 8-byte write and the 16-byte read are different C++ types)
@@ -998,9 +1030,9 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
               __builtin_amdgcn_wave_barrier();
               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
             };
-            auto tile_col = [](int t) { return FLAT ? t * 16 : (t & 1) * 16; };   // first pixel column of N-tile t
+            auto tile_col = [](int t) { return LIN ? t * 16 : (t & 1) * 16; };   // first pixel column of N-tile t
             auto convert_write = [&](int t) {
-              const bool rowok = FLAT ? true : row0 + (t >> 1) < a.Ho;
+              const bool rowok = LIN ? true : row0 + (t >> 1) < a.Ho;
               union { half2_ h[NC / 2]; uint4 u4[NC / 8 > 0 ? NC / 8 : 1]; uint2 u2; } hv;
               const float keep = (full || (rowok && tile_col(t) + p < collim)) ? 1.f : 0.f;
               const f32x2 k2 = {keep, keep};
@@ -1035,9 +1067,9 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             };
             union U4 { uint4 u; half2_ h[4]; };
             auto dest = [&](int t, int ps, bool& valid) {
-              const bool rowok = FLAT ? true : row0 + (t >> 1) < a.Ho;
+              const bool rowok = LIN ? true : row0 + (t >> 1) < a.Ho;
               const int c0 = tile_col(t) + ps * PIXPASS;              // compile-time column of lane group 0
-              const long soff = FLAT ? (long)c0 * a.ldy : ((long)(t >> 1) * a.Wo + c0) * a.ldy;  // scalar
+              const long soff = LIN ? (long)c0 * a.ldy : ((long)(t >> 1) * a.Wo + c0) * a.ldy;  // scalar
               valid = rowok && chok && dpix < 16 && c0 + dpix < collim;
               if (SEGY) {  // (FLAT) pixel pix0 + wgs * 64 + c0 + dpix of the lane's segment (a segment stays below 4 GB: 32-bit offset)
                 char* const pzs = sbase + (size_t)((unsigned)(pix0 + wgs * (NT * 16) + c0 + dpix) * sld2);
@@ -1055,9 +1087,9 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
                 return (valid && sacc) ? *pd : make_uint4(0, 0, 0, 0);
               }
               if (!RESV) return *dest(t, ps, valid);
-              const bool rowok = FLAT ? true : row0 + (t >> 1) < a.Ho;
+              const bool rowok = LIN ? true : row0 + (t >> 1) < a.Ho;
               const int c0 = tile_col(t) + ps * PIXPASS;
-              const long soff = FLAT ? (long)c0 * a.ldres : ((long)(t >> 1) * a.Wo + c0) * a.ldres;
+              const long soff = LIN ? (long)c0 * a.ldres : ((long)(t >> 1) * a.Wo + c0) * a.ldres;
               valid = rowok && chok && dpix < 16 && c0 + dpix < collim;
               return *reinterpret_cast<const uint4*>(valid ? rbase + soff * 2 + rloff : reinterpret_cast<const char*>(a.res));
             };
@@ -1119,13 +1151,14 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
             const int row0 = FLAT ? 0 : oy0 + wgs * TROWS;
             const long tbase = FLAT ? (long)(pix0 + wgs * (NT * 16)) * a.ldy : ((long)(n * a.Ho + row0) * a.Wo + ox0) * a.ldy;
             char* const ybase = reinterpret_cast<char*>(a.y) + tbase * 4;
-            const int collim = FLAT ? a.npix - (pix0 + wgs * (NT * 16)) : a.Wo - ox0;
+            const int fwrows = a.Ho - row0 < 0 ? 0 : (a.Ho - row0 < TROWS ? a.Ho - row0 : TROWS);
+            const int collim = FLAT ? a.npix - (pix0 + wgs * (NT * 16)) : (FW ? fwrows * FW : a.Wo - ox0);
             const unsigned loff = (unsigned)((p * a.ldy + co0) * 4);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-              const int tcol = FLAT ? t * 16 : (t & 1) * 16;
-              const bool rowok = FLAT ? true : row0 + (t >> 1) < a.Ho;
-              const long soff = FLAT ? (long)tcol * a.ldy : ((long)(t >> 1) * a.Wo + tcol) * a.ldy;
+              const int tcol = LIN ? t * 16 : (t & 1) * 16;
+              const bool rowok = LIN ? true : row0 + (t >> 1) < a.Ho;
+              const long soff = LIN ? (long)tcol * a.ldy : ((long)(t >> 1) * a.Wo + tcol) * a.ldy;
               const bool valid = rowok && tcol + p < collim;
               f32x4* const yp = reinterpret_cast<f32x4*>(ybase + soff * 4 + (valid ? loff : 0u));
               if (valid) {
@@ -1164,7 +1197,8 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
               valid = gp < a.npix;
               yoff = (size_t)gp * a.ldy;
             } else {
-              const int oy = oy0 + wg * TROWS + (t >> 1), ox = ox0 + (t & 1) * 16 + p;
+              const int fpix = t * 16 + p;  // (FW) pixel of the wave's strip
+              const int oy = oy0 + wg * TROWS + (FW ? fpix / (FW ? FW : 1) : (t >> 1)), ox = FW ? fpix % (FW ? FW : 1) : ox0 + (t & 1) * 16 + p;
               valid = oy < a.Ho && ox < a.Wo;
               yoff = ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.ldy;
             }
@@ -1766,10 +1800,11 @@ __global__ __launch_bounds__(512) void conv_mfma_dg2_kernel(ConvArgs a, int ntil
 // ---- v4 (ping-pong) host side
 #define DY_NUM_CUS 256  // MI355X
 static bool g_force_v3 = getenv("DY_CONV_V3") != nullptr;
-static size_t pp_lds_bytes(int cc, int mt, int ks, int stride, int nch, int trows) {
+static size_t pp_lds_bytes(int cc, int mt, int ks, int stride, int nch, int trows, int fw = 0) {
   const bool flat = ks == 1;
-  const int th = 4 * trows, hw = flat ? 4 * 2 * trows * 16 : 31 * stride + ks, hh = flat ? 1 : (th - 1) * stride + ks;
-  size_t tile = (size_t)hh * hw * ps_bytes(cc, stride);
+  const bool swz = ks == 3 && stride == 1 && cc == 32;  // conv_mfma_pp_kernel, SWZ: 64-byte pixels, rows padded to a multiple of 8 pixels
+  const int th = 4 * trows, hw = flat ? 4 * 2 * trows * 16 : (swz ? ((fw ? fw : 32) + 2 + 7) / 8 * 8 : 31 * stride + ks), hh = flat ? 1 : (th - 1) * stride + ks;
+  size_t tile = (size_t)hh * hw * (swz ? 64 : ps_bytes(cc, stride));
   const size_t red = 8 * 2 * 16 * mt * 4;
   if (tile < red) tile = red;
   const size_t wts = (size_t)nch * ((ks * ks * cc + 31) / 32) * 16 * mt * 64;
@@ -1786,16 +1821,59 @@ static int pp_trows(int cc, int mt, int ks, int stride, int nch) {
 }
 // workgroups of a ping-pong launch: every workgroup resident at once (one per CU, two when two fit in LDS), each owning
 // two tiles per period; this is also the number of BN partial rows the launch writes
-static int pp_grid(int cc, int mt, int ks, int stride, int nch, int trows, int ntiles) {
-  const int per_cu = 2 * pp_lds_bytes(cc, mt, ks, stride, nch, trows) <= 160 * 1024 ? 2 : 1;
+static int pp_grid(int cc, int mt, int ks, int stride, int nch, int trows, int ntiles, int fw = 0) {
+  // (the swizzled 3x3 tiles would let the 32-wide cout groups sit two per CU: measured SLOWER -- 32->32 @40x40 12.1 -> 15.5 us, @80x80
+  // 19.5 -> 22.8, @160x160 50.2 -> 57.7 -- twice the weight preloads for half the tiles each: they stay at one)
+  const bool swz_wide = ks == 3 && stride == 1 && cc == 32 && mt >= 2;
+  const int per_cu = (!swz_wide && 2 * pp_lds_bytes(cc, mt, ks, stride, nch, trows, fw) <= 160 * 1024) ? 2 : 1;
   int want = cdiv(ntiles, 2);
   const int cap = DY_NUM_CUS * per_cu;
   if (want >= 8) want = (want + 7) & ~7;  // a multiple of the XCD count, so that the XCD-aware tile map applies
   return want < cap ? want : cap;
 }
 
+// full-width tiles (conv_mfma_pp_kernel, FW): maps exactly 40 / 80 pixels wide, 3x3 stride-1 with 32-channel chunks.  DY_CONV_FW=0: off
+template <int MT, int FW>
+static int launch_pp_fw(const ConvArgs& a, int grid_y, hipStream_t s) {
+  constexpr int TR = 80 / FW;
+  static bool attr_set = false;
+  auto kern = conv_mfma_pp_kernel<32, MT, 3, 1, TR, false, FW>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DY_WLDS_BUDGET) != hipSuccess)
+      return DY_ERR_LAUNCH;
+    attr_set = true;
+  }
+  ConvArgs b = a;
+  b.tiles_x = 1;
+  b.tiles_y = cdiv(a.Ho, 4 * TR);
+  const int ntiles = b.tiles_y * a.N;
+  const int gx = pp_grid(32, MT, 3, 1, a.nch, TR, ntiles, FW);
+  hipLaunchKernelGGL(kern, dim3(gx, grid_y), dim3(512), pp_lds_bytes(32, MT, 3, 1, a.nch, TR, FW), s, b, ntiles);
+  DY_CHECK_LAUNCH();
+  return DY_OK;
+}
+// DY_CONV_FW: 0 = off, 40 (default) = 40-wide maps, 80 = 40- and 80-wide maps (measured on the step: 80-wide tiles gain nothing --
+// 32->32 @80x80 19.3 -> 18.3 us stand-alone, 11.43 vs 11.44 ms per step -- so they stay behind the switch)
+static int pp_fw_for(int cc, int mt, int ks, int stride, int nch, int wo, int dil, int epi, bool red) {
+  static const int on = getenv("DY_CONV_FW") ? atoi(getenv("DY_CONV_FW")) : 40;
+  if (!on || ks != 3 || stride != 1 || cc != 32 || dil == 2 || red) return 0;
+  if ((epi & DY_EPI_STATS) && !(epi & DY_EPI_STATS_ACC)) return 0;  // partial-row statistics: dy_conv_num_partials sizes the rows for the 32-wide tiles
+  const int fw = wo == 40 ? 40 : ((wo == 80 && on >= 80) ? 80 : 0);
+  if (!fw || pp_lds_bytes(cc, mt, ks, stride, nch, 80 / fw, fw) > DY_WLDS_BUDGET) return 0;
+  return fw;
+}
+static int pp_fw_width(const ConvArgs& a, int cc, int mt, int ks, int stride) {
+  if (a.Wo != a.Wr || a.Ho != a.Hr) return 0;
+  return pp_fw_for(cc, mt, ks, stride, a.nch, a.Wo, a.dil, a.epi, a.racc != nullptr);
+}
+
 template <int CC, int MT, int KS, int STRIDE, int TR, bool REDK = false>
 static int launch_pp(const ConvArgs& a, int grid_y, hipStream_t s) {
+  if constexpr (CC == 32 && KS == 3 && STRIDE == 1 && !REDK) {
+    const int fw = pp_fw_width(a, CC, MT, KS, STRIDE);
+    if (fw == 40) return launch_pp_fw<MT, 40>(a, grid_y, s);
+    if (fw == 80) return launch_pp_fw<MT, 80>(a, grid_y, s);
+  }
   if (!REDK && a.racc) {  // the epilogue that also runs a BatchNorm backward reduce: its own instantiation (stride-1 dgrads only), so
     if constexpr (STRIDE == 1) return launch_pp<CC, MT, KS, 1, TR, true>(a, grid_y, s);  // that its registers are not every launch's problem
     return DY_ERR_ARG;
@@ -2043,7 +2121,7 @@ extern "C" int dy_conv_kernel_name(int cin, int cout, int ks, int stride, char* 
   if (!out || cap < 8 || dy_conv_geometry(cin, cout, ks, stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return DY_ERR_ARG;
   const int pp = pp_trows(cc, mt, ks, stride, nch);
   if (pp) {
-    snprintf(out, cap, "conv_mfma_pp_kernel<%d, %d, %d, %d, %d, false>", cc, mt, ks, stride, pp);  // "true": dy_conv_input_grad_red
+    snprintf(out, cap, "conv_mfma_pp_kernel<%d, %d, %d, %d, %d, false, 0>", cc, mt, ks, stride, pp);  // "true": dy_conv_input_grad_red
     return DY_OK;
   }
   const int cfg = (g_force_v1 || (cc == 64 && stride == 2)) ? 0 : v3_trows(cc, mt, ks, stride, nch);
@@ -2051,6 +2129,19 @@ extern "C" int dy_conv_kernel_name(int cin, int cout, int ks, int stride, char* 
   else if (cfg == 4 && ks == 3 && stride == 1) snprintf(out, cap, "conv_mfma_wlds_kernel<%d, %d, %d, %d, 2, 4>", cc, mt, ks, stride);
   else if (cfg == 1) snprintf(out, cap, "conv_mfma_wlds_kernel<%d, %d, %d, %d, 1, 8>", cc, mt, ks, stride);
   else snprintf(out, cap, "conv_mfma_kernel<%d, %d, %d, %d, %d>", cc, mt, ks, stride, (ks == 3 && stride == 2) ? 1 : 2);
+  return DY_OK;
+}
+
+// ... for a given output width and epilogue: maps exactly 40 (80) pixels wide take the full-width tiles of conv_mfma_pp_kernel (last
+// template argument), whose launches rocprofv3 lists as a kernel of their own
+extern "C" int dy_conv_kernel_name_at(int cin, int cout, int ks, int stride, int out_w, int dil, int epi, char* out, int cap) {
+  const int rc = dy_conv_kernel_name(cin, cout, ks, stride, out, cap);
+  if (rc != DY_OK) return rc;
+  int cp, op, cc, nch, mt, ng, kst, pe;
+  dy_conv_geometry(cin, cout, ks, stride, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe);
+  const int pp = pp_trows(cc, mt, ks, stride, nch);
+  const int fw = pp ? pp_fw_for(cc, mt, ks, stride, nch, out_w, dil, epi, false) : 0;
+  if (fw) snprintf(out, cap, "conv_mfma_pp_kernel<%d, %d, %d, %d, %d, false, %d>", cc, mt, ks, stride, 80 / fw, fw);
   return DY_OK;
 }
 

@@ -645,7 +645,8 @@ class StepPlan:
             n, h, w, cin, cout, ks, stride, dil = args[7:15]
             if dil == 2 and ks == 3:
                 return f"conv_mfma_dg2_kernel (input gradient of the {cout}->{cin} stride-2 3x3)", self.conv_algorithmic_bytes(args)
-            if L.dy_conv_kernel_name(cin, cout, ks, stride, buf, 128) == 0:
+            pad = ks // 2
+            if L.dy_conv_kernel_name_at(cin, cout, ks, stride, (w + 2 * pad - ks) // stride + 1, dil, int(args[17]), buf, 128) == 0:
                 return buf.value.decode(), self.conv_algorithmic_bytes(args)
         if name == "dy_conv_wgrad":
             n, h, w, cin, cout, ks, stride = args[6:13]
@@ -654,7 +655,7 @@ class StepPlan:
         if name == "dy_conv_input_grad_red":  # (dy, lddy, w, dx, lddx, n, h, w, cin, cout, ks, ...): a stride-1 input gradient
             n, h, w, cin, cout, ks = args[5:11]
             if L.dy_conv_kernel_name(cin, cout, ks, 1, buf, 128) == 0:
-                return buf.value.decode().replace("false>", "true>"), n * h * w * (cin + cout) * 2
+                return buf.value.decode().replace("false, 0>", "true, 0>"), n * h * w * (cin + cout) * 2
         if name == "dy_stem_forward":  # (img, w, raw, ldraw, acc, n, h, w, mul): 3 input channels read once, 16 output channels written once
             n, h, w = args[5:8]
             return "stem_fwd_kernel", n * h * w * 3 * 2 + n * ((h - 1) // 2 + 1) * ((w - 1) // 2 + 1) * 16 * 2

@@ -103,6 +103,9 @@ int dy_conv_input_grad_red(const void* dy, int lddy, const void* w_packed_t, voi
                            int ks, const void* raw, int ldraw, const float* coef, double* acc, int C, hipStream_t stream);
 /* host-side: the kernel instantiation dy_conv_forward launches for this geometry, spelled as rocprofv3 prints it */
 int dy_conv_kernel_name(int cin, int cout, int ks, int stride, char* out, int cap);
+/* ... for a launch with this output width, dilation and epilogue: maps exactly 40 pixels wide run 3x3 stride-1 convs of 32-channel
+ * chunks on full-width tiles (conv_mfma_pp_kernel's last template argument), which rocprofv3 lists as a kernel of their own */
+int dy_conv_kernel_name_at(int cin, int cout, int ks, int stride, int out_w, int dil, int epi, char* out, int cap);
 
 /* ---- weight-gradient half of aten::convolution_backward for the same modules. dw: fp32 OIHW (cout,cin,ks,ks). -- */
 int dy_wgrad_workspace(int n, int h, int w, int cin, int cout, int ks, int stride, int* nslabs, long* slab_elems);

@@ -60,7 +60,9 @@ def test_conv_kernel_name_helper():
     from ultralytics.hip import lib
     L = lib()
     buf = C.create_string_buffer(128)
-    assert L.dy_conv_kernel_name(64, 64, 3, 1, buf, 128) == 0 and buf.value == b"conv_mfma_pp_kernel<32, 4, 3, 1, 2, false>"
+    assert L.dy_conv_kernel_name(64, 64, 3, 1, buf, 128) == 0 and buf.value == b"conv_mfma_pp_kernel<32, 4, 3, 1, 2, false, 0>"
+    assert L.dy_conv_kernel_name_at(64, 64, 3, 1, 40, 1, 0, buf, 128) == 0 and buf.value == b"conv_mfma_pp_kernel<32, 4, 3, 1, 2, false, 40>"
+    assert L.dy_conv_kernel_name_at(64, 64, 3, 1, 48, 1, 0, buf, 128) == 0 and buf.value == b"conv_mfma_pp_kernel<32, 4, 3, 1, 2, false, 0>"
     assert L.dy_conv_kernel_name(64, 64, 1, 1, buf, 128) == 0 and buf.value.startswith(b"conv_mfma_pp_kernel<64, 4, 1, 1,")
     assert L.dy_conv_kernel_name(64, 64, 5, 1, buf, 128) != 0
     # the weight gradient of the same layer: one (64, 64) channel block per workgroup on a large map, (32, 32) blocks on a 40x40 one,

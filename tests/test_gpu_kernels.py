@@ -2,6 +2,7 @@
 storage format of the path; accumulation is fp32 on both sides).  Tolerances are relative to the largest reference
 magnitude: 2e-3 covers the single fp16 rounding of the output, 5e-3 two roundings (bn/act chains)."""
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -43,6 +44,8 @@ CONV_CASES = [  # cin, cout, ks, s, H, W
     (16, 16, 3, 1, 33, 35), (64, 80, 1, 1, 6, 6), (192, 128, 1, 1, 5, 7),
     # padded cout group (48 -> MT = 4), 128-channel layers with narrowed cout groups, parity-class stride-2 dgrad at odd sizes
     (32, 48, 3, 1, 10, 14), (128, 128, 3, 1, 12, 12), (64, 64, 3, 2, 15, 17), (128, 64, 3, 2, 9, 9), (64, 48, 1, 1, 11, 3),
+    # maps 40 / 80 pixels wide (full-width tiles), heights that end inside a wave's strip
+    (32, 32, 3, 1, 37, 40), (128, 64, 3, 1, 11, 40), (64, 32, 3, 1, 5, 80),
 ]
 
 
@@ -101,6 +104,32 @@ def test_conv_forward_dgrad_wgrad(cin, cout, ks, s, H, W):
         assert relerr(xa.st.gbuf[..., :cin].permute(0, 3, 1, 2).float(), 2 * xr.grad) < 3e-3
         assert relerr(sp.gweight, 2 * wr.grad) < 3e-4
     _ = coutp
+
+
+def test_full_width_tiles_give_the_bits_of_the_32_column_tiles(tmp_path):
+    """conv_mfma_pp_kernel's full-width tiles (maps exactly 40 / 80 pixels wide: a wave owns an 80-pixel strip instead of 2 x 32
+    columns, csrc/conv.hip FW) change WHICH pixels a wave computes, not how a pixel is computed: chunk / tap order per output is the
+    same, so every epilogue's output must be EQUAL to the 32-column scheme's -- plain store, BatchNorm statistics (the sums to fp32
+    rounding: a workgroup's fp32 partial sums cover other pixels, 6e-8 measured), bias + SiLU, accumulate, residual, fp32 + bias;
+    heights that end inside a strip included."""
+    import subprocess
+    import sys
+    outs = {}
+    for fw in ("0", "80"):
+        f = tmp_path / f"fw{fw}.pt"
+        env = dict(os.environ, DY_CONV_FW=fw)
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "fw_worker.py"), str(f)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[fw] = torch.load(f)
+    assert outs["0"].keys() == outs["80"].keys() and len(outs["0"]) > 50
+    for k, a in outs["0"].items():
+        b = outs["80"][k]
+        assert torch.isfinite(a.float()).all() and float(a.float().abs().max()) > 0, k
+        if k.endswith("stats_acc"):
+            assert relerr(b, a) < 1e-6, k
+        else:
+            assert torch.equal(a, b), f"{k}: max diff {float((a.float() - b.float()).abs().max()):.3e}"
 
 
 @pytest.mark.parametrize("C_,act", [(16, 1), (64, 1), (32, 2), (128, 0)])
