@@ -55,7 +55,8 @@ BIAS_WGRAD = BN_ACC and os.environ.get("DY_BIAS_WGRAD", "1") != "0"
 # gradient.  MEASURED SLOWER (round 3, one box, alternating): 12.87 ms per step without, 13.06 ms with it for outputs up to 32 channels,
 # 15.34 ms up to 64 channels (those instantiations spill): exp + rcp per element in the memory slot of the ping-pong kernel make that
 # slot, not the MFMA slot, set the pace (a fused 32->32 3x3 dgrad at 160x160: 90-107 us against ~50 us + ~50 us for the two launches).
-# Off by default; DY_BN_DGRED=1 enables it, DY_BN_DGRED_MAXC bounds the output width it is used for.
+# Off by default; DY_BN_DGRED=1 enables it, DY_BN_DGRED_MAXC bounds the output width it is used for, DY_BN_DGRED_MAXPIX the map size
+# (round 4: restricted to the latency-bound maps <= 80x80 it still loses, 11.44 -> 11.48-11.51 ms: profiles/r04_stage_ab.md).
 # SPPF's three chained 5x5 pools (and their backward chain) as one launch each with the map resident in LDS, when it fits
 # (Engine.sppf_pools); maps that do not fit take three dy_maxpool5 / dy_maxpool5_backward launches (the form a test flips this to).
 SPPF_FUSED = True
@@ -102,6 +103,7 @@ PLANAR = os.environ.get("DY_PLANAR", "1") != "0"
 HEAD_APPLY = HEAD_DECODE and os.environ.get("DY_SILU_FAST", "1") != "0" and os.environ.get("DY_HEAD_APPLY", "1") != "0"
 BN_DGRED = BN_WGRAD and os.environ.get("DY_BN_DGRED", "0") != "0"
 BN_DGRED_MAXC = int(os.environ.get("DY_BN_DGRED_MAXC", "64"))
+BN_DGRED_MAXPIX = int(os.environ.get("DY_BN_DGRED_MAXPIX", str(1 << 40)))  # ... and the map size (N*H*W): small maps are latency-bound
 
 
 def dev_empty(shape, dtype, device):
@@ -1026,7 +1028,7 @@ class Engine:
             prod = self._sole_consumer_of_conv(x) if (BN_DGRED and not acc and spec.stride == 1 and spec.ld is None) else None
             if prod is not None:
                 ps, praw = prod
-                if not (ps.act == DY_ACT_SILU and ps.acc_b is not None and ps.cout == x.C == spec.cin and x.C <= BN_DGRED_MAXC
+                if not (ps.act == DY_ACT_SILU and ps.acc_b is not None and ps.cout == x.C == spec.cin and x.C <= BN_DGRED_MAXC and x.npix <= BN_DGRED_MAXPIX
                         and (praw.N, praw.H, praw.W) == (x.N, x.H, x.W)
                         and self.L.dy_conv_red_supported(spec.cout_phys, spec.cin, spec.ks)):
                     prod = None
