@@ -2024,6 +2024,17 @@ static int segs_chunk(int cin, int cout, const DySegs* s) {
 extern "C" int dy_conv1x1_segs_supported(int cin, int cout, const DySegs* xs) {
   return (segs_valid(xs, cin) && segs_chunk(cin, cout, xs) != 0) ? 1 : 0;
 }
+// the instantiation dy_conv1x1_forward_segs launches for these segments, spelled as rocprofv3 prints it (see dy_conv_kernel_name)
+extern "C" int dy_conv1x1_segs_kernel_name(int cin, int cout, const DySegs* xs, char* out, int cap) {
+  if (!out || cap < 8 || !segs_valid(xs, cin)) return DY_ERR_ARG;
+  const int c = segs_chunk(cin, cout, xs);
+  int cp, op, cc, nch, mt, ng, kst, pe;
+  if (!c || dy_conv_geometry(cin, cout, 1, 1, &cp, &op, &cc, &nch, &mt, &ng, &kst, &pe) != DY_OK) return DY_ERR_ARG;
+  const int pp = pp_trows(c, mt, 1, 1, cin / c);
+  if (!pp) return DY_ERR_ARG;
+  snprintf(out, cap, "conv_mfma_pp_kernel<%d, %d, 1, 1, %d, false, 0>", c, mt, pp);
+  return DY_OK;
+}
 // dy_conv_forward for a 1x1 convolution whose INPUT is the concatenation xs (n, h, w, cin = xs->c_end[last]): Conv.forward over
 // torch.cat(...) (reference nn/modules/block.py:222-226 C2f, :166-171 SPPF, nn/modules/conv.py:338-348 Concat) without the cat.
 extern "C" int dy_conv1x1_forward_segs(const DySegs* xs, const void* w_packed, const float* bias, void* y, int ldy, float* partials, int n,

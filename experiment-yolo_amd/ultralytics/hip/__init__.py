@@ -81,6 +81,7 @@ SIGNATURES = {
     "dy_conv_red_supported": (i32, [i32, i32, i32]),
     "dy_conv_input_grad_red": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp]),
     "dy_conv_kernel_name": (i32, [i32, i32, i32, i32, C.c_char_p, i32]),
+    "dy_conv1x1_segs_kernel_name": (i32, [i32, i32, C.POINTER(DySegs), C.c_char_p, i32]),
     "dy_conv_kernel_name_at": (i32, [i32, i32, i32, i32, i32, i32, i32, C.c_char_p, i32]),
     "dy_wgrad_kernel_name": (i32, [i32, i32, i32, i32, C.c_char_p, i32]),
     "dy_wgrad_kernel_name_at": (i32, [i32, i32, i32, i32, i32, i32, i32, C.c_char_p, i32]),

@@ -636,6 +636,13 @@ class StepPlan:
         elif name == "dy_stem_wgrad_bn":
             n, h, w = args[11:14]
             own = alg + n * ((h - 1) // 2 + 1) * ((w - 1) // 2 + 1) * 16 * e
+        elif name in ("dy_conv1x1_wgrad_bn_segs", "dy_conv1x1_wgrad_bn_planes") and alg:  # + raw read and d(raw) written
+            n, h, w, _cin, cout = args[13:18] if name.endswith("segs") else args[17:22]
+            own = alg + 2 * n * h * w * ((cout + 7) // 8 * 8) * e
+        elif name == "dy_bn_act_apply_acc_split":
+            own = int(args[13]) * int(args[14]) * e * 2
+        elif name == "dy_bn_act_bwd_reduce_acc_split":
+            own = int(args[9]) * int(args[10]) * e * 2
         return key, alg, own
 
     def _kernel_alg(self, name, args):
@@ -648,6 +655,20 @@ class StepPlan:
             pad = ks // 2
             if L.dy_conv_kernel_name_at(cin, cout, ks, stride, (w + 2 * pad - ks) // stride + 1, dil, int(args[17]), buf, 128) == 0:
                 return buf.value.decode(), self.conv_algorithmic_bytes(args)
+        # 1x1 convolutions over a never-materialised concatenation (the segment table travels by reference: args[k]._obj)
+        if name == "dy_conv1x1_forward_segs":
+            n, h, w, cin, cout = args[6:11]
+            if L.dy_conv1x1_segs_kernel_name(cin, cout, args[0], buf, 128) == 0:
+                return buf.value.decode(), n * h * w * (cin + (cout + 7) // 8 * 8) * 2
+        if name == "dy_conv1x1_input_grad_segs":  # (dy, lddy, w^T, dxs, n, h, w, channels of dy, channels of the concatenation)
+            n, h, w, cin, cout = args[4:9]
+            if L.dy_conv_kernel_name(cin, cout, 1, 1, buf, 128) == 0:
+                return buf.value.decode(), n * h * w * (cin + cout) * 2
+        if name in ("dy_conv1x1_wgrad_bn_segs", "dy_conv1x1_wgrad_bn_planes"):
+            n, h, w, cin, cout = args[13:18] if name.endswith("segs") else args[17:22]
+            if L.dy_wgrad_kernel_name_at(n, h, w, cin, cout, 1, 1, buf, 128) == 0:
+                seg = args[0] is not None
+                return buf.value.decode().replace(", 0>", ", 3>" if seg else ", 1>"), n * h * w * (cin + (cout + 7) // 8 * 8) * 2
         if name == "dy_conv_wgrad":
             n, h, w, cin, cout, ks, stride = args[6:13]
             if L.dy_wgrad_kernel_name_at(n, h, w, cin, cout, ks, stride, buf, 128) == 0:
@@ -684,6 +705,10 @@ class StepPlan:
                 "dy_bn_act_bwd_apply_acc": ("bn_act_bwd_apply_kernel<{}, true>", 12)}
         if name == "dy_bn_act_bwd_reduce_acc":  # <activation, shortcut gradient passed on>
             return f"bn_act_bwd_reduce_kernel<{int(args[8])}, {'true' if args[9] else 'false'}>", 0
+        if name == "dy_bn_act_bwd_reduce_acc_split":
+            return f"bn_act_bwd_reduce_kernel<{int(args[11])}, false>", 0
+        if name == "dy_bn_act_apply_acc_split":
+            return f"bn_act_apply_kernel<{int(args[15])}, true, true>", 0
         if name in tmpl:
             k, i = tmpl[name]
             return k.format(int(args[i])), 0

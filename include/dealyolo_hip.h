@@ -131,6 +131,7 @@ int dy_conv_wgrad_ld_bn(const void* x, int ldx, const void* dy, int lddy, const 
  * apply inside (dy_conv_wgrad_bn with xs in place of (x, ldx)).  dy_conv1x1_segs_supported: a Cin chunk exists that no segment boundary
  * cuts (the geometry's own, or 32 where that is 64: same packed weights) and the ping-pong kernel takes the shape. */
 int dy_conv1x1_segs_supported(int cin, int cout, const DySegs* xs);
+int dy_conv1x1_segs_kernel_name(int cin, int cout, const DySegs* xs, char* out, int cap); /* as dy_conv_kernel_name, for dy_conv1x1_forward_segs */
 int dy_conv1x1_forward_segs(const DySegs* xs, const void* w_packed, const float* bias, void* y, int ldy, float* partials, int n, int h,
                             int w, int cin, int cout, int epi, hipStream_t stream);
 int dy_conv1x1_input_grad_segs(const void* dy, int lddy, const void* w_packed_t, const DySegs* dxs, int n, int h, int w, int cin, int cout,
