@@ -65,6 +65,20 @@ def test_conv_kernel_name_helper():
     assert L.dy_conv_kernel_name_at(64, 64, 3, 1, 48, 1, 0, buf, 128) == 0 and buf.value == b"conv_mfma_pp_kernel<32, 4, 3, 1, 2, false, 0>"
     assert L.dy_conv_kernel_name(64, 64, 1, 1, buf, 128) == 0 and buf.value.startswith(b"conv_mfma_pp_kernel<64, 4, 1, 1,")
     assert L.dy_conv_kernel_name(64, 64, 5, 1, buf, 128) != 0
+    # a 1x1 conv over a never-materialised concatenation stages the chunk no segment boundary cuts: four 32-channel members -> 32
+    # (the dense 128-channel input takes 64), three 16-channel members -> 16
+    from ultralytics.hip import DySegs
+    t = DySegs()
+    t.nseg = 4
+    for i in range(4):
+        t.c_end[i], t.ld[i], t.ptr[i] = 32 * (i + 1), 32, 4096
+    assert L.dy_conv1x1_segs_kernel_name(128, 64, C.byref(t), buf, 128) == 0 and buf.value == b"conv_mfma_pp_kernel<32, 4, 1, 1, 2, false, 0>"
+    assert L.dy_conv_kernel_name(128, 64, 1, 1, buf, 128) == 0 and buf.value == b"conv_mfma_pp_kernel<64, 4, 1, 1, 2, false, 0>"
+    t.nseg = 3
+    for i in range(3):
+        t.c_end[i], t.ld[i] = 16 * (i + 1), 16
+    assert L.dy_conv1x1_segs_kernel_name(48, 32, C.byref(t), buf, 128) == 0 and buf.value == b"conv_mfma_pp_kernel<16, 2, 1, 1, 2, false, 0>"
+    assert L.dy_conv1x1_segs_kernel_name(64, 32, C.byref(t), buf, 128) != 0  # the table does not cover the channels
     # the weight gradient of the same layer: one (64, 64) channel block per workgroup on a large map, (32, 32) blocks on a 40x40 one,
     # where the fp32 weight slabs of 256 workgroup columns would outweigh the activations
     assert L.dy_wgrad_kernel_name(64, 64, 3, 1, buf, 128) == 0 and buf.value == b"conv_wgrad_kernel<3, 1, 4, 4, 0>"
