@@ -710,8 +710,9 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
     const unsigned long long base = (unsigned long long)(reinterpret_cast<const f16*>(a.xs.ptr[sg]) + (ch0 - cb));
     xtab[tid * 4 + 0] = (unsigned)base;
     xtab[tid * 4 + 1] = (unsigned)(base >> 32);
-    xtab[tid * 4 + 2] = (unsigned)a.xs.ld[sg];
-    xtab[tid * 4 + 3] = (unsigned)a.npix * (unsigned)a.xs.ld[sg] * 2u - (unsigned)(ch0 - cb) * 2u;
+    const bool up = (a.xs.acc[sg] & 2) != 0;  // the segment is a 2x nearest-neighbour up-sampling of a (N, H/2, W/2) tensor (DySegs)
+    xtab[tid * 4 + 2] = (unsigned)a.xs.ld[sg] | (up ? 0x80000000u : 0u);
+    xtab[tid * 4 + 3] = (up ? (unsigned)(a.N * (a.H >> 1) * (a.W >> 1)) : (unsigned)a.npix) * (unsigned)a.xs.ld[sg] * 2u - (unsigned)(ch0 - cb) * 2u;
   }
   // Segmented output (1x1 input gradient): this lane's 8-channel piece lives in ONE segment for the whole launch -- its base at the
   // piece's channel, its pixel stride in bytes, whether that segment accumulates
@@ -818,9 +819,32 @@ __global__ __launch_bounds__(512) void conv_mfma_pp_kernel(ConvArgs a, int ntile
         // segmented input: the chunk's own base pointer and pixel stride from the table the prologue left in LDS
         const uint4 e = *reinterpret_cast<const uint4*>(xtab + (h < 16 ? h : 15) * 4);
         const unsigned blo = __builtin_amdgcn_readfirstlane(e.x), bhi = __builtin_amdgcn_readfirstlane(e.y);
-        const int ld = __builtin_amdgcn_readfirstlane(e.z);
+        const unsigned ldw = __builtin_amdgcn_readfirstlane(e.z);
+        const int ld = (int)(ldw & 0x7fffffffu);
         const f16* base = reinterpret_cast<const f16*>(((unsigned long long)bhi << 32) | blo);
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(base), 0, (int)__builtin_amdgcn_readfirstlane(e.w), 0x00020000);
+        if (ldw >> 31) {
+          // an UP-SAMPLED segment (reference nn.Upsample(None, 2, 'nearest') in front of a Concat: models/*.yaml): pixel (n, y, x) of the
+          // concatenation reads pixel (n, y >> 1, x >> 1) of the low-resolution tensor -- the four-times-larger copy is never written.
+          // The tile's first pixel is decomposed once (wave-uniform integer divisions); a lane's pixel lies < 256 further, so its
+          // row / image carries are two exact float divisions of small integers.
+          const int g0 = tile * HW_;
+          const int hw = a.H * a.W;
+          const int n0 = g0 / hw, r0 = g0 - n0 * hw, y0 = r0 / a.W, x0 = r0 - y0 * a.W;
+          const float invW = 1.0f / (float)a.W, invH = 1.0f / (float)a.H;
+          const int Hh = a.H >> 1, Wh = a.W >> 1;
+#pragma unroll
+          for (int i = 0; i < NPF; ++i) {
+            const int id = gtid + i * GTHR, lp = id / CPP;
+            const int xx = x0 + lp, dy_ = (int)(((float)xx + 0.5f) * invW), x = xx - dy_ * a.W;
+            const int yt = y0 + dy_, dn = (int)(((float)yt + 0.5f) * invH), y = yt - dn * a.H;
+            const bool ok = id < NCHUNK16 && g0 + lp < a.npix;
+            const unsigned off = ok ? (unsigned)(((((n0 + dn) * Hh + (y >> 1)) * Wh + (x >> 1)) * ld + (id % CPP) * 8) * 2) : NEVER;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
+            pf[i] = *reinterpret_cast<const uint4*>(&v);
+          }
+          return;
+        }
         const unsigned org = (unsigned)tile * HW_ * ld * 2u;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -2042,6 +2066,8 @@ extern "C" int dy_conv1x1_forward_segs(const DySegs* xs, const void* w_packed, c
   if (!segs_valid(xs, cin)) return DY_ERR_ARG;
   const int c = segs_chunk(cin, cout, xs);
   if (!c) return DY_ERR_ARG;
+  for (int k = 0; k < xs->nseg; ++k)  // an up-sampled member (acc bit 1) halves both map sides
+    if ((xs->acc[k] & 2) && ((h | w) & 1)) return DY_ERR_ARG;
   const RedHost red{nullptr, 0, nullptr, nullptr, 0, nullptr, 0, xs, nullptr, c};
   return conv_forward_impl(nullptr, 0, w_packed, bias, y, ldy, partials, n, h, w, cin, cout, 1, 1, 1, 0, 0, epi, nullptr, stream, &red);
 }

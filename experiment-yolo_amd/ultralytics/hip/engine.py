@@ -65,6 +65,10 @@ SPPF_FUSED = True
 # planes, the backward reduce and the weight-gradient kernel read the gradient from both (dy_*_split / dy_conv1x1_wgrad_bn_planes).
 # DY_PLANAR_CV1=0: cv1 writes one 2c-wide tensor, the second half is a channel slice of it.
 PLANAR_CV1 = os.environ.get("DY_PLANAR_CV1", "1") != "0"
+# Inference: nn.Upsample(None, 2, 'nearest') in front of a Concat (every model YAML's top-down path) is never executed -- the 1x1 conv
+# behind the concatenation reads pixel (y >> 1, x >> 1) of the low-resolution tensor where it stages that member (UpAct; DySegs.acc = 2).
+# DY_UPSEG=0: dy_upsample2x writes the four-times-larger copy.
+UPSEG = os.environ.get("DY_UPSEG", "1") != "0"
 # Add's backward hands the sum's gradient buffer to an operand that has no other consumer instead of copying it (Engine.add).
 ADD_ALIAS = os.environ.get("DY_ADD_ALIAS", "1") != "0"
 # The Add that follows ScalSeq (ASF models) folded into ScalSeq's tail kernel as a residual operand (nn/tasks.py, forward_act).
@@ -261,6 +265,22 @@ class ImageAct:
         if self._act is None:
             self._act = self.eng.import_image(self.img, 8, self.mul)
         return self._act
+
+
+class UpAct:
+    """``nn.Upsample(None, 2, 'nearest')`` of ``src`` that has not been executed (inference only: no gradient path).  As a member of a
+    SegAct the segmented 1x1 conv reads the low-resolution tensor directly; anything else asks ``Engine.dense`` to run the launch."""
+    needs_grad = False
+
+    def __init__(self, src):
+        self.src = src
+        self.N, self.H, self.W, self.C = src.N, 2 * src.H, 2 * src.W, src.C
+        self.st, self.c0 = src.st, src.c0  # (dtype checks look at the storage)
+        self._full = None
+
+    ld = property(lambda s: s.src.ld)
+    ptr = property(lambda s: s.src.ptr)
+    npix = property(lambda s: 4 * s.src.npix)
 
 
 class SegAct:
@@ -664,7 +684,7 @@ class Engine:
         for i, q in enumerate(x.parts):
             end += q.C
             t.c_end[i], t.ld[i], t.ptr[i] = end, q.ld, (q.gptr if grad else q.ptr)
-            t.acc[i] = int(acc[i]) if acc is not None else 0
+            t.acc[i] = int(acc[i]) if acc is not None else (2 if isinstance(q, UpAct) else 0)
         return t
 
     def seg_conv_ok(self, spec, x):
@@ -699,7 +719,12 @@ class Engine:
         return sts[0].act(), sts[1].act()
 
     def dense(self, x):
-        """``x`` as ONE tensor: a SegAct is copied together (and its gradient split again in the backward pass); Acts pass through."""
+        """``x`` as ONE tensor: a SegAct is copied together (and its gradient split again in the backward pass), an UpAct is executed;
+        Acts pass through."""
+        if isinstance(x, UpAct):
+            if x._full is None:
+                x._full = self._upsample_now(x.src)
+            return x._full
         return self._concat_copy(x.parts) if isinstance(x, SegAct) else x
 
     def _conv_raw(self, spec, x, y_ptr, ldy, epi, partials_ptr=0, bias=None):
@@ -736,7 +761,7 @@ class Engine:
                 self.call("dy_bn_act_apply", raw.ptr, raw.ld, 0, 0, y.ptr, y.ld, spec.coef.data_ptr(), y.npix, spec.cout, spec.act)
                 return y
             x = x.materialize()
-        if isinstance(x, SegAct) and not self.seg_conv_ok(spec, x):
+        if isinstance(x, UpAct) or (isinstance(x, SegAct) and not self.seg_conv_ok(spec, x)):
             x = self.dense(x)
         assert x.C == spec.cin_phys, (spec.name, x.C, spec.cin_phys)
         Ho, Wo = self.out_hw(spec, x)
@@ -1078,7 +1103,7 @@ class Engine:
                           x.mul, 1 if spec.act == DY_ACT_SILU else 0)
                 return y
             x = x.materialize()
-        if isinstance(x, SegAct) and not self.seg_conv_ok(spec, x):
+        if isinstance(x, UpAct) or (isinstance(x, SegAct) and not self.seg_conv_ok(spec, x)):
             x = self.dense(x)
         Ho, Wo = self.out_hw(spec, x)
         y = out if out is not None else self.new_act(x.N, Ho, Wo, spec.cout)
@@ -1273,6 +1298,11 @@ class Engine:
 
     def upsample2x(self, x: Act, out: Act | None = None):
         x = self.dense(x)
+        if (UPSEG and PLANAR and out is None and self.tape is None and not self.training and x.st.buf.dtype == torch.float16):
+            return UpAct(x)  # inference: left to the consumer (a Concat member read through the segment table, or Engine.dense)
+        return self._upsample_now(x, out)
+
+    def _upsample_now(self, x: Act, out: Act | None = None):
         y = out if out is not None else self.new_act(x.N, 2 * x.H, 2 * x.W, x.C)
         self._use(x)
         self.call("dy_upsample2x", x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, 0, 0)
@@ -1382,7 +1412,10 @@ class Engine:
         off = 0
         parts = []
         for t in xs:
-            self.call("dy_copy_slice", t.ptr, t.ld, y.ptr + 2 * off, y.ld, t.npix, t.C)
+            if isinstance(t, UpAct):  # (inference) the up-sampling that was left to its consumer, written straight into its slice
+                self.call("dy_upsample2x", t.src.ptr, t.src.ld, y.ptr + 2 * off, y.ld, t.src.N, t.src.H, t.src.W, t.C, 0, 0)
+            else:
+                self.call("dy_copy_slice", t.ptr, t.ld, y.ptr + 2 * off, y.ld, t.npix, t.C)
             parts.append((t, off))
             off += t.C
         if self.tape is not None:

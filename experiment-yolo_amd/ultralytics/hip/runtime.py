@@ -252,8 +252,8 @@ class HipModule(nn.Module):
         return self._export(rt, y)
 
     def _export(self, rt, y):
-        from .engine import SegAct
-        if isinstance(y, SegAct):
+        from .engine import SegAct, UpAct
+        if isinstance(y, (SegAct, UpAct)):
             y = rt.eng.dense(y)
         if isinstance(y, Act):
             return rt.to_tensor(y)

@@ -174,7 +174,7 @@ class BaseModel(HipModule):
     def forward_act(self, x, out=None):
         """BaseModel._predict_once (reference tasks.py:85-126) over engine Acts."""
         eng = self.rt.eng
-        from ..hip.engine import PLANAR, SegAct
+        from ..hip.engine import PLANAR, SegAct, UpAct
         # (PLANAR: a Concat's inputs stay where their producers put them -- the 1x1 conv behind it reads them through a segment table)
         plan = {} if PLANAR else self._concat_plan()
         ys, cats = [], {}
@@ -224,7 +224,7 @@ class BaseModel(HipModule):
             x = m.forward_act(x, dst) if dst is not None else m.forward_act(x)
             ys.append(x if m.i in self.save else None)
             if self.__dict__.get("_capture") is not None:  # tests: per-layer outputs (engine Acts) of this forward
-                self._capture.append(eng.dense(x) if isinstance(x, SegAct) else x)
+                self._capture.append(eng.dense(x) if isinstance(x, (SegAct, UpAct)) else x)
         return x
 
     def _export(self, rt, y):

@@ -42,7 +42,10 @@ typedef struct DySegs {
   int nseg;                      /* 1..DY_MAX_SEGS */
   int c_end[DY_MAX_SEGS];        /* exclusive end channel of segment s in the concatenated tensor (multiples of 8, increasing) */
   int ld[DY_MAX_SEGS];           /* pixel stride of segment s in elements */
-  int acc[DY_MAX_SEGS];          /* as an OUTPUT: 1 = add to what the segment holds (gradient fan-in), 0 = store */
+  int acc[DY_MAX_SEGS];          /* as an OUTPUT: 1 = add to what the segment holds (gradient fan-in), 0 = store.  As the INPUT of
+                                    dy_conv1x1_forward_segs: 2 = the segment is nn.Upsample(None, 2, 'nearest') of a (n, h/2, w/2) tensor
+                                    (ptr / ld are that tensor's): pixel (y, x) reads (y >> 1, x >> 1), the up-sampled copy in front
+                                    of the reference's Concat (the head of every cfg/models YAML) is never written */
   const void* ptr[DY_MAX_SEGS];  /* first channel of segment s */
 } DySegs;
 int dy_segs_bytes(void); /* sizeof(DySegs) in the library (bindings check their layout) */

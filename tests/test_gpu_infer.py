@@ -172,3 +172,51 @@ def test_split_tail_cout_group_is_the_same_convolution(monkeypatch):
     e = relerr(outs[0], outs[1])
     print(f"split vs padded tail group: {e:.2e}")
     assert e < 1e-5
+
+
+@pytest.mark.parametrize("N,h,w,ca,cb,cout", [(9, 3, 3, 32, 32, 32), (2, 20, 20, 64, 64, 64), (3, 5, 7, 32, 64, 48), (1, 40, 40, 128, 64, 128),
+                                              (5, 2, 8, 64, 128, 64)])
+def test_upsampled_concat_member_is_read_where_it_lies(N, h, w, ca, cb, cout):
+    """nn.Upsample(None, 2, 'nearest') in front of a Concat (reference cfg/models/*.yaml, top-down path) left to the 1x1 conv behind
+    the concatenation (engine.UpAct, DySegs.acc = 2): the staging reads pixel (y >> 1, x >> 1) of the low-resolution tensor -- the
+    same values the materialised copy holds, so the output must be EQUAL; maps smaller than a 256-pixel tile (a tile then spans
+    several images) and channel-sliced members included."""
+    from ultralytics.hip.engine import ConvSpec, Engine, SegAct, Storage, UpAct
+    eng = Engine("cuda:0")
+    eng.training = False
+    g = torch.Generator().manual_seed(N * 100 + h * 10 + w)
+    wt = (torch.randn(cout, ca + cb, 1, 1, generator=g) / (ca + cb) ** 0.5).cuda()
+    sp = ConvSpec("c", wt, torch.randn(cout, generator=g).cuda(), None, 1, 1, 1)
+    eng.prepare_conv(sp)
+    eng.pack(sp, transposed=False)
+    a = Storage(eng, N, h, w, ca + 16)     # the low-resolution member is a channel slice of a wider buffer
+    a.buf.copy_(torch.randn(N, h, w, ca + 16, generator=g).half())
+    b = Storage(eng, N, 2 * h, 2 * w, cb)
+    b.buf.copy_(torch.randn(N, 2 * h, 2 * w, cb, generator=g).half())
+    aa = a.act(8, ca)
+    seg = SegAct([UpAct(aa), b.act()])
+    if not eng.seg_conv_ok(sp, seg):
+        pytest.skip("this shape is not taken by the segmented kernel")
+    y1 = eng.conv_fused(sp, seg)
+    y0 = eng.conv_fused(sp, eng._concat_copy([eng._upsample_now(aa), b.act()]))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y1.st.buf.float()).all() and float(y1.st.buf.float().abs().max()) > 0
+    assert torch.equal(y1.st.buf, y0.st.buf), f"max diff {float((y1.st.buf.float() - y0.st.buf.float()).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("name,fuse,size", [("yolov8n-p2", True, 128), ("yolov8n-ASF-P2P2", False, 96), ("yolov8n-LD-P2", True, 64)])
+def test_models_without_the_upsample_launch_give_the_same_bits(name, fuse, size, monkeypatch):
+    from ultralytics.hip import engine as E
+    x = torch.rand(2, 3, size, size, generator=torch.Generator().manual_seed(3)).cuda()
+    outs = []
+    for on in (False, True):
+        monkeypatch.setattr(E, "UPSEG", on)
+        m = _model(name, fuse=fuse)
+        with torch.no_grad():
+            m(x)
+            y, _ = m(x)
+        plan = m._infer_plans["plans"][(2, 3, size, size)]
+        n_up = sum(1 for o in plan.rec.ops if o[2] == "dy_upsample2x")
+        assert (n_up == 0) == on, n_up
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
