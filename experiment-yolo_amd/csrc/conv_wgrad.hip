@@ -131,7 +131,11 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
   }
   const char* xb[XSEG ? NPX : 1];  // XSEG: where this thread's granule i lives (its segment's base at the granule's channel) ...
   int xl[XSEG ? NPX : 1];          // ... and that segment's pixel stride in bytes
-  (void)xb; (void)xl;
+  unsigned xup = 0;                // ... bit i: granule i's segment is a 2x nearest up-sampling of a (N, H/2, W/2) tensor (DySegs.acc = 2)
+  bool any_up = false;             // (kernel-uniform) some segment is
+  if (XSEG)
+    for (int k = 0; k < a.xs.nseg; ++k) any_up = any_up || (a.xs.acc[k] & 2);
+  (void)xb; (void)xl; (void)xup; (void)any_up;
   if (XSEG) {
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
       const bool ok = id < NGX && ch < a.cin_r8;
       xb[XSEG ? i : 0] = ok ? reinterpret_cast<const char*>(a.xs.ptr[sg]) + (ch - cb) * 2 : nullptr;
       xl[XSEG ? i : 0] = a.xs.ld[sg] * 2;
+      if (ok && (a.xs.acc[sg] & 2)) xup |= 1u << i;
     }
   }
 #pragma unroll
@@ -200,11 +205,29 @@ __global__ __launch_bounds__(256, (KS == 3 && NCI * MTC >= 16) ? 1 : 2) void con
       const unsigned ox = (unsigned)tile * (TH * TW) * a.ldx * 2u, oy = (unsigned)tile * (TH * TW) * a.lddy * 2u;
       if (XSEG) {
         const long p0 = (long)tile * (TH * TW);
+        // up-sampled members: pixel (n, y, x) of the concatenation reads (n, y >> 1, x >> 1) of the low-resolution tensor.  The tile's
+        // first pixel is decomposed once (uniform integer divisions), a lane's pixel lies < TH * TW further: exact float divisions
+        int n0 = 0, y0 = 0, x0 = 0;
+        if (any_up) {
+          const int hw = a.H * a.W, g0 = (int)p0;
+          n0 = g0 / hw;
+          const int r0 = g0 - n0 * hw;
+          y0 = r0 / a.W;
+          x0 = r0 - y0 * a.W;
+        }
+        const float invW = 1.0f / (float)a.W, invH = 1.0f / (float)a.H;
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
-          const long gp = p0 + (tid + i * 256) / CPGX;
+          const int lp = (tid + i * 256) / CPGX;
+          long gp = p0 + lp;
+          const bool inside = gp < a.npix;
+          if ((xup >> i) & 1u) {
+            const int xx = x0 + lp, dy_ = (int)(((float)xx + 0.5f) * invW), x = xx - dy_ * a.W;
+            const int yt = y0 + dy_, dn = (int)(((float)yt + 0.5f) * invH), y = yt - dn * a.H;
+            gp = ((long)(n0 + dn) * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1);
+          }
           const char* src = xb[XSEG ? i : 0];
-          pfx[i] = (src && gp < a.npix) ? *reinterpret_cast<const uint4*>(src + gp * xl[XSEG ? i : 0]) : make_uint4(0, 0, 0, 0);
+          pfx[i] = (src && inside) ? *reinterpret_cast<const uint4*>(src + gp * xl[XSEG ? i : 0]) : make_uint4(0, 0, 0, 0);
         }
       } else {
 #pragma unroll
@@ -671,7 +694,8 @@ extern "C" int dy_conv1x1_wgrad_bn_segs(const DySegs* xs, const void* dy, int ld
   if (!raw || !coef || !acc || (ldraw & 7) || ((uintptr_t)raw & 15) || ((uintptr_t)draw & 15) || (cout & 15)) return DY_ERR_ARG;
   if (!xs || xs->nseg < 1 || xs->nseg > DY_MAX_SEGS || xs->c_end[xs->nseg - 1] != cin) return DY_ERR_ARG;
   for (int k = 0; k < xs->nseg; ++k)
-    if ((xs->c_end[k] & 7) || (xs->ld[k] & 7) || !xs->ptr[k] || ((uintptr_t)xs->ptr[k] & 15) || xs->c_end[k] <= (k ? xs->c_end[k - 1] : 0)) return DY_ERR_ARG;
+    if ((xs->c_end[k] & 7) || (xs->ld[k] & 7) || !xs->ptr[k] || ((uintptr_t)xs->ptr[k] & 15) || xs->c_end[k] <= (k ? xs->c_end[k - 1] : 0) ||
+        ((xs->acc[k] & 2) && ((h | w) & 1))) return DY_ERR_ARG;  // (acc = 2: an up-sampled member, read at (y >> 1, x >> 1): DySegs)
   WgBnHost bn{raw, draw, coef, acc, dgamma, dbeta, ldraw, count};
   bn.xs = xs;
   return conv_wgrad_impl(xs->ptr[0], 8, dy, lddy, slabs, dw, n, h, w, cin, cout, 1, 1, accumulate, 0, 0, 0, stream, &bn);
@@ -690,7 +714,8 @@ extern "C" int dy_conv1x1_wgrad_bn_planes(const DySegs* xs, const void* x, int l
   if (xs) {
     if (xs->nseg < 1 || xs->nseg > DY_MAX_SEGS || xs->c_end[xs->nseg - 1] != cin) return DY_ERR_ARG;
     for (int k = 0; k < xs->nseg; ++k)
-      if ((xs->c_end[k] & 7) || (xs->ld[k] & 7) || !xs->ptr[k] || ((uintptr_t)xs->ptr[k] & 15) || xs->c_end[k] <= (k ? xs->c_end[k - 1] : 0)) return DY_ERR_ARG;
+      if ((xs->c_end[k] & 7) || (xs->ld[k] & 7) || !xs->ptr[k] || ((uintptr_t)xs->ptr[k] & 15) || xs->c_end[k] <= (k ? xs->c_end[k - 1] : 0) ||
+          ((xs->acc[k] & 2) && ((h | w) & 1))) return DY_ERR_ARG;
   }
   WgBnHost bn{raw, draw, coef, acc, dgamma, dbeta, ldraw, count};
   bn.xs = xs;

@@ -69,6 +69,9 @@ PLANAR_CV1 = os.environ.get("DY_PLANAR_CV1", "1") != "0"
 # behind the concatenation reads pixel (y >> 1, x >> 1) of the low-resolution tensor where it stages that member (UpAct; DySegs.acc = 2).
 # DY_UPSEG=0: dy_upsample2x writes the four-times-larger copy.
 UPSEG = os.environ.get("DY_UPSEG", "1") != "0"
+# ... in training too: forward and weight gradient read the low-resolution tensor, the input gradient of that member goes to a
+# full-resolution gradient tensor that Upsample's backward folds as before.  DY_UPSEG_TRAIN=0: training runs the up-sampling launch.
+UPSEG_TRAIN = UPSEG and os.environ.get("DY_UPSEG_TRAIN", "1") != "0"
 # Add's backward hands the sum's gradient buffer to an operand that has no other consumer instead of copying it (Engine.add).
 ADD_ALIAS = os.environ.get("DY_ADD_ALIAS", "1") != "0"
 # The Add that follows ScalSeq (ASF models) folded into ScalSeq's tail kernel as a residual operand (nn/tasks.py, forward_act).
@@ -163,6 +166,14 @@ class Storage:
         return Act(self, c0, self.C - c0 if C is None else C)
 
     @classmethod
+    def grad_only(cls, eng, N, H, W, C):
+        """A Storage that only ever holds a GRADIENT (an UpAct's: the up-sampled tensor itself is never written)."""
+        st = object.__new__(cls)
+        st.eng, st.N, st.H, st.W, st.C = eng, N, H, W, C
+        st.buf, st.gbuf, st.gwritten = None, None, []
+        return st
+
+    @classmethod
     def over(cls, eng, t):
         """Storage over an existing contiguous (N,H,W,C) tensor (a plan's static input)."""
         assert t.dim() == 4 and t.is_contiguous() and t.shape[3] % 8 == 0
@@ -197,7 +208,8 @@ class Act:
     def _gbuf(self):
         st = self.st
         if st.gbuf is None:
-            st.gbuf = st.eng.transient(tuple(st.buf.shape), st.buf.dtype)
+            st.gbuf = (st.eng.transient(tuple(st.buf.shape), st.buf.dtype) if st.buf is not None
+                       else st.eng.transient((st.N, st.H, st.W, st.C), torch.float16))
             st.eng.hold(st.gbuf)
         return st.gbuf
 
@@ -268,19 +280,37 @@ class ImageAct:
 
 
 class UpAct:
-    """``nn.Upsample(None, 2, 'nearest')`` of ``src`` that has not been executed (inference only: no gradient path).  As a member of a
-    SegAct the segmented 1x1 conv reads the low-resolution tensor directly; anything else asks ``Engine.dense`` to run the launch."""
-    needs_grad = False
+    """``nn.Upsample(None, 2, 'nearest')`` of ``src`` that has not been executed.  As a member of a SegAct the segmented 1x1 conv reads
+    the low-resolution tensor directly (forward and weight gradient); its input gradient goes to a full-resolution gradient tensor
+    of this object's own, which Upsample's backward (the 2x2 sums) folds into ``src``'s.  Anything else asks ``Engine.dense`` to run
+    the launch after all."""
 
     def __init__(self, src):
         self.src = src
         self.N, self.H, self.W, self.C = src.N, 2 * src.H, 2 * src.W, src.C
         self.st, self.c0 = src.st, src.c0  # (dtype checks look at the storage)
+        self.needs_grad = src.needs_grad
         self._full = None
+        self._g = None
 
     ld = property(lambda s: s.src.ld)
     ptr = property(lambda s: s.src.ptr)
     npix = property(lambda s: 4 * s.src.npix)
+
+    @property
+    def g(self):
+        if self._g is None:
+            self._g = Storage.grad_only(self.src.st.eng, self.N, self.H, self.W, self.C).act()
+        return self._g
+
+    gptr = property(lambda s: s.g.gptr)
+    gld = property(lambda s: s.g.ld)
+
+    def grad_target(self):
+        return self.g.grad_target()
+
+    def grad_ready(self):
+        return self.g.grad_ready()
 
 
 class SegAct:
@@ -683,8 +713,9 @@ class Engine:
         t.nseg, end = len(x.parts), 0
         for i, q in enumerate(x.parts):
             end += q.C
-            t.c_end[i], t.ld[i], t.ptr[i] = end, q.ld, (q.gptr if grad else q.ptr)
-            t.acc[i] = int(acc[i]) if acc is not None else (2 if isinstance(q, UpAct) else 0)
+            up = isinstance(q, UpAct)
+            t.c_end[i], t.ld[i], t.ptr[i] = end, (q.gld if (grad and up) else q.ld), (q.gptr if grad else q.ptr)
+            t.acc[i] = int(acc[i]) if acc is not None else (2 if (up and not grad) else 0)
         return t
 
     def seg_conv_ok(self, spec, x):
@@ -1298,8 +1329,20 @@ class Engine:
 
     def upsample2x(self, x: Act, out: Act | None = None):
         x = self.dense(x)
-        if (UPSEG and PLANAR and out is None and self.tape is None and not self.training and x.st.buf.dtype == torch.float16):
-            return UpAct(x)  # inference: left to the consumer (a Concat member read through the segment table, or Engine.dense)
+        if UPSEG and PLANAR and out is None and x.st.buf.dtype == torch.float16 and (self.tape is None or UPSEG_TRAIN):
+            # left to the consumer: a Concat member read through the segment table (or Engine.dense, which runs the launch after all)
+            up = UpAct(x)
+            if self.tape is not None and x.needs_grad:
+                self._use(x)
+
+                def bwd():
+                    if up._full is not None:  # it was executed after all: that launch's own closure carries the gradient
+                        return
+                    assert up.grad_ready(), "gradient of an up-sampled concat member incomplete"
+                    acc = x.grad_target()
+                    self.call("dy_upsample2x", up.gptr, up.gld, x.gptr, x.ld, x.N, x.H, x.W, x.C, 1, acc)
+                self.tape.append(bwd)
+            return up
         return self._upsample_now(x, out)
 
     def _upsample_now(self, x: Act, out: Act | None = None):
@@ -1425,10 +1468,11 @@ class Engine:
                         continue
                     acc = t.grad_target()
                     gsrc = y.gptr + 2 * o
+                    gl = t.gld if isinstance(t, UpAct) else t.ld  # (an UpAct's gradient tensor is full-resolution, of its own pitch)
                     if acc:
-                        self.call("dy_add", t.gptr, t.ld, gsrc, y.ld, 0, 0, t.gptr, t.ld, t.npix, t.C)
+                        self.call("dy_add", t.gptr, gl, gsrc, y.ld, 0, 0, t.gptr, gl, t.npix, t.C)
                     else:
-                        self.call("dy_copy_slice", gsrc, y.ld, t.gptr, t.ld, t.npix, t.C)
+                        self.call("dy_copy_slice", gsrc, y.ld, t.gptr, gl, t.npix, t.C)
             self.tape.append(bwd)
         return y
 

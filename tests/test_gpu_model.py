@@ -166,6 +166,34 @@ def test_cv1_halves_as_planes_are_the_same_step_bit_for_bit(golden, name, monkey
     assert torch.equal(outs[0][0], outs[1][0]), f"max diff {float((outs[0][0] - outs[1][0]).abs().max()):.3e}"
 
 
+@pytest.mark.parametrize("name", MODELS)
+def test_upsample_left_to_the_concat_consumer_is_the_same_step_bit_for_bit(golden, name, monkeypatch):
+    """nn.Upsample in front of a Concat never executed in TRAINING either (engine.UpAct, DY_UPSEG_TRAIN): the segmented 1x1 conv and its
+    weight-gradient kernel read the low-resolution tensor at (y >> 1, x >> 1), the member's input gradient lands in a full-resolution
+    gradient tensor that Upsample's backward folds as before -- the same values in the same order: loss items and ALL gradients EQUAL."""
+    from ultralytics.hip import engine as E
+    from ultralytics.hip.train import StepPlan
+    G = golden("models")
+    batch = {k: G.t(f"{name}/{k}") for k in ("img", "batch_idx", "cls", "bboxes")}
+    outs = []
+    for on in (False, True):
+        monkeypatch.setattr(E, "UPSEG_TRAIN", on)
+        m, _ = _build(name, MODELS.index(name))
+        plan = StepPlan(m, 2, 64, nmax=8, init_scale=1024.0)
+        plan.forward_backward(batch)
+        plan.forward_backward(batch)
+        torch.cuda.synchronize()
+        ups = [o for o in plan.rec_fb.ops if o[0] is not None and o[2] == "dy_upsample2x"]
+        assert len(ups) == (2 if on else 4), len(ups)  # two Upsample layers: forward + backward launches, or the backward ones alone
+        outs.append((plan.rt.flat_g.clone(), plan.crit.scalars.clone()))
+    assert torch.isfinite(outs[0][0]).all() and float(outs[0][0].abs().max()) > 0
+    if "LD" in name:
+        assert relerr(outs[0][1][5:9], outs[1][1][5:9]) < 1e-6 and relerr(outs[0][0], outs[1][0]) < 1e-4
+        return
+    assert torch.equal(outs[0][1][5:9], outs[1][1][5:9])
+    assert torch.equal(outs[0][0], outs[1][0]), f"max diff {float((outs[0][0] - outs[1][0]).abs().max()):.3e}"
+
+
 def test_optimizer_trace_vs_golden(golden):
     """5 SGD-nesterov steps (warm-up lr/momentum, clip 10, EMA) against the reference's own optimizer_step trace."""
     from golden.cases import synth_batch
