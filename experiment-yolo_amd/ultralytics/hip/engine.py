@@ -729,6 +729,17 @@ class Engine:
             return False
         return bool(self.L.dy_conv1x1_segs_supported(x.C, spec.cout, C.byref(self._segs(x))))
 
+    def snapshot(self, x):
+        """``x`` as one tensor for INSPECTION (a per-layer capture): a copy that never joins the backward pass -- a copy made by
+        ``dense`` registers a closure that hands ITS gradient on, and an inspection copy has no consumer to write one."""
+        if not isinstance(x, (SegAct, UpAct)):
+            return x
+        tape, self._tape = self._tape, None  # (not through the property: an empty tape there means "a new trace begins")
+        try:
+            return self._upsample_now(x.src) if isinstance(x, UpAct) else self._concat_copy(x.parts)
+        finally:
+            self._tape = tape
+
     def planes_ok(self, spec, x):
         """``spec`` (a 1x1 Conv + BatchNorm + SiLU) may write its output as two planes: the training forms that take them are the
         accumulator-statistics apply, the split backward reduce and the BatchNorm-in-the-weight-gradient kernel."""
@@ -754,7 +765,7 @@ class Engine:
         Acts pass through."""
         if isinstance(x, UpAct):
             if x._full is None:
-                x._full = self._upsample_now(x.src)
+                x._full = self._upsample_now(x.src, optional=True)
             return x._full
         return self._concat_copy(x.parts) if isinstance(x, SegAct) else x
 
@@ -1336,7 +1347,8 @@ class Engine:
                 self._use(x)
 
                 def bwd():
-                    if up._full is not None:  # it was executed after all: that launch's own closure carries the gradient
+                    if up._g is None or not up._g.st.gwritten:  # no segmented consumer wrote a gradient: it was executed after all
+                        assert up._full is not None, "an up-sampled tensor without a consumer"  # (that launch's closure carries it)
                         return
                     assert up.grad_ready(), "gradient of an up-sampled concat member incomplete"
                     acc = x.grad_target()
@@ -1345,12 +1357,16 @@ class Engine:
             return up
         return self._upsample_now(x, out)
 
-    def _upsample_now(self, x: Act, out: Act | None = None):
+    def _upsample_now(self, x: Act, out: Act | None = None, optional=False):
+        """``optional``: the copy of an UpAct that something asked for after all (a per-layer capture, a consumer that is not a
+        segmented conv) -- it may end up without a consumer of its own, i.e. without a gradient."""
         y = out if out is not None else self.new_act(x.N, 2 * x.H, 2 * x.W, x.C)
         self._use(x)
         self.call("dy_upsample2x", x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, 0, 0)
         if self.tape is not None:
             def bwd():
+                if optional and not y.st.gwritten:
+                    return
                 acc = x.grad_target()
                 self.call("dy_upsample2x", y.gptr, y.ld, x.gptr, x.ld, x.N, x.H, x.W, x.C, 1, acc)
             self.tape.append(bwd)

@@ -224,7 +224,7 @@ class BaseModel(HipModule):
             x = m.forward_act(x, dst) if dst is not None else m.forward_act(x)
             ys.append(x if m.i in self.save else None)
             if self.__dict__.get("_capture") is not None:  # tests: per-layer outputs (engine Acts) of this forward
-                self._capture.append(eng.dense(x) if isinstance(x, (SegAct, UpAct)) else x)
+                self._capture.append(eng.snapshot(x))
         return x
 
     def _export(self, rt, y):

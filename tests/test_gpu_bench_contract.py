@@ -74,7 +74,7 @@ def test_bench_gpus_2_from_a_plain_python_start():
     env.pop("WORLD_SIZE", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
                         "--imgsz", "320", "--lr", "0.0005", "--no-cpu", "--probe", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.returncode == 0, p.stderr[-8000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-1000:]
     d = json.loads(lines[0])
