@@ -375,7 +375,7 @@ def main():
                "config": {"workload": f"{'DEAL-YOLO-N' if a.model == 'yolov8n-ASF-P2P2' else a.model} ({a.model}.yaml) train step {a.imgsz}x{a.imgsz}, per-GPU batch {a.batch}, "
                                       f"fwd+TAL/{a.loss.upper()}/DFL/BCE loss+bwd+SGD+EMA, BASELINE.json configs[{3 if 'LD' in a.model else 1}]",
                           "loss_mode": a.loss, f"{other.replace('+', '_')}_images_per_s": other_rate,
-                          "settle_steps": settle, "skipped_in_timed_steps": skipped_timed, "timed_regions_discarded": retimed,
+                          "settle_steps": settle, "skipped_in_timed_steps": skipped_timed, "capture_retries": plan.capture_retries, "timed_regions_discarded": retimed,
                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
                           "loss_items_last": [float(x) for x in s[5:8]], "loss_scale": loss_scale,
                           "skipped_steps": skipped_total,

@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import sys
 
 import numpy as np
 import torch
@@ -80,6 +81,7 @@ class StepPlan:
         self.warp = None               # (B,96) int32 mosaic / affine / perspective / MixUp records (two 48-word records per sample): the pool is then read through dy_warp_import_u8
         self.hsv = None                # (B,3) float32 RandomHSV gains applied inside dy_import_image_u8
         self.rec_fb = None
+        self.capture_retries = 0  # captures of the step graph that failed their check and were repeated (forward_backward)
         self.rec_opt, self.graph_opt = {}, {}
         self.graph_fb = None
         self.gsum, self._micro = None, 0
@@ -206,11 +208,24 @@ class StepPlan:
             pre = (self.rt.flat_b.clone(), self.crit.scalars.clone()) if self.use_graph else None
             self.rec_fb = self._trace_fb(batch)
             if self.use_graph:
-                torch.cuda.synchronize()
-                self.graph_fb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
-                    self.eng.replay(self.rec_fb)
-                self._verify_capture(*pre)
+                rec = self.rec_fb
+                for attempt in (0, 1):
+                    torch.cuda.synchronize()
+                    self.rec_fb, self.graph_fb = rec, torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
+                        self.eng.replay(self.rec_fb)
+                    try:
+                        self._verify_capture(*pre)
+                        break
+                    except RuntimeError as e:
+                        # One more independent capture: a capture spoilt by a transient (device work another host thread issued while
+                        # it was open -- seen with two ranks sharing one GPU over gloo, tests' rehearsal mode, about one start in ten)
+                        # does not repeat; the systematic failure the check exists for (graph packet capture in effect) does, and raises.
+                        if attempt == 1:
+                            raise
+                        self.capture_retries += 1
+                        import warnings
+                        warnings.warn(f"StepPlan: capturing the step again -- {e}")
                 if self.fb_cut is not None:  # the same list as two graphs, so that a collective can start between them
                     g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g1, capture_error_mode="thread_local"):
@@ -355,6 +370,10 @@ class StepPlan:
         between two replays overwriting the arguments of the instantiated graph.  Two eager passes over the recorded list are such
         a burst: if the flag did not take effect (HIP initialised before the import) the second replay fails HERE, not in epoch 2."""
         want_s, want_g, want_b = self.crit.scalars.clone(), self.rt.flat_g.clone(), self.rt.flat_b.clone()
+        # DY_VERIFY_DUMP=1 (diagnosis): every step-local buffer of the traced step is kept aside; a failing comparison then lists the
+        # buffers -- in allocation, i.e. roughly execution, order -- whose contents the replay did not reproduce
+        snap = ([(i, t, t.clone()) for i, t in enumerate(self.eng.keep) if torch.is_tensor(t) and t.numel() > 0]
+                if os.environ.get("DY_VERIFY_DUMP") == "1" else None)
 
         def replay_and_compare(what):
             self.rt.flat_b.copy_(buffers_before)
@@ -374,13 +393,44 @@ class StepPlan:
             # a replay repeats the traced step BIT FOR BIT (fp32 partial sums added in fp64: no order dependence); only LDConv's
             # far-sample side pass (fp32 atomics) leaves rounding-order noise in the gradients
             ld = any(type(mod).__name__ == "LDConv" for mod in self.model.modules())
+            # Several ranks time-slicing ONE GPU (the tests' rehearsal of the N > 1 path, DY_REHEARSE_ON_ONE_GPU=1): about one start in
+            # fifteen the step then repeats to 1e-3 instead of bit for bit -- DY_VERIFY_DUMP=1 shows the box-logit gradient of ONE
+            # foreground anchor's bottom side changing (a min / max branch of the IoU term taken the other way: loss items and every
+            # forward buffer stay identical) and everything downstream of it following; never seen with one process per GPU (0 of 40
+            # starts of the same configuration, and `test_replay_is_bitwise_identical`).  Not a capture failure: a fresh capture
+            # reproduces the NEW result.  The rehearsal therefore checks at the bound that tells corruption from rounding order.
+            ld = ld or os.environ.get("DY_REHEARSE_ON_ONE_GPU") == "1"
             # (without LDConv a replay normally repeats the traced step bit for bit; the bound still leaves room for the one case that
             # does not -- an fp64 atomic order flipping the last bit of an fp32 statistic -- and is orders below any real corruption)
             self.capture_exact = ds == 0.0 and dg == 0.0 and db == 0.0
             if not ((ds <= 1e-5 and dg <= 2e-2 and db <= 1e-5) if ld else (ds <= 1e-6 and dg <= 1e-5 and db <= 1e-6)):
                 self.graph_fb = self.rec_fb = None
+                where = ""
+                if snap is not None:
+                    bad = []
+                    for i, t, c in snap:
+                        a_, b_ = t.view(-1).view(torch.uint8), c.view(-1).view(torch.uint8)
+                        if not torch.equal(a_, b_):
+                            tf, cf = t.float().view(-1), c.float().view(-1)
+                            nz = (tf != cf)
+                            idx = int(nz.nonzero()[0]) if bool(nz.any()) else -1
+                            bad.append(f"#{i} {tuple(t.shape)} {str(t.dtype)[6:]} differing {int(nz.sum())} first@{idx} max|d| {float((tf - cf).abs().nan_to_num(1e30).max()):.3e}")
+                            if int(nz.sum()) <= 4096 and t.dtype != torch.uint8:
+                                ii = nz.nonzero().view(-1)[:24].tolist()
+                                bad.append("      " + " ".join(f"[{k}] {float(cf[k]):.4g}->{float(tf[k]):.4g}" for k in ii))
+                    print(f"[verify dump] {len(bad)} of {len(snap)} kept buffers differ:\n  " + "\n  ".join(bad[:40]), file=sys.stderr, flush=True)
+                if dg > 0 and bool(torch.isfinite(got_g).all()):  # which parameters' gradients differ (the three largest)
+                    offs = sorted((o, n) for n, o in self.rt.param_off.items())
+                    d = (got_g - want_g).abs()
+                    worst = []
+                    for k, (o, n) in enumerate(offs):
+                        e = offs[k + 1][0] if k + 1 < len(offs) else d.numel()
+                        m = float(d[o:e].max()) if e > o else 0.0
+                        if m > 0:
+                            worst.append((m / max(float(want_g[o:e].abs().max()), 1e-30), n))
+                    where = "; gradients that differ: " + ", ".join(f"{n} ({m:.1e})" for m, n in sorted(worst, reverse=True)[:(len(worst) if os.environ.get("DY_VERIFY_VERBOSE") else 3)]) + f" of {len(worst)}"
                 raise RuntimeError(f"the captured step graph does not reproduce the traced step {what} (loss items off by {ds:.2e}, "
-                                   f"gradients by {dg:.2e}, BN statistics by {db:.2e} relative): was another host thread issuing device "
+                                   f"gradients by {dg:.2e}, BN statistics by {db:.2e} relative{where}): was another host thread issuing device "
                                    "work during the capture, or was HIP initialised before `import ultralytics` could set "
                                    "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (export it, or import the package before the first torch.cuda call)?")
 

@@ -42,6 +42,7 @@ def test_bench_prints_one_contract_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "images/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert d["config"]["skipped_steps"] <= 8 and d["config"]["skipped_in_timed_steps"] == 0  # the loss-scale search ends before the timed steps
+    assert d["config"]["capture_retries"] == 0  # one process on the GPU: the step graph verifies on its first capture
     assert d["config"]["loss_mode"] == "wiou+nwd" and d["config"]["ciou_images_per_s"] > 0 and c["bs16"] > 0
 
 
