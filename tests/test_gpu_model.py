@@ -194,6 +194,35 @@ def test_upsample_left_to_the_concat_consumer_is_the_same_step_bit_for_bit(golde
     assert torch.equal(outs[0][0], outs[1][0]), f"max diff {float((outs[0][0] - outs[1][0]).abs().max()):.3e}"
 
 
+@pytest.mark.parametrize("name", [MODELS[0], "yolov8n-p2"])
+def test_per_layer_capture_does_not_touch_the_gradients(golden, name):
+    """``model._capture = []`` (the per-layer outputs some parity tests read) takes inspection copies of concatenations / lazily
+    up-sampled tensors (Engine.snapshot): they never join the backward pass, so the step's gradients are the bits of the step without
+    a capture.  (A copy made through Engine.dense registered a closure that handed an unwritten gradient on.)"""
+    from golden.cases import synth_batch
+    from ultralytics.hip.train import StepPlan
+    from ultralytics.nn.tasks import DetectionModel
+    p = os.path.join(CFG_DIR, name + ".yaml")
+    g = og.build_graph(og.load_yaml(p))
+    batch = synth_batch(5, 2, 4, g.nc)
+    outs = []
+    for cap in (False, True):
+        m = DetectionModel(p, ch=3, verbose=False)
+        m.load_state_dict(og.fill_state(og.state_layout(g), 10), strict=True)
+        m.cuda().train()
+        plan = StepPlan(m, 2, 64, nmax=8, init_scale=1.0)
+        if cap:
+            m._capture = []
+        plan.forward_backward(batch)
+        torch.cuda.synchronize()
+        if cap:
+            assert len(m._capture) == len(m.model)
+            m._capture = None
+        outs.append(plan.rt.flat_g.clone())
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
+    assert torch.equal(outs[0], outs[1]), f"max diff {float((outs[0] - outs[1]).abs().max()):.3e}"
+
+
 def test_optimizer_trace_vs_golden(golden):
     """5 SGD-nesterov steps (warm-up lr/momentum, clip 10, EMA) against the reference's own optimizer_step trace."""
     from golden.cases import synth_batch
