@@ -407,6 +407,8 @@ class StepPlan:
                 self.graph_fb = self.rec_fb = None
                 where = ""
                 if snap is not None:
+                    print(f"[verify dump] scalars traced {[f'{v:.9g}' for v in want_s.tolist()]}\n[verify dump] scalars replay {[f'{v:.9g}' for v in got_s.tolist()]}"
+                          f"\n[verify dump] state {[f'{v:.9g}' for v in self.state.tolist()]}", file=sys.stderr, flush=True)
                     bad = []
                     for i, t, c in snap:
                         a_, b_ = t.view(-1).view(torch.uint8), c.view(-1).view(torch.uint8)
