@@ -208,19 +208,22 @@ class StepPlan:
             pre = (self.rt.flat_b.clone(), self.crit.scalars.clone()) if self.use_graph else None
             self.rec_fb = self._trace_fb(batch)
             if self.use_graph:
-                rec = self.rec_fb
+                rec = self.rec_last = self.rec_fb  # (rec_last: kept for diagnosis when the check below drops rec_fb)
+                torch.cuda.synchronize()
+                want = (self.crit.scalars.clone(), self.rt.flat_g.clone(), self.rt.flat_b.clone())  # what the TRACED step left
                 for attempt in (0, 1):
                     torch.cuda.synchronize()
                     self.rec_fb, self.graph_fb = rec, torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
                         self.eng.replay(self.rec_fb)
                     try:
-                        self._verify_capture(*pre)
+                        self._verify_capture(*pre, want=want)
                         break
                     except RuntimeError as e:
-                        # One more independent capture: a capture spoilt by a transient (device work another host thread issued while
-                        # it was open -- seen with two ranks sharing one GPU over gloo, tests' rehearsal mode, about one start in ten)
-                        # does not repeat; the systematic failure the check exists for (graph packet capture in effect) does, and raises.
+                        # One more independent capture, checked against the same traced reference.  What this absorbs was seen with
+                        # two processes sharing one GPU only: ONE execution of the step -- a replay, never the same one
+                        # twice -- leaves the box-logit gradient of one anchor's bottom side different; the next execution is clean
+                        # again.  The systematic failure the check exists for (graph packet capture in effect) repeats, and raises.
                         if attempt == 1:
                             raise
                         self.capture_retries += 1
@@ -361,7 +364,7 @@ class StepPlan:
         from .engine import ImageAct  # fp32 NCHW (the trainer's ``batch["img"].float() / 255``): a Conv(3->16, 3, 2) stem reads it directly
         return ImageAct(eng, self.img)
 
-    def _verify_capture(self, buffers_before, scalars_before):
+    def _verify_capture(self, buffers_before, scalars_before, want=None):
         """Replay the freshly captured forward/backward graph on the traced batch -- from the state the traced step started from
         (BN running statistics, WIoU running mean), so nothing is applied twice -- and require it to reproduce the traced step;
         then once more after a burst of ordinary launches.  A graph can be broken without any error on this ROCm, two ways
@@ -369,7 +372,7 @@ class StepPlan:
         runtime's graph packet capture on, which hip/__init__.py turns off at import -- ~1,000 ordinary launches of this library
         between two replays overwriting the arguments of the instantiated graph.  Two eager passes over the recorded list are such
         a burst: if the flag did not take effect (HIP initialised before the import) the second replay fails HERE, not in epoch 2."""
-        want_s, want_g, want_b = self.crit.scalars.clone(), self.rt.flat_g.clone(), self.rt.flat_b.clone()
+        want_s, want_g, want_b = want if want is not None else (self.crit.scalars.clone(), self.rt.flat_g.clone(), self.rt.flat_b.clone())
         # DY_VERIFY_DUMP=1 (diagnosis): every step-local buffer of the traced step is kept aside; a failing comparison then lists the
         # buffers -- in allocation, i.e. roughly execution, order -- whose contents the replay did not reproduce
         snap = ([(i, t, t.clone()) for i, t in enumerate(self.eng.keep) if torch.is_tensor(t) and t.numel() > 0]
@@ -393,13 +396,6 @@ class StepPlan:
             # a replay repeats the traced step BIT FOR BIT (fp32 partial sums added in fp64: no order dependence); only LDConv's
             # far-sample side pass (fp32 atomics) leaves rounding-order noise in the gradients
             ld = any(type(mod).__name__ == "LDConv" for mod in self.model.modules())
-            # Several ranks time-slicing ONE GPU (the tests' rehearsal of the N > 1 path, DY_REHEARSE_ON_ONE_GPU=1): about one start in
-            # fifteen the step then repeats to 1e-3 instead of bit for bit -- DY_VERIFY_DUMP=1 shows the box-logit gradient of ONE
-            # foreground anchor's bottom side changing (a min / max branch of the IoU term taken the other way: loss items and every
-            # forward buffer stay identical) and everything downstream of it following; never seen with one process per GPU (0 of 40
-            # starts of the same configuration, and `test_replay_is_bitwise_identical`).  Not a capture failure: a fresh capture
-            # reproduces the NEW result.  The rehearsal therefore checks at the bound that tells corruption from rounding order.
-            ld = ld or os.environ.get("DY_REHEARSE_ON_ONE_GPU") == "1"
             # (without LDConv a replay normally repeats the traced step bit for bit; the bound still leaves room for the one case that
             # does not -- an fp64 atomic order flipping the last bit of an fp32 statistic -- and is orders below any real corruption)
             self.capture_exact = ds == 0.0 and dg == 0.0 and db == 0.0
@@ -421,6 +417,22 @@ class StepPlan:
                                 ii = nz.nonzero().view(-1)[:24].tolist()
                                 bad.append("      " + " ".join(f"[{k}] {float(cf[k]):.4g}->{float(tf[k]):.4g}" for k in ii))
                     print(f"[verify dump] {len(bad)} of {len(snap)} kept buffers differ:\n  " + "\n  ".join(bad[:40]), file=sys.stderr, flush=True)
+                    refp = os.environ.get("DY_VERIFY_REF")  # the same buffers saved by a clean process (scratch tooling): is it the TRACED
+                    if refp and os.path.exists(refp):       # step or the replay that left the reference?
+                        ref = torch.load(refp)
+                        for tag, pick in (("traced", lambda t, c: c), ("replay", lambda t, c: t)):
+                            out = []
+                            for i, t, c in snap:
+                                r = ref.get(f"keep{i}")
+                                v = pick(t, c).detach().cpu()
+                                if r is None or r.shape != v.shape or r.dtype != v.dtype or v.dtype == torch.uint8 or v.dtype == torch.float64:
+                                    continue
+                                if not torch.equal(v.view(-1).view(torch.uint8), r.view(-1).view(torch.uint8)):
+                                    vf, rf = v.float().view(-1), r.float().view(-1)
+                                    nz = (vf != rf).nonzero().view(-1)
+                                    out.append(f"#{i} {tuple(v.shape)} differing {nz.numel()} first@{int(nz[0]) if nz.numel() else -1} "
+                                               + " ".join(f"[{k}] {float(rf[k]):.7g}->{float(vf[k]):.7g}" for k in nz[:6].tolist()))
+                            print(f"[verify dump] {tag} step vs the clean reference: {len(out)} buffers differ\n  " + "\n  ".join(out[:12]), file=sys.stderr, flush=True)
                 if dg > 0 and bool(torch.isfinite(got_g).all()):  # which parameters' gradients differ (the three largest)
                     offs = sorted((o, n) for n, o in self.rt.param_off.items())
                     d = (got_g - want_g).abs()
