@@ -69,6 +69,11 @@ PLANAR_CV1 = os.environ.get("DY_PLANAR_CV1", "1") != "0"
 # behind the concatenation reads pixel (y >> 1, x >> 1) of the low-resolution tensor where it stages that member (UpAct; DySegs.acc = 2).
 # DY_UPSEG=0: dy_upsample2x writes the four-times-larger copy.
 UPSEG = os.environ.get("DY_UPSEG", "1") != "0"
+# Weight gradients of SMALL maps (N*H*W <= DY_SIDE_SMALL pixels) on the side stream beside the input-gradient chain: there a launch is
+# mostly fixed latency and leaves CUs idle (profiles/r04_stage_ab.md), so the layer gives up the BatchNorm-in-the-weight-gradient fusion
+# (a separate backward-apply launch writes d(raw)) to take its weight gradient off the critical path.  0 (default): off -- MEASURED
+# SLOWER (round 4, one box): 11.33 ms off, 11.66 for maps <= 40x40, 11.99 <= 80x80, 12.17 <= 160x160 (profiles/r04_stage_ab.md).
+SIDE_SMALL = int(os.environ.get("DY_SIDE_SMALL", "0"))
 # ... in training too: forward and weight gradient read the low-resolution tensor, the input gradient of that member goes to a
 # full-resolution gradient tensor that Upsample's backward folds as before.  DY_UPSEG_TRAIN=0: training runs the up-sampling launch.
 UPSEG_TRAIN = UPSEG and os.environ.get("DY_UPSEG_TRAIN", "1") != "0"
@@ -410,6 +415,7 @@ class Engine:
 
     # ---- two-stream plumbing: fork = "side waits for everything issued on main so far", join = "main waits for side" ----
     side_wgrad = False      # StepPlan switches it on for its backward trace
+    _side_used = False      # a weight gradient of this backward pass went to the side stream (SIDE_SMALL): flush_wgrad joins
     cur_sid = 0             # stream id launches go to (0 = the caller's current stream); set by ``branch`` / ``_on``
     _side_streams = None
     _FORK, _JOIN = "<fork>", "<join>"
@@ -1007,14 +1013,16 @@ class Engine:
                       spec.cout, spec.act, C.byref(n))
             self.call("dy_bn_bwd_finalize", part.data_ptr(), n.value, spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(),
                       spec.bwdcoef.data_ptr(), spec.cout, float(npix), 0)
-        if (self.side_wgrad and self.deferred_wgrad is not None) or self.cur_sid:
+        side_small = bool(SIDE_SMALL and npix <= SIDE_SMALL and self.deferred_wgrad is not None and not self.cur_sid and not self.side_wgrad
+                          and acc and isinstance(x, Act) and x.needs_grad and spec.ld is None)
+        if ((self.side_wgrad or side_small) and self.deferred_wgrad is not None) or self.cur_sid:
             # the weight gradient reads this buffer on the side stream while the main stream moves on to the next layer (or this
             # layer's backward runs on a branch beside the main chain's): it cannot be the shared scratch
             draw = self.transient((npix * spec.cout,), torch.float16)
             self.hold(draw)
         else:
             draw = self.scratch("draw", npix * spec.cout * 2)
-        if acc and BN_WGRAD and spec.act == DY_ACT_SILU and not self.side_wgrad and raw.ld == spec.cout:
+        if acc and BN_WGRAD and spec.act == DY_ACT_SILU and not self.side_wgrad and not side_small and raw.ld == spec.cout:
             # no apply launch: the weight-gradient kernel forms d(raw) while staging and leaves it in ``draw`` for the dgrad
             bn = (raw, draw, spec.coef.data_ptr(), spec.acc_b.data_ptr(), spec.gbn_w.data_ptr(), spec.gbn_b.data_ptr(), float(npix))
             self._conv_bwd(spec, x, y.gptr, y.ld, y.H, y.W, bn=bn)
@@ -1025,9 +1033,9 @@ class Engine:
         else:
             self.call("dy_bn_act_bwd_apply", y.gptr, y.ld, raw.ptr, raw.ld, draw.data_ptr(), spec.cout, spec.coef.data_ptr(),
                       spec.bwdcoef.data_ptr(), npix, spec.cout, spec.act, 0)
-        self._conv_bwd(spec, x, draw.data_ptr(), spec.cout, y.H, y.W)
+        self._conv_bwd(spec, x, draw.data_ptr(), spec.cout, y.H, y.W, side_hint=side_small)
 
-    def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0, defer=True, bn=None, bias_acc=None, planes=None):
+    def _conv_bwd(self, spec, x, dy_ptr, lddy, Ho, Wo, accumulate_w=0, defer=True, bn=None, bias_acc=None, planes=None, side_hint=False):
         """weight gradient + input gradient of one convolution given d(raw output) (fp16, (N,Ho,Wo,lddy)).
         When the engine is collecting (``self.deferred_wgrad`` is a list: StepPlan's backward trace) the per-workgroup slabs of
         this layer are kept and reduced together with every other layer's by ONE ``dy_wgrad_reduce_batched`` launch at the end
@@ -1045,8 +1053,9 @@ class Engine:
             dw = spec.gweight.data_ptr()
         # deferred weight gradients are off the critical path (needed only by the batched reduction at the end of the
         # backward pass): with ``side_wgrad`` they run on the side stream beside the input-gradient chain
-        side = deferred and self.side_wgrad
+        side = deferred and (self.side_wgrad or side_hint)
         if side:
+            self._side_used = True
             self.fork()
         if planes is not None:  # dY in two planes (dy_ptr, planes[0]), split at channel planes[1]; x a tensor or a concatenation
             raw, draw, coef, accb, gw, gb, cnt = bn
@@ -1114,8 +1123,9 @@ class Engine:
     def flush_wgrad(self):
         """Reduce the slabs of every deferred layer into its fp32 weight gradient: one launch, one descriptor per layer."""
         items, self.deferred_wgrad = self.deferred_wgrad, None
-        if self.side_wgrad:
+        if self.side_wgrad or self._side_used:
             self.join()
+            self._side_used = False
         if not items:
             return
         sz = self.L.dy_wgrad_reduce_desc_bytes()
