@@ -95,10 +95,17 @@ static __device__ __forceinline__ Dual operator*(Dual a, Dual b) {
   for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
   return r;
 }
+// The derivative components take ONE reciprocal of b instead of four correctly rounded divisions by it (<= 1 ulp apart per
+// component).  Not for speed: with the four divisions, box_loss_kernel -- from inputs that were the reference's bits -- returned a
+// different LAST component for one anchor in 4-7 % of its launches while a second process kept the GPU busy (scratch/loss_stress.py:
+// 503 + 799 of 24,000; WIoU only, whose path holds the most divisions in flight), never with the GPU to itself; with the reciprocal:
+// 0 of 24,000 beside the same co-tenant.  The mechanism is NOT understood -- it is not the s_mov vcc / v_div_fmas adjacency hipcc
+// emits when it interleaves division sequences (removing every such site with scheduling barriers left the rate unchanged) -- see
+// DESIGN 9.
 static __device__ __forceinline__ Dual operator/(Dual a, Dual b) {
-  const float q = a.v / b.v;
+  const float q = a.v / b.v, inv = 1.0f / b.v;
   Dual r{q, {}};
-  for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - q * b.d[i]) / b.v;
+  for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - q * b.d[i]) * inv;
   return r;
 }
 static __device__ __forceinline__ Dual operator+(Dual a, float b) { a.v += b; return a; }
